@@ -1,0 +1,208 @@
+/* rtr.h — C ABI of librtr_hip.so, the MI355X-native replacement for the reference's
+ * Vulkan dispatch + GLSL ray-tracing pipeline.
+ *
+ * The reference has no plugin / FFI interface: Application::run() talks to its Vulkan
+ * wrappers directly (reference src/app/application.cppm:99-484).  The boundary cut here is
+ * "everything run() hands to the GPU and everything it reads back" (SURVEY.md §8b).  Each
+ * entry point cites the reference code it replaces.  Plain pointers and sizes only; no
+ * C++/torch types; no exceptions cross this boundary (every call returns an rtr_status and
+ * rtr_last_error() gives the thread-local message — the C++ shim in
+ * realtimeraytracer_amd/csrc/host rethrows std::runtime_error to keep the reference's
+ * caller-visible convention, src/main.cpp:12-15).
+ *
+ * Threading: handles are not thread-safe; one rtr_ctx per device; calls are synchronous
+ * unless stated (reference is single-threaded with waitIdle between passes,
+ * src/app/application.cppm:353,396,437).
+ */
+#ifndef RTR_H
+#define RTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rtr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTR_ABI_VERSION 1
+
+typedef enum rtr_status {
+    RTR_OK = 0,
+    RTR_ERR_INVALID_ARGUMENT = -1,
+    RTR_ERR_HIP = -2,            /* a HIP runtime call failed (message has hipGetErrorString) */
+    RTR_ERR_NO_DEVICE = -3,
+    RTR_ERR_UNSUPPORTED = -4,    /* feature on a "next" row (textures, HDRI) requested */
+    RTR_ERR_OUT_OF_MEMORY = -5,
+    RTR_ERR_BVH_TOO_DEEP = -6,   /* traversal stack bound exceeded; fail loudly, never clamp */
+    RTR_ERR_IO = -7
+} rtr_status;
+
+typedef struct rtr_ctx   rtr_ctx;    /* one per device: replaces Instance/Device/CommandPool (src/vulkan/context/) */
+typedef struct rtr_scene rtr_scene;  /* replaces vertex/index/info buffers + BLAS[] + TLAS (src/app/application.cppm:230-271) */
+typedef struct rtr_frame rtr_frame;  /* replaces the storage images of descriptor set 0 (src/app/application.cppm:108-138) */
+
+/* Which image of the reference's descriptor set 0 (src/shaders/raygen.rgen:12-16;
+ * binding numbers kept).  All are R8G8B8A8_UNORM with bytes B,G,R,255 as raygen stores them. */
+typedef enum rtr_image {
+    RTR_IMAGE_ANALYTIC = 0,           /* binding 0: LTC analytic, needs LTC tables */
+    RTR_IMAGE_SHADOWED = 1,           /* binding 1: THE framebuffer of the north-star path */
+    RTR_IMAGE_UNSHADOWED = 2,         /* binding 2 */
+    RTR_IMAGE_DENOISED_SHADOWED = 3,  /* binding 3 (denoise.comp output) */
+    RTR_IMAGE_DENOISED_UNSHADOWED = 4,/* binding 4 */
+    RTR_IMAGE_FINAL = 5,              /* binding 5 (combine.comp output) */
+    RTR_IMAGE_NORMAL = 6,             /* binding 6 */
+    RTR_IMAGE_POSITION = 7,           /* binding 7 */
+    RTR_IMAGE_HDR = 16                /* float4 pre-tonemap accumulation of SHADOWED (build-side extension) */
+} rtr_image;
+
+/* Bit mask of images a frame owns / a render call writes. */
+#define RTR_IMG_BIT(which) (1u << (which))
+#define RTR_IMAGES_FRAMEBUFFER (RTR_IMG_BIT(RTR_IMAGE_SHADOWED))
+#define RTR_IMAGES_RAYGEN5 (RTR_IMG_BIT(RTR_IMAGE_ANALYTIC) | RTR_IMG_BIT(RTR_IMAGE_SHADOWED) | \
+                            RTR_IMG_BIT(RTR_IMAGE_UNSHADOWED) | RTR_IMG_BIT(RTR_IMAGE_NORMAL) | \
+                            RTR_IMG_BIT(RTR_IMAGE_POSITION))
+#define RTR_IMAGES_DENOISE (RTR_IMG_BIT(RTR_IMAGE_DENOISED_SHADOWED) | RTR_IMG_BIT(RTR_IMAGE_DENOISED_UNSHADOWED) | \
+                            RTR_IMG_BIT(RTR_IMAGE_FINAL))
+
+/* What Application::run() uploads once (src/app/application.cppm:226-271,
+ * src/app/setup/geometry_builder.cppm:50-212, src/vulkan/raytracing/tlas.cppm:44-149).
+ * The library copies everything; the caller keeps ownership of its arrays. */
+typedef struct rtr_scene_desc {
+    const RtrVertex*        vertices;      uint32_t numVertices;   /* Vertex SSBO, application.cppm:242-248 */
+    const uint32_t*         indices;       uint32_t numIndices;    /* mesh-local indices, geometry_builder.cppm:162-169 */
+    const RtrMesh*          meshes;        uint32_t numMeshes;     /* one per BLAS */
+    const RtrInstance*      instances;     uint32_t numInstances;  /* TLAS instances: lights first, then objects */
+    const RtrObjectInfo*    objects;       uint32_t numObjects;    /* ObjectInfo SSBO, application.cppm:254-261 */
+    const RtrAreaLightInfo* lights;        uint32_t numLights;     /* LightInfo SSBO, application.cppm:264-271 */
+    /* texSamplers[0], [1]: 64x64 RGBA32F LTC tables (src/app/setup/create_scene.cppm:65-69,162-214).
+     * NULL -> RTR_IMAGE_ANALYTIC cannot be rendered (RTR_ERR_UNSUPPORTED if asked for). */
+    const float*            ltc1;          /* 64*64*4 floats or NULL */
+    const float*            ltc2;          /* 64*64*4 floats or NULL */
+    /* miss.rmiss:21-26 samples an equirect HDRI; until the texture row lands the sky is this
+     * constant (sRGB-encoded, ToLinear applied as the miss shader does). */
+    float                   skyColor[3];
+    float                   _pad;
+} rtr_scene_desc;
+
+typedef struct rtr_scene_stats {
+    uint32_t numTriangles;
+    uint32_t numNodes;
+    uint32_t maxDepth;        /* deepest leaf, root = 1 */
+    uint32_t maxLeafSize;
+    uint32_t bvhLayoutVersion;
+    uint32_t stackEntries;    /* LDS stack entries per lane the kernels were specialised for */
+    float    buildMs;
+    float    sahCost;
+    float    boundsMin[3];
+    float    boundsMax[3];
+    float    boxPad;
+    float    _pad;
+} rtr_scene_stats;
+
+/* Per-dispatch arguments: what the reference passes as the traceRaysKHR extent + the two
+ * shader constants (src/vulkan/ray_tracing_pipeline.cppm:212-214, src/shaders/raygen.rgen:8-9),
+ * plus the band sharding and accumulation that are new in this build. */
+typedef struct rtr_render_params {
+    uint32_t width;            /* full frame width  (dispatch extent x) */
+    uint32_t height;           /* full frame height (dispatch extent y) */
+    uint32_t spp;              /* NUM_PRIMARY_RAYS (reference: 4) */
+    uint32_t numShadowRays;    /* NUM_SHADOW_RAYS  (reference: 3) */
+    uint32_t images;           /* mask of RTR_IMG_BIT(...) to produce; 0 -> RTR_IMAGES_FRAMEBUFFER */
+    uint32_t bandRows;         /* rows per band; 0 -> 8 */
+    uint32_t shardIndex;       /* this device renders bands b with b % shardCount == shardIndex */
+    uint32_t shardCount;       /* 0 or 1 -> whole frame */
+    uint32_t accumulate;       /* 0: HDR = this frame; 1: HDR += this frame (needs RTR_IMAGE_HDR in the frame) */
+    uint32_t accumulatedFrames;/* frames already summed in HDR (tonemap divides by accumulatedFrames+1) */
+    uint32_t collectStats;     /* 1: run the counting variants of the kernels and fill rtr_frame_stats counters */
+    uint32_t pipeline;         /* 0: default; 1: megakernel; 2: wavefront (staged) */
+} rtr_render_params;
+
+typedef struct rtr_frame_stats {
+    /* exact work counters of the last render with collectStats=1 */
+    uint64_t numRays;          /* every traceRay-equivalent issued: primary + shadow */
+    uint64_t numPrimaryRays;
+    uint64_t numShadowRays;
+    uint64_t numNodeVisits;    /* N_node: 64-B node fetches */
+    uint64_t numTriTests;      /* N_tri : 48-B triangle record fetches */
+    uint64_t numHits;          /* N_hit : closest-hit shading fetches (236 B each) */
+    uint64_t numLightFetches;  /* N_lightfetch: LightInfo reads (96 B each) */
+    uint64_t numLightTriFetches;/* light triangle vertex fetches (3 idx + 3 x 48 B = 156 B each) */
+    uint64_t algorithmicBytes; /* B = 64 N_node + 48 N_tri + 236 N_hit + 96 N_lf + 156 N_ltf + 4 k P (+32 P if HDR RMW) */
+    /* timings of the last render (HIP events on the render stream), milliseconds */
+    float    totalMs;
+    float    traceMs;          /* sum over the traversal kernels (the dominant kernels) */
+    float    shadeMs;
+    float    resolveMs;
+    uint32_t localRows;        /* rows this shard rendered */
+    uint32_t localPixels;
+} rtr_frame_stats;
+
+/* ---- context -------------------------------------------------------------------------- */
+/* replaces Instance+Device creation (src/app/application.cppm:65-69): picks HIP device `ordinal`. */
+int  rtr_ctx_create(int deviceOrdinal, rtr_ctx** out);
+void rtr_ctx_destroy(rtr_ctx* ctx);
+/* Use an existing HIP stream (e.g. torch's current stream) for all work of this ctx; NULL -> own stream. */
+int  rtr_ctx_set_stream(rtr_ctx* ctx, void* hipStream);
+int  rtr_ctx_device_name(rtr_ctx* ctx, char* buf, size_t bytes);
+
+/* ---- scene ---------------------------------------------------------------------------- */
+/* replaces createSceneFromObjectsAndLights' GPU half (src/app/setup/create_scene.cppm:48-160):
+ * validates, flattens instances to world space, builds the BVH on the host, uploads. */
+int  rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* desc, rtr_scene** out);
+void rtr_scene_destroy(rtr_scene* scene);
+int  rtr_scene_get_stats(const rtr_scene* scene, rtr_scene_stats* out);
+/* Copy out the device BVH arrays (test / oracle hook; sizes from rtr_scene_get_stats). */
+int  rtr_scene_export_bvh(const rtr_scene* scene, RtrBvhNode* nodes, size_t nodeBytes,
+                          RtrBvhTri* tris, size_t triBytes);
+/* Host-only BVH build (no device needed): validates `desc`, flattens and builds exactly as
+ * rtr_scene_create does and copies the result out.  Call with nodes == tris == NULL to get the counts
+ * in `stats`.  Used by the CPU-side tests (BVH invariants, oracle BVH-vs-brute-force). */
+int  rtr_host_build_bvh(const rtr_scene_desc* desc, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes,
+                        RtrBvhTri* tris, size_t triBytes);
+/* replaces the host-visible LightInfo buffer rewrite (src/app/application.cppm:264-271). */
+int  rtr_scene_update_lights(rtr_scene* scene, const RtrAreaLightInfo* lights, uint32_t numLights);
+
+/* ---- frame ---------------------------------------------------------------------------- */
+/* replaces the 8 storage images (src/app/application.cppm:108-138).  `rows` is the number of
+ * LOCAL rows (== height when unsharded; see rtr_shard_rows).  `images` is a RTR_IMG_BIT mask. */
+int  rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t images, rtr_frame** out);
+void rtr_frame_destroy(rtr_frame* frame);
+/* Let an RGBA8 image of this frame live in caller-owned device memory (e.g. a torch tensor that
+ * RCCL will gather).  bytes must be width*rows*4. */
+int  rtr_frame_bind_external(rtr_frame* frame, int which, void* devicePtr, size_t bytes);
+int  rtr_frame_device_ptr(const rtr_frame* frame, int which, void** devicePtr, size_t* bytes);
+/* replaces the image->swapchain copy / readback (src/app/application.cppm:450-457). */
+int  rtr_frame_download(const rtr_frame* frame, int which, void* dst, size_t bytes);
+int  rtr_frame_clear(rtr_frame* frame);
+int  rtr_frame_get_stats(const rtr_frame* frame, rtr_frame_stats* out);
+
+/* Number of local rows shard `shardIndex` of `shardCount` owns, padded so every shard has the
+ * same count (equal-size shards for the gather). */
+uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount);
+
+/* ---- dispatch ------------------------------------------------------------------------- */
+/* replaces bind pipeline + push constants + vkCmdTraceRaysKHR + waitIdle
+ * (src/app/application.cppm:362-389, src/vulkan/ray_tracing_pipeline.cppm:212-214). Synchronous. */
+int  rtr_render(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo,
+                const rtr_render_params* params, rtr_frame* frame);
+/* Asynchronous variant: enqueues on the ctx stream and returns; rtr_frame_wait() joins. */
+int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo,
+                      const rtr_render_params* params, rtr_frame* frame);
+int  rtr_frame_wait(rtr_frame* frame);
+
+/* Rank-0 step after the RCCL gather: `gathered` holds shardCount blocks of (localRows x width)
+ * RGBA8 pixels in rank order; writes the de-interleaved (height x width) image to `dst`.
+ * Both are device pointers; runs on the ctx stream. */
+int  rtr_deinterleave_bands(rtr_ctx* ctx, const void* gathered, void* dst, uint32_t width, uint32_t height,
+                            uint32_t bandRows, uint32_t shardCount);
+
+/* ---- errors --------------------------------------------------------------------------- */
+const char* rtr_last_error(void);
+const char* rtr_status_string(int status);
+int         rtr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTR_H */

@@ -1,0 +1,266 @@
+/* rtr_math.h — the numerical contract of the renderer.
+ *
+ * Every float operation on the hot path is spelled here in terms of IEEE-754 binary32
+ * + - * / sqrt and explicit fma(), each of which is correctly rounded on x86-64 and on
+ * gfx950 (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).  Both compilers are
+ * run with -ffp-contract=off and without fast-math, so an expression means the same bits
+ * on the host cores and on the GPU.  That is what makes "RGBA8 framebuffer bit-exact
+ * between the HIP path and the CPU oracle" a testable statement.
+ *
+ * pow/exp2/log2 are our own polynomial forms (libm and ocml differ by ULPs, and
+ * pow(x,1/2.2) feeds the 8-bit quantiser); they are pinned against libm in
+ * tests/test_math.py with a stated ULP tolerance.
+ *
+ * Used by: the HIP kernels (device), the host scene layer, and the CPU oracle.
+ */
+#ifndef RTR_MATH_H
+#define RTR_MATH_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) || defined(__HIP__) || defined(__CUDACC__)
+#define RTR_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define RTR_HD static inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RTR_DEVICE_CODE 1
+#else
+#define RTR_DEVICE_CODE 0
+#endif
+
+typedef struct rtr_v3 { float x, y, z; } rtr_v3;
+
+/* ---- scalar helpers ---------------------------------------------------------------- */
+RTR_HD float rtr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RTR_HD float rtr_sqrt(float a) { return __builtin_sqrtf(a); }
+RTR_HD float rtr_abs(float a) { return __builtin_fabsf(a); }
+
+/* select-form min/max/clamp: identical on every target, NaN in 'a' yields 'b' */
+RTR_HD float rtr_min(float a, float b) { return a < b ? a : b; }
+RTR_HD float rtr_max(float a, float b) { return a > b ? a : b; }
+RTR_HD float rtr_clamp(float x, float lo, float hi) { return rtr_min(rtr_max(x, lo), hi); }
+
+/* hardware min/max: only for NaN-free operands whose zero sign is never observed
+ * (the slab test).  On the device these are single v_min/v_max instructions. */
+RTR_HD float rtr_hwmin(float a, float b) {
+#if RTR_DEVICE_CODE
+    return __builtin_fminf(a, b);
+#else
+    return a < b ? a : b;
+#endif
+}
+RTR_HD float rtr_hwmax(float a, float b) {
+#if RTR_DEVICE_CODE
+    return __builtin_fmaxf(a, b);
+#else
+    return a > b ? a : b;
+#endif
+}
+
+RTR_HD uint32_t rtr_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+RTR_HD float    rtr_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ---- PCG hash: reference src/shaders/raycommon.glsl:22-27 ------------------------------ */
+RTR_HD uint32_t rtr_pcg_hash(uint32_t seed) {
+    uint32_t state = seed * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+/* float(hash) / 2^32: one round-to-nearest-even convert, then an exact scaling.
+ * May return exactly 1.0 (hash >= 0xFFFFFF80), as the reference does (quirk Q2). */
+RTR_HD float rtr_random(uint32_t seed) {
+    return (float)rtr_pcg_hash(seed) * 2.3283064365386963e-10f;
+}
+
+/* ---- vec3 ------------------------------------------------------------------------------ */
+RTR_HD rtr_v3 rtr_mk(float x, float y, float z) { rtr_v3 r; r.x = x; r.y = y; r.z = z; return r; }
+RTR_HD rtr_v3 rtr_ld3(const float* p) { return rtr_mk(p[0], p[1], p[2]); }
+RTR_HD rtr_v3 rtr_add(rtr_v3 a, rtr_v3 b) { return rtr_mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RTR_HD rtr_v3 rtr_sub(rtr_v3 a, rtr_v3 b) { return rtr_mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RTR_HD rtr_v3 rtr_mul(rtr_v3 a, rtr_v3 b) { return rtr_mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RTR_HD rtr_v3 rtr_scale(rtr_v3 a, float s) { return rtr_mk(a.x * s, a.y * s, a.z * s); }
+RTR_HD rtr_v3 rtr_neg(rtr_v3 a) { return rtr_mk(-a.x, -a.y, -a.z); }
+/* a + b*s, one fma per component */
+RTR_HD rtr_v3 rtr_madd(rtr_v3 a, rtr_v3 b, float s) {
+    return rtr_mk(rtr_fma(b.x, s, a.x), rtr_fma(b.y, s, a.y), rtr_fma(b.z, s, a.z));
+}
+/* dot = fma(az,bz, fma(ay,by, ax*bx)) */
+RTR_HD float rtr_dot(rtr_v3 a, rtr_v3 b) {
+    return rtr_fma(a.z, b.z, rtr_fma(a.y, b.y, a.x * b.x));
+}
+/* cross: each component fma(p, q, -(r*s)) */
+RTR_HD rtr_v3 rtr_cross(rtr_v3 a, rtr_v3 b) {
+    return rtr_mk(rtr_fma(a.y, b.z, -(a.z * b.y)),
+                  rtr_fma(a.z, b.x, -(a.x * b.z)),
+                  rtr_fma(a.x, b.y, -(a.y * b.x)));
+}
+RTR_HD float rtr_length(rtr_v3 a) { return rtr_sqrt(rtr_dot(a, a)); }
+/* GLSL normalize(): v * (1/sqrt(dot)); normalize(0) = NaN exactly as in GLSL (0 * inf). */
+RTR_HD rtr_v3 rtr_normalize(rtr_v3 a) {
+    float inv = 1.0f / rtr_sqrt(rtr_dot(a, a));
+    return rtr_scale(a, inv);
+}
+
+/* ---- transforms ------------------------------------------------------------------------ */
+/* row-major 3x4 (vk::TransformMatrixKHR / gl_ObjectToWorldEXT) times (p,1) */
+RTR_HD rtr_v3 rtr_xform_point34(const float* m, rtr_v3 p) {
+    return rtr_mk(rtr_fma(m[2],  p.z, rtr_fma(m[1], p.y, m[0] * p.x)) + m[3],
+                  rtr_fma(m[6],  p.z, rtr_fma(m[5], p.y, m[4] * p.x)) + m[7],
+                  rtr_fma(m[10], p.z, rtr_fma(m[9], p.y, m[8] * p.x)) + m[11]);
+}
+/* column-major mat4 (GLSL `mat4 * vec4(p,1)`, raygen.rgen:187-189) */
+RTR_HD rtr_v3 rtr_xform_point44cm(const float* m, rtr_v3 p) {
+    return rtr_mk(rtr_fma(m[8],  p.z, rtr_fma(m[4], p.y, m[0] * p.x)) + m[12],
+                  rtr_fma(m[9],  p.z, rtr_fma(m[5], p.y, m[1] * p.x)) + m[13],
+                  rtr_fma(m[10], p.z, rtr_fma(m[6], p.y, m[2] * p.x)) + m[14]);
+}
+/* 3x3 row-major times vector */
+RTR_HD rtr_v3 rtr_mul33(const float* m, rtr_v3 p) {
+    return rtr_mk(rtr_fma(m[2], p.z, rtr_fma(m[1], p.y, m[0] * p.x)),
+                  rtr_fma(m[5], p.z, rtr_fma(m[4], p.y, m[3] * p.x)),
+                  rtr_fma(m[8], p.z, rtr_fma(m[7], p.y, m[6] * p.x)));
+}
+/* transpose(inverse(mat3(O2W))) of a row-major 3x4, as closesthit.rchit:74 builds it.
+ * = cofactor matrix / determinant; out is row-major 3x3. */
+RTR_HD void rtr_normal_matrix(const float* m, float* out) {
+    rtr_v3 r0 = rtr_mk(m[0], m[1], m[2]);
+    rtr_v3 r1 = rtr_mk(m[4], m[5], m[6]);
+    rtr_v3 r2 = rtr_mk(m[8], m[9], m[10]);
+    rtr_v3 c0 = rtr_cross(r1, r2);
+    rtr_v3 c1 = rtr_cross(r2, r0);
+    rtr_v3 c2 = rtr_cross(r0, r1);
+    float det = rtr_dot(r0, c0);
+    float inv = 1.0f / det;
+    out[0] = c0.x * inv; out[1] = c0.y * inv; out[2] = c0.z * inv;
+    out[3] = c1.x * inv; out[4] = c1.y * inv; out[5] = c1.z * inv;
+    out[6] = c2.x * inv; out[7] = c2.y * inv; out[8] = c2.z * inv;
+}
+
+/* ---- log2 / exp2 / pow ----------------------------------------------------------------- */
+/* log2(x) for normal x > 0.  x = m * 2^e with m in [sqrt(1/2), sqrt(2)); with s=(m-1)/(m+1),
+ * ln(m) = 2s(1 + s^2/3 + s^4/5 + s^6/7 + s^8/9 + s^10/11); |s| <= 0.1716 so the truncation
+ * error is < 2e-10 relative.  The integer part is added last to keep it exact. */
+RTR_HD float rtr_log2(float x) {
+    uint32_t ix = rtr_f2u(x);
+    /* move the split point to sqrt(2)/2: add (1.0 - sqrt(.5)) in bit space */
+    uint32_t t = ix + (0x3f800000u - 0x3f3504f3u);
+    int32_t e = (int32_t)(t >> 23) - 127;
+    uint32_t im = (t & 0x007fffffu) + 0x3f3504f3u;
+    float m = rtr_u2f(im);
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = 0.09090909090909091f;             /* 1/11 */
+    p = rtr_fma(p, z, 0.1111111111111111f);     /* 1/9  */
+    p = rtr_fma(p, z, 0.14285714285714285f);    /* 1/7  */
+    p = rtr_fma(p, z, 0.2f);                    /* 1/5  */
+    p = rtr_fma(p, z, 0.3333333333333333f);     /* 1/3  */
+    p = rtr_fma(p, z, 1.0f);
+    float lnm2 = (s + s) * p;                   /* ln(m) */
+    return rtr_fma(lnm2, 1.4426950408889634f, (float)e);
+}
+/* 2^z.  z = n + f, f in [-0.5, 0.5]; 2^f = e^(f ln2) by a degree-8 Taylor form
+ * (|f ln2| <= 0.3466 -> truncation < 2e-10 relative).  Result 0 below 2^-126. */
+RTR_HD float rtr_exp2(float z) {
+    if (z < -126.0f) return 0.0f;
+    if (z > 127.0f) z = 127.0f;
+    float nf = __builtin_floorf(z + 0.5f);
+    float f = z - nf;
+    float r = f * 0.6931471805599453f;
+    float p = 2.48015873015873e-05f;            /* 1/8! */
+    p = rtr_fma(p, r, 1.984126984126984e-04f);  /* 1/7! */
+    p = rtr_fma(p, r, 1.388888888888889e-03f);  /* 1/6! */
+    p = rtr_fma(p, r, 8.333333333333333e-03f);  /* 1/5! */
+    p = rtr_fma(p, r, 4.1666666666666664e-02f); /* 1/4! */
+    p = rtr_fma(p, r, 0.16666666666666666f);    /* 1/3! */
+    p = rtr_fma(p, r, 0.5f);
+    p = rtr_fma(p, r, 1.0f);
+    p = rtr_fma(p, r, 1.0f);
+    int32_t n = (int32_t)nf;
+    float scale = rtr_u2f((uint32_t)(n + 127) << 23);
+    return p * scale;
+}
+/* GLSL pow(x,y) for the uses on this path (x >= 0, y > 0: 2.2, 1/2.2, 5.0).
+ * x below FLT_MIN (incl. 0, negatives, NaN) -> 0, documented divergence from GLSL's
+ * "undefined for x < 0". */
+RTR_HD float rtr_pow(float x, float y) {
+    if (!(x >= 1.17549435e-38f)) return 0.0f;
+    return rtr_exp2(y * rtr_log2(x));
+}
+
+/* ---- ray / box / triangle ---------------------------------------------------------------- */
+/* Direction components are kept away from 0 so 1/d is finite and the slab test never
+ * forms inf*0 or inf-inf (no NaN reaches rtr_hwmin/rtr_hwmax). */
+RTR_HD float rtr_safe_rcp_dir(float d) {
+    const float tiny = 1e-20f;
+    float a = rtr_abs(d);
+    float c = a < tiny ? tiny : a;
+    float r = 1.0f / c;
+    return d < 0.0f ? -r : r;
+}
+
+/* Slab test against one box.  t = b*idir + ood (one fma per plane), ood = -o*idir.
+ * Returns entry distance through *t_entry; hit iff max(entry, tmin) <= min(exit, tmax)*(1+2^-21).
+ * The 1+2^-21 widening (Ize, "Robust BVH ray traversal", 2013, uses 1+2ulp) together with the
+ * builder's outward box padding makes the test conservative w.r.t. rtr_mt_intersect's t. */
+#define RTR_BOX_WIDEN 1.0000004768371582f
+RTR_HD int rtr_slab(const float* bmin, const float* bmax, rtr_v3 idir, rtr_v3 ood,
+                    float tmin, float tmax, float* t_entry) {
+    float tx0 = rtr_fma(bmin[0], idir.x, ood.x), tx1 = rtr_fma(bmax[0], idir.x, ood.x);
+    float ty0 = rtr_fma(bmin[1], idir.y, ood.y), ty1 = rtr_fma(bmax[1], idir.y, ood.y);
+    float tz0 = rtr_fma(bmin[2], idir.z, ood.z), tz1 = rtr_fma(bmax[2], idir.z, ood.z);
+    float lo = rtr_hwmax(rtr_hwmax(rtr_hwmin(tx0, tx1), rtr_hwmin(ty0, ty1)),
+                         rtr_hwmax(rtr_hwmin(tz0, tz1), tmin));
+    float hi = rtr_hwmin(rtr_hwmin(rtr_hwmax(tx0, tx1), rtr_hwmax(ty0, ty1)),
+                         rtr_hwmin(rtr_hwmax(tz0, tz1), tmax));
+    *t_entry = lo;
+    return lo <= hi * RTR_BOX_WIDEN;
+}
+
+/* Moeller-Trumbore, following the only in-repo statement of the ray-triangle arithmetic,
+ * reference src/shaders/intersect.rint:18-41 (EPSILON, the u / v / u+v rejections, t > tmin),
+ * on a precomputed {v0, e1, e2} record.  Returns 1 and (t,u,v) when tmin < t. */
+#define RTR_MT_EPSILON 0.00001f
+RTR_HD int rtr_mt_intersect(rtr_v3 o, rtr_v3 d, rtr_v3 v0, rtr_v3 e1, rtr_v3 e2,
+                            float tmin, float* t_out, float* u_out, float* v_out) {
+    rtr_v3 h = rtr_cross(d, e2);
+    float a = rtr_dot(e1, h);
+    if (rtr_abs(a) < RTR_MT_EPSILON) return 0;
+    float f = 1.0f / a;
+    rtr_v3 s = rtr_sub(o, v0);
+    float u = f * rtr_dot(s, h);
+    if (u < 0.0f || u > 1.0f) return 0;
+    rtr_v3 q = rtr_cross(s, e1);
+    float v = f * rtr_dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return 0;
+    float t = f * rtr_dot(e2, q);
+    if (!(t > tmin)) return 0;
+    *t_out = t; *u_out = u; *v_out = v;
+    return 1;
+}
+
+/* ---- tone map: reference src/shaders/raygen.rgen:45-59 ----------------------------------- */
+RTR_HD float rtr_aces(float x) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    float num = x * rtr_fma(a, x, b);
+    float den = rtr_fma(x, rtr_fma(c, x, d), e);
+    return rtr_clamp(num / den, 0.0f, 1.0f);
+}
+RTR_HD float rtr_to_srgb(float x) { return rtr_pow(x, 0.45454545454545453f); }
+RTR_HD float rtr_to_linear(float x) { return rtr_pow(x, 2.2f); }
+
+/* Vulkan UNORM8 store: clamp to [0,1], scale by 255, round to nearest even (NaN -> 0). */
+RTR_HD uint32_t rtr_unorm8(float x) {
+    float c = rtr_clamp(x, 0.0f, 1.0f);       /* NaN: max(NaN,0)->0 via select form */
+    float s = c * 255.0f;
+    float r = __builtin_rintf(s);
+    return (uint32_t)(int32_t)r;
+}
+/* imageStore(vec4(b,g,r,1)) into an rgba8 image: bytes in memory are B,G,R,255 (quirk Q14). */
+RTR_HD uint32_t rtr_pack_bgra8(float r, float g, float b) {
+    return rtr_unorm8(b) | (rtr_unorm8(g) << 8) | (rtr_unorm8(r) << 16) | 0xff000000u;
+}
+
+#endif /* RTR_MATH_H */

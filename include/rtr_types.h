@@ -1,0 +1,147 @@
+/* rtr_types.h — plain-old-data layouts shared by the host scene layer, the C ABI,
+ * the HIP kernels and the CPU oracle.  All little-endian fp32 / u32.
+ *
+ * Every struct here is byte-for-byte the layout the reference hands to its GPU
+ * (SURVEY.md Appendix A); the reference file:line each one mirrors is cited.
+ * No glm, no Vulkan types: a 3x4 row-major float matrix replaces
+ * vk::TransformMatrixKHR, float[3]+pad replaces glm::vec3+pad.
+ */
+#ifndef RTR_TYPES_H
+#define RTR_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: src/scene/geometry/vertex.cppm:11-15, src/shaders/raycommon.glsl:4-8 (48 B) */
+typedef struct RtrVertex {
+    float position[3]; float pad0;
+    float normal[3];   float pad1;
+    float uv[2];       float pad2[2];
+} RtrVertex;
+
+/* reference: src/scene/camera.cppm:21-26, src/shaders/raycommon.glsl:10-15 (64 B) */
+typedef struct RtrCameraData {
+    float position[3];                float _pad0;
+    float topLeftViewportCorner[3];   float _pad1;
+    float horizontalViewportDelta[3]; float _pad2;
+    float verticalViewportDelta[3];   float _pad3;
+} RtrCameraData;
+
+/* reference: src/scene/scene_info.cppm:10-20, src/shaders/raygen.rgen:35-43 (32 B push constant) */
+typedef struct RtrSceneInfo {
+    uint32_t frame;
+    uint32_t numAreaLights;
+    uint32_t _pad0;
+    uint32_t _pad1;
+    float    camPosition[3];
+    float    pad2_;
+} RtrSceneInfo;
+
+/* reference: src/scene/object.cppm:21-44, src/shaders/raycommon.glsl:29-51 (80 B) */
+typedef struct RtrObjectInfo {
+    uint32_t vertexOffset;
+    uint32_t indexOffset;
+    float    pad0_[2];
+    uint32_t usesColorMap;
+    uint32_t usesSpecularMap;
+    uint32_t usesMetallicMap;
+    uint32_t usesOpacityMap;
+    uint32_t colorIndex;
+    uint32_t specularIndex;
+    uint32_t metallicIndex;
+    uint32_t opacityIndex;
+    float    color[3];
+    float    pad1_;
+    float    specular;
+    float    metallic;
+    float    pad3_[2];
+} RtrObjectInfo;
+
+/* reference: src/scene/area_light.cppm:23-33, src/shaders/raycommon.glsl:53-63 (96 B).
+ * transform is a column-major mat4 (element [c*4+r]), packed as in src/core/utils.cppm:11-39. */
+typedef struct RtrAreaLightInfo {
+    float    color[3];
+    float    intensity;
+    uint32_t vertexOffset;
+    uint32_t indexOffset;
+    uint32_t numTriangles;
+    uint32_t isTwoSided;
+    float    transform[16];
+} RtrAreaLightInfo;
+
+/* reference: src/app/structs.cppm:14-21, src/shaders/denoise.comp:9-16 (24 B) */
+typedef struct RtrDenoisingInfo {
+    int32_t step_width;
+    float   c_phi;
+    float   n_phi;
+    float   p_phi;
+    int32_t denoisedImagesAreOutput;
+    int32_t isShadowedImage;
+} RtrDenoisingInfo;
+
+/* One mesh = one BLAS in the reference (src/vulkan/raytracing/blas.cppm:75-167;
+ * BLASCreateInfo filled at src/app/setup/geometry_builder.cppm:98-112, src/core/file.cppm:254-267).
+ * Offsets are element indices into the concatenated vertex / index arrays; indices are mesh-local. */
+typedef struct RtrMesh {
+    uint32_t vertexOffset;   /* vertexIndexOffset */
+    uint32_t indexOffset;    /* indexIndexOffset  */
+    uint32_t vertexCount;
+    uint32_t indexCount;     /* 3 * triangles */
+    uint32_t isOpaque;       /* BLAS geometry OPAQUE flag (blas.cppm:98-100) */
+    uint32_t _pad[3];
+} RtrMesh;
+
+/* One TLAS instance (src/vulkan/raytracing/tlas.cppm:52-82): lights first, then objects;
+ * customIndex = position in that list; transform = 3x4 row-major object->world. */
+typedef struct RtrInstance {
+    uint32_t meshIndex;
+    uint32_t customIndex;
+    uint32_t _pad[2];
+    float    transform[12];  /* row-major 3x4: m[r*4+c] */
+} RtrInstance;
+
+/* ---- device BVH layout, version 2 ("BVH2 / children-in-parent / 64 B") -------------------
+ * One node holds the boxes of BOTH children so a visit is one 64-B fetch (4 x dwordx4).
+ *   f[0..2]  = left  min xyz    f[3..5]  = left  max xyz
+ *   f[6..8]  = right min xyz    f[9..11] = right max xyz
+ *   child[0], child[1]: >= 0 -> index of an inner node;
+ *                       <  0 -> leaf: code = ~child; first = code >> 3; count = (code & 7) + 1
+ *   An empty child has an inverted box (min=+big, max=-big) and child = RTR_BVH_EMPTY.
+ */
+#define RTR_BVH_LAYOUT_VERSION 2
+#define RTR_BVH_EMPTY ((int32_t)0x7fffffff)
+#define RTR_BVH_MAX_LEAF 8
+typedef struct RtrBvhNode {
+    float   f[12];
+    int32_t child[2];
+    int32_t _pad[2];
+} RtrBvhNode;
+
+/* 48-B world-space Moeller-Trumbore record, in BVH leaf order.
+ * v0 / e1 = v1-v0 / e2 = v2-v0 in world space; the three w slots carry the ids the
+ * reference's hit shaders read (gl_InstanceCustomIndexEXT, gl_PrimitiveID) and flags. */
+typedef struct RtrBvhTri {
+    float    v0[3]; uint32_t customIndex;
+    float    e1[3]; uint32_t primitiveId;
+    float    e2[3]; uint32_t flags;      /* bit0: alpha-tested (any-hit needed) */
+} RtrBvhTri;
+
+#ifdef __cplusplus
+}
+#endif
+
+#ifdef __cplusplus
+static_assert(sizeof(RtrVertex) == 48, "Vertex must be 48 B");
+static_assert(sizeof(RtrCameraData) == 64, "GPUCameraData must be 64 B");
+static_assert(sizeof(RtrSceneInfo) == 32, "SceneInfo must be 32 B");
+static_assert(sizeof(RtrObjectInfo) == 80, "GPUObjectInfo must be 80 B");
+static_assert(sizeof(RtrAreaLightInfo) == 96, "GPUAreaLightInfo must be 96 B");
+static_assert(sizeof(RtrDenoisingInfo) == 24, "DenoisingInfo must be 24 B");
+static_assert(sizeof(RtrBvhNode) == 64, "BVH node must be 64 B");
+static_assert(sizeof(RtrBvhTri) == 48, "BVH triangle must be 48 B");
+#endif
+
+#endif /* RTR_TYPES_H */

@@ -1,0 +1,74 @@
+/* oracle.h — C interface of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * The oracle is a scalar C++ restatement of the reference's per-pixel ray-tracing path
+ * (reference src/shaders/raygen.rgen + closesthit.rchit + miss.rmiss + cook-torrance.glsl +
+ * LTC.glsl + intersect.rint).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (realtimeraytracer_amd/) never does.
+ *
+ * PARITY STATUS: "parity unpinned" at the traversal / intersection boundary — the reference
+ * runs BVH build, traversal and the ray-triangle test inside the Vulkan driver / RT hardware
+ * and ships no tests or golden images.  What IS pinned: the PCG hash, the
+ * camera basis and the OBJ ingest counts (SURVEY Appendix B known answers), and the OBJ reader
+ * against the real tinyobjloader compiled from the reference tree (oracle/_ref).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+#include "../include/rtr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_scene {
+    rtr_scene_desc desc;          /* same arrays the product's rtr_scene_create receives */
+    /* Optional BVH exported by the product (rtr_scene_export_bvh).  NULL -> brute force over all
+     * world-space triangles in (instance, primitive) order: an independent check of the packer,
+     * the BVH builder and the traversal. */
+    const RtrBvhNode* nodes;  uint32_t numNodes;
+    const RtrBvhTri*  tris;   uint32_t numTris;
+} oracle_scene;
+
+typedef struct oracle_out {
+    /* any pointer may be NULL; sizes are localRows*width elements */
+    uint32_t* analytic;      /* RGBA8 packed B,G,R,255 */
+    uint32_t* shadowed;
+    uint32_t* unshadowed;
+    uint32_t* normal;
+    uint32_t* position;
+    float*    hdr;           /* float4 per pixel: pre-tonemap shadowed radiance (accumulated if params.accumulate) */
+    rtr_frame_stats stats;   /* counters filled when params.collectStats */
+} oracle_out;
+
+/* Renders with the same semantics as rtr_render (same params struct, same band sharding).
+ * threads <= 1 -> scalar single-thread loop.  Returns 0 on success. */
+int oracle_render(const oracle_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo,
+                  const rtr_render_params* params, oracle_out* out, int threads);
+
+/* Primary-visibility only (raygen + traversal + MT): per pixel-sample t,u,v and ids, for the
+ * BVH-vs-brute-force cross-check.  Arrays of width*height*spp. */
+int oracle_primary_hits(const oracle_scene* scene, const RtrCameraData* camera, const rtr_render_params* params,
+                        float* t, float* u, float* v, uint32_t* customIndex, uint32_t* primitiveId, int threads);
+
+/* Denoise + combine restatement (reference src/shaders/denoise.comp, combine.comp and the host
+ * protocol src/app/application.cppm:391-445).  All images RGBA8, width*height. */
+int oracle_denoise_combine(uint32_t width, uint32_t height, const uint32_t* analytic,
+                           uint32_t* shadowed, uint32_t* unshadowed, const uint32_t* normal, const uint32_t* position,
+                           uint32_t* denoisedShadowed, uint32_t* denoisedUnshadowed, uint32_t* finalImage,
+                           int iterations);
+
+/* known-answer helpers exported for tests */
+uint32_t oracle_pcg_hash(uint32_t seed);
+float    oracle_random(uint32_t seed);
+float    oracle_pow(float x, float y);
+float    oracle_log2(float x);
+float    oracle_exp2(float x);
+uint32_t oracle_pack_bgra8(float r, float g, float b);
+int      oracle_mt(const float* o, const float* d, const float* v0, const float* e1, const float* e2,
+                   float tmin, float* tuv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,605 @@
+/* oracle_render.cpp — CPU ORACLE (test infrastructure, never shipped, never the thing measured
+ * except as bench.py's reported cpu_baseline).
+ *
+ * Scalar C++ restatement of the reference's per-pixel path.  Each function cites the reference
+ * file:line it follows.  Parity status: UNPINNED at traversal/intersection (see oracle.h).
+ *
+ * Deliberate divergences from the reference text (all recorded in DESIGN.md):
+ *   D1 (Q3)  zero vertex normals: reference computes normalize(vec3(0)) = NaN
+ *            (closesthit.rchit:74-76); here the geometric normal, flipped to face the ray.
+ *   D2       miss.rmiss HDRI lookup -> constant sky colour (texture row is "next").
+ *   D3       pow(): own exp2/log2 forms (rtr_math.h); x < FLT_MIN -> 0.
+ *   D4       hit accepted iff tmin < t < tmax; closest = min over (t, customIndex, primitiveID).
+ *
+ * Build: g++ -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ */
+#include "oracle.h"
+#include "../include/rtr_math.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Counters {
+    uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
+    void add(const Counters& o) {
+        rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
+        hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
+    }
+};
+
+struct WorldTri { rtr_v3 v0, e1, e2; uint32_t custom, prim; };
+
+struct Scene {
+    const oracle_scene* s;
+    std::vector<WorldTri> brute;            /* only when no BVH is supplied */
+    std::vector<float> normalMat;           /* 9 floats per instance, indexed by customIndex */
+    std::vector<const RtrInstance*> byCustom;
+    rtr_v3 skyLinear;
+};
+
+struct Hit { bool hit; float t, u, v; uint32_t custom, prim; };
+
+/* ---- traversal: the algorithm the HIP kernels restate (DESIGN.md "Traversal") ---------------- */
+inline bool id_less(uint32_t c0, uint32_t p0, uint32_t c1, uint32_t p1) {
+    return c0 < c1 || (c0 == c1 && p0 < p1);
+}
+
+inline void consider(Hit& best, float t, float u, float v, uint32_t custom, uint32_t prim, float tmax) {
+    if (!(t < tmax)) return;
+    if (!best.hit) {
+        best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = custom; best.prim = prim;
+        return;
+    }
+    if (t < best.t || (t == best.t && id_less(custom, prim, best.custom, best.prim))) {
+        best.t = t; best.u = u; best.v = v; best.custom = custom; best.prim = prim;
+    }
+}
+
+Hit trace_brute(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
+    Hit best{}; best.hit = false; best.t = tmax;
+    for (const WorldTri& w : sc.brute) {
+        float t, u, v;
+        c.tris++;
+        if (rtr_mt_intersect(o, d, w.v0, w.e1, w.e2, tmin, &t, &u, &v)) {
+            consider(best, t, u, v, w.custom, w.prim, tmax);
+            if (anyHit && best.hit) return best;
+        }
+    }
+    return best;
+}
+
+Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
+    const RtrBvhNode* nodes = sc.s->nodes;
+    const RtrBvhTri* tris = sc.s->tris;
+    Hit best{}; best.hit = false; best.t = tmax;
+    rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+    rtr_v3 ood = rtr_mk(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+    int32_t stack[128];
+    int sp = 0;
+    int32_t cur = 0;   /* root is always an inner node */
+    for (;;) {
+        if (cur >= 0) {
+            const RtrBvhNode& n = nodes[cur];
+            c.nodes++;
+            float tl, tr;
+            float limit = best.hit ? best.t : tmax;
+            int hl = rtr_slab(&n.f[0], &n.f[3], idir, ood, tmin, limit, &tl);
+            int hr = rtr_slab(&n.f[6], &n.f[9], idir, ood, tmin, limit, &tr);
+            if (hl && hr) {
+                int32_t nearC = n.child[0], farC = n.child[1];
+                if (tr < tl) { nearC = n.child[1]; farC = n.child[0]; }
+                stack[sp++] = farC;
+                cur = nearC;
+                continue;
+            } else if (hl) { cur = n.child[0]; continue; }
+            else if (hr) { cur = n.child[1]; continue; }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const RtrBvhTri& tr = tris[first + i];
+                float t, u, v;
+                c.tris++;
+                if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
+                    consider(best, t, u, v, tr.customIndex, tr.primitiveId, tmax);
+                    if (anyHit && best.hit) return best;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
+
+inline Hit trace(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
+    c.rays++;
+    if (anyHit) c.shadow++; else c.primary++;
+    if (!(tmax > tmin)) { Hit h{}; h.hit = false; return h; }
+    return sc.s->nodes ? trace_bvh(sc, o, d, tmin, tmax, anyHit, c) : trace_brute(sc, o, d, tmin, tmax, anyHit, c);
+}
+
+/* ---- cook-torrance.glsl ----------------------------------------------------------------------- */
+const float PI_F = 3.14159265359f;   /* cook-torrance.glsl:1 */
+
+inline float chiGGX(float v) { return v > 0.0f ? 1.0f : 0.0f; }                       /* :3-6 */
+inline float GGX_Distribution(rtr_v3 n, rtr_v3 h, float alpha) {                       /* :11-18 */
+    float NoH = rtr_dot(n, h);
+    float alpha2 = alpha * alpha;
+    float NoH2 = NoH * NoH;
+    float den = rtr_max(rtr_fma(NoH2, alpha2, 1.0f - NoH2), 0.001f);
+    return (chiGGX(NoH) * alpha2) / (PI_F * den * den);
+}
+inline float GGX_PartialGeometryTerm(rtr_v3 v, rtr_v3 n, rtr_v3 h, float alpha) {      /* :43-50 */
+    float VoH2 = rtr_clamp(rtr_dot(v, h), 0.001f, 1.0f);
+    float chi = chiGGX(VoH2 / rtr_clamp(rtr_dot(v, n), 0.001f, 1.0f));
+    VoH2 = VoH2 * VoH2;
+    float tan2 = (1.0f - VoH2) / VoH2;
+    return (chi * 2.0f) / (1.0f + rtr_sqrt(rtr_fma(alpha * alpha, tan2, 1.0f)));
+}
+inline rtr_v3 Fresnel_Schlick(float cosT, rtr_v3 F0) {                                  /* :58-61 */
+    float p = rtr_pow(1.0f - cosT, 5.0f);
+    return rtr_mk(rtr_fma(1.0f - F0.x, p, F0.x), rtr_fma(1.0f - F0.y, p, F0.y), rtr_fma(1.0f - F0.z, p, F0.z));
+}
+
+/* ---- LTC.glsl --------------------------------------------------------------------------------- */
+const float LUT_SIZE = 64.0f;                               /* raygen.rgen:65-67 */
+const float LUT_SCALE = (LUT_SIZE - 1.0f) / LUT_SIZE;
+const float LUT_BIAS = 0.5f / LUT_SIZE;
+
+/* texture() on a 64x64 RGBA32F image with the reference's sampler: linear filter, repeat
+ * addressing, single mip (src/vulkan/memory/image_sampler.cppm:26-42). */
+inline void sample_lut(const float* lut, float u, float v, float out[4]) {
+    float x = rtr_fma(u, LUT_SIZE, -0.5f), y = rtr_fma(v, LUT_SIZE, -0.5f);
+    if (!(x >= -1.0e6f && x <= 1.0e6f)) x = 0.0f;      /* NaN / huge coordinates sample texel (0,0) */
+    if (!(y >= -1.0e6f && y <= 1.0e6f)) y = 0.0f;
+    float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = ((int)x0f) & 63, y0 = ((int)y0f) & 63;
+    int x1 = (x0 + 1) & 63, y1 = (y0 + 1) & 63;
+    const float* t00 = lut + (y0 * 64 + x0) * 4;
+    const float* t10 = lut + (y0 * 64 + x1) * 4;
+    const float* t01 = lut + (y1 * 64 + x0) * 4;
+    const float* t11 = lut + (y1 * 64 + x1) * 4;
+    for (int k = 0; k < 4; ++k) {
+        float a = rtr_fma(t10[k] - t00[k], fx, t00[k]);
+        float b = rtr_fma(t11[k] - t01[k], fx, t01[k]);
+        out[k] = rtr_fma(b - a, fy, a);
+    }
+}
+
+inline rtr_v3 IntegrateEdgeVec(rtr_v3 v1, rtr_v3 v2) {                                  /* LTC.glsl:2-14 */
+    float x = rtr_dot(v1, v2);
+    float y = rtr_abs(x);
+    float a = rtr_fma(rtr_fma(0.0145206f, y, 0.4965155f), y, 0.8543985f);
+    float b = rtr_fma(4.1616724f + y, y, 3.4175940f);
+    float v = a / b;
+    float theta_sintheta = (x > 0.0f) ? v : 0.5f * (1.0f / rtr_sqrt(rtr_max(rtr_fma(-x, x, 1.0f), 1e-7f))) - v;
+    return rtr_scale(rtr_cross(v1, v2), theta_sintheta);
+}
+
+/* Minv given as the 4 LUT parameters (t1) of raygen.rgen:153-157, or identity.
+ * GLSL mat3(c0,c1,c2) is column-major: Minv = [ t1.x 0 t1.z ; 0 1 0 ; t1.y 0 t1.w ] as rows. */
+inline float LTC_Evaluate(rtr_v3 N, rtr_v3 V, rtr_v3 P, bool identity, const float t1[4],
+                          const rtr_v3 points[3], rtr_v3 lightNormal, bool twoSided, const float* ltc2) {
+    /* LTC.glsl:19-22 */
+    rtr_v3 T1 = rtr_normalize(rtr_sub(V, rtr_scale(N, rtr_dot(V, N))));
+    rtr_v3 T2 = rtr_cross(N, T1);
+    /* :25  Minv * transpose(mat3(T1,T2,N)) applied to a vector w:
+     *       first q = (dot(T1,w), dot(T2,w), dot(N,w)), then Minv * q */
+    rtr_v3 L[3];
+    for (int k = 0; k < 3; ++k) {
+        rtr_v3 w = rtr_sub(points[k], P);
+        rtr_v3 q = rtr_mk(rtr_dot(T1, w), rtr_dot(T2, w), rtr_dot(N, w));
+        if (identity) L[k] = q;
+        else L[k] = rtr_mk(rtr_fma(t1[2], q.z, t1[0] * q.x), q.y, rtr_fma(t1[3], q.z, t1[1] * q.x));
+        L[k] = rtr_normalize(L[k]);                                                     /* :41-43 */
+    }
+    rtr_v3 dir = rtr_sub(points[0], P);                                                 /* :36-38 */
+    bool behind = rtr_dot(dir, lightNormal) < 0.0f;
+    rtr_v3 vsum = IntegrateEdgeVec(L[0], L[1]);                                         /* :46-49 */
+    vsum = rtr_add(vsum, IntegrateEdgeVec(L[1], L[2]));
+    vsum = rtr_add(vsum, IntegrateEdgeVec(L[2], L[0]));
+    float len = rtr_length(vsum);                                                       /* :52 */
+    float z = vsum.z / len;
+    if (behind) z = -z;
+    float uvx = rtr_fma(rtr_fma(z, 0.5f, 0.5f), LUT_SCALE, LUT_BIAS);                   /* :58-59 */
+    float uvy = rtr_fma(len, LUT_SCALE, LUT_BIAS);
+    float tex[4];
+    sample_lut(ltc2, uvx, uvy, tex);                                                    /* :62 */
+    float sum = len * tex[3];
+    if (!behind && !twoSided) sum = 0.0f;                                               /* :65-66 */
+    return sum;
+}
+
+/* ---- closesthit.rchit:45-110 ------------------------------------------------------------------ */
+struct Surface { rtr_v3 hitPoint, normal, color; float roughness, metallic; };
+
+inline Surface closest_hit_shader(const Scene& sc, const Hit& h, rtr_v3 rayDir, Counters& c) {
+    const rtr_scene_desc& D = sc.s->desc;
+    Surface sf;
+    c.hits++;
+    uint32_t objIndex = h.custom - D.numLights;                                          /* :53 */
+    const RtrObjectInfo& oi = D.objects[objIndex];
+    uint32_t i0 = D.indices[3 * h.prim + 0 + oi.indexOffset];                            /* :59-61 */
+    uint32_t i1 = D.indices[3 * h.prim + 1 + oi.indexOffset];
+    uint32_t i2 = D.indices[3 * h.prim + 2 + oi.indexOffset];
+    const RtrVertex& v0 = D.vertices[i0 + oi.vertexOffset];                              /* :63-65 */
+    const RtrVertex& v1 = D.vertices[i1 + oi.vertexOffset];
+    const RtrVertex& v2 = D.vertices[i2 + oi.vertexOffset];
+    float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;                                     /* :71 */
+    rtr_v3 p0 = rtr_ld3(v0.position), p1 = rtr_ld3(v1.position), p2 = rtr_ld3(v2.position);
+    rtr_v3 localPos = rtr_madd(rtr_madd(rtr_scale(p0, b0), p1, b1), p2, b2);             /* :72 */
+    const RtrInstance* inst = sc.byCustom[h.custom];
+    sf.hitPoint = rtr_xform_point34(inst->transform, localPos);                          /* :73 */
+    rtr_v3 n0 = rtr_ld3(v0.normal), n1 = rtr_ld3(v1.normal), n2 = rtr_ld3(v2.normal);
+    rtr_v3 nsum = rtr_madd(rtr_madd(rtr_scale(n0, b0), n1, b1), n2, b2);                 /* :74 */
+    const float* nm = &sc.normalMat[9 * (size_t)h.custom];
+    if (rtr_dot(nsum, nsum) > 0.0f) {
+        sf.normal = rtr_normalize(rtr_mul33(nm, rtr_normalize(nsum)));                   /* :74-76 */
+    } else {
+        /* D1: geometric normal of the local triangle, through the normal matrix, facing the ray */
+        rtr_v3 g = rtr_cross(rtr_sub(p1, p0), rtr_sub(p2, p0));
+        rtr_v3 n = rtr_normalize(rtr_mul33(nm, rtr_normalize(g)));
+        if (rtr_dot(n, rayDir) > 0.0f) n = rtr_neg(n);
+        sf.normal = n;
+    }
+    /* :79-101 materials: constants only (textures are a "next" row; scene creation rejects maps) */
+    rtr_v3 col = rtr_ld3(oi.color);
+    float rough = oi.specular;
+    sf.metallic = oi.metallic;
+    sf.color = rtr_mk(rtr_to_linear(col.x), rtr_to_linear(col.y), rtr_to_linear(col.z)); /* :104 */
+    sf.roughness = 1.0f - rough;                                                         /* :106 */
+    return sf;
+}
+
+/* ---- raygen.rgen:71-366 for one pixel --------------------------------------------------------- */
+struct PixelOut { rtr_v3 analytic, shadowed, unshadowed, avgNormal, avgPosition; };
+
+PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneInfo& info,
+                     const rtr_render_params& prm, uint32_t px, uint32_t py, bool wantAnalytic, Counters& c) {
+    const rtr_scene_desc& D = sc.s->desc;
+    PixelOut o;
+    o.analytic = o.shadowed = o.unshadowed = o.avgNormal = o.avgPosition = rtr_mk(0, 0, 0);
+    const rtr_v3 camPos = rtr_ld3(cam.position);
+    const rtr_v3 TL = rtr_ld3(cam.topLeftViewportCorner);
+    const rtr_v3 dH = rtr_ld3(cam.horizontalViewportDelta);
+    const rtr_v3 dV = rtr_ld3(cam.verticalViewportDelta);
+
+    for (uint32_t i = 0; i < prm.spp; ++i) {                                             /* :81 */
+        /* :83 int(pixelCoord + i) is the x coordinate only (quirk Q1) */
+        float jx = rtr_random(px + i), jy = rtr_random(px + i * 322u);
+        float offx = ((float)px + jx) - 0.5f, offy = ((float)py + jy) - 0.5f;            /* :84 */
+        rtr_v3 pw = rtr_madd(rtr_madd(TL, dH, offx), dV, offy);                          /* :86-89 */
+        rtr_v3 rayDir = rtr_normalize(rtr_sub(pw, camPos));                              /* :91-92 */
+        Hit h = trace(sc, camPos, rayDir, 0.001f, 10000.0f, false, c);                   /* :99-107 */
+        if (!h.hit) {                                                                    /* :110-115, miss.rmiss */
+            o.analytic = rtr_add(o.analytic, sc.skyLinear);
+            o.unshadowed = rtr_add(o.unshadowed, sc.skyLinear);
+            o.shadowed = rtr_add(o.shadowed, sc.skyLinear);
+            continue;
+        }
+        if (h.custom < D.numLights) {                                                    /* :116-121, closesthit.rchit:46-50 */
+            rtr_v3 lc = rtr_ld3(D.lights[h.custom].color);
+            o.analytic = rtr_add(o.analytic, lc);
+            o.unshadowed = rtr_add(o.unshadowed, lc);
+            o.shadowed = rtr_add(o.shadowed, lc);
+            continue;
+        }
+        Surface sf = closest_hit_shader(sc, h, rayDir, c);
+        rtr_v3 hitPoint = sf.hitPoint, hitNormal = sf.normal, color = sf.color;          /* :125-130 */
+        rtr_v3 viewDir = rtr_normalize(rtr_sub(camPos, hitPoint));
+        float roughness = sf.roughness, metallic = sf.metallic;
+        o.avgNormal = rtr_add(o.avgNormal, hitNormal);                                   /* :132-133 */
+        o.avgPosition = rtr_add(o.avgPosition, hitPoint);
+        float om = 1.0f - metallic;
+        rtr_v3 mDiffuse = rtr_scale(color, om);                                          /* :135 */
+        rtr_v3 mSpecular = rtr_mk(rtr_fma(color.x, metallic, 0.04f * om),                /* :136 mix(vec3(.04),color,metallic) */
+                                  rtr_fma(color.y, metallic, 0.04f * om),
+                                  rtr_fma(color.z, metallic, 0.04f * om));
+        float dotNV = rtr_clamp(rtr_dot(hitNormal, viewDir), 0.0f, 1.0f);                /* :140 */
+        float t1[4] = {1, 0, 0, 1}, t2[4] = {0, 0, 0, 0};
+        if (wantAnalytic) {                                                              /* :144-151 */
+            float lu = rtr_fma(roughness, LUT_SCALE, LUT_BIAS);
+            float lv = rtr_fma(rtr_sqrt(1.0f - dotNV), LUT_SCALE, LUT_BIAS);
+            sample_lut(D.ltc1, lu, lv, t1);
+            sample_lut(D.ltc2, lu, lv, t2);
+        }
+        rtr_v3 shadowOrigin = rtr_madd(hitPoint, hitNormal, 0.01f);                      /* :224, :297 */
+
+        for (uint32_t li = 0; li < info.numAreaLights; ++li) {                           /* :165 */
+            const RtrAreaLightInfo& L = D.lights[li];
+            c.lightFetch++;
+            rtr_v3 lcol = rtr_ld3(L.color);
+            for (uint32_t ti = 0; ti < L.numTriangles; ++ti) {                           /* :172 */
+                c.lightTriFetch++;
+                uint32_t i0 = D.indices[ti * 3 + 0 + L.indexOffset];                     /* :176-182 */
+                uint32_t i1 = D.indices[ti * 3 + 1 + L.indexOffset];
+                uint32_t i2 = D.indices[ti * 3 + 2 + L.indexOffset];
+                rtr_v3 P[3];
+                P[0] = rtr_xform_point44cm(L.transform, rtr_ld3(D.vertices[i0 + L.vertexOffset].position)); /* :184-189 */
+                P[1] = rtr_xform_point44cm(L.transform, rtr_ld3(D.vertices[i1 + L.vertexOffset].position));
+                P[2] = rtr_xform_point44cm(L.transform, rtr_ld3(D.vertices[i2 + L.vertexOffset].position));
+                rtr_v3 lightNormal = rtr_cross(rtr_sub(P[2], P[1]), rtr_sub(P[0], P[1])); /* :192 */
+                float area = rtr_length(lightNormal) * 0.5f;                              /* :193 */
+                float pdf = 1.0f / (area * 0.7f);                                         /* :194 */
+                lightNormal = rtr_normalize(lightNormal);                                 /* :195 */
+                if (!L.isTwoSided) {                                                      /* :197-201 */
+                    if (rtr_dot(lightNormal, rtr_sub(hitPoint, P[0])) < 0.0f) continue;
+                }
+                rtr_v3 shadowedSample = rtr_mk(0, 0, 0), unshadowedSample = rtr_mk(0, 0, 0);
+                for (uint32_t s = 0; s < prm.numShadowRays; ++s) {                        /* :206 */
+                    uint32_t seed = s + px * 733u + py * 1933u + info.frame;              /* :209 */
+                    float r1 = rtr_random(seed), r2 = rtr_random(seed + 100u);            /* :210-211 */
+                    if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }               /* :215-218 */
+                    rtr_v3 lightSamplePos = rtr_madd(rtr_madd(P[0], rtr_sub(P[1], P[0]), r1), rtr_sub(P[2], P[0]), r2); /* :219 */
+                    rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
+                    rtr_v3 sampledLightDir = rtr_normalize(lightVec);                     /* :221 */
+                    float lightDistance = rtr_length(lightVec);                           /* :222 */
+                    Hit sh = trace(sc, shadowOrigin, sampledLightDir, 0.001f, lightDistance - 0.5f, true, c); /* :226-241 */
+                    float currShadow = sh.hit ? 0.0f : 1.0f;                              /* :244 */
+                    rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir)); /* :247 */
+                    float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f); /* :250 */
+                    float Dg = GGX_Distribution(hitNormal, halfVector, roughness);        /* :252 */
+                    float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
+                              GGX_PartialGeometryTerm(sampledLightDir, hitNormal, halfVector, roughness); /* :253 */
+                    rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);                      /* :254 */
+                    float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 0.1f);             /* :256 */
+                    float NdotL = rtr_max(rtr_dot(hitNormal, sampledLightDir), 0.1f);     /* :257 */
+                    float den = 4.0f * NdotV * NdotL;                                     /* :259 */
+                    float DG = Dg * G;
+                    rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+                    rtr_v3 currDiffuse = rtr_mk((om * color.x) / PI_F, (om * color.y) / PI_F, (om * color.z) / PI_F); /* :260 */
+                    float attenuation = 1.0f / (lightDistance * lightDistance);           /* :262-264 */
+                    rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);                     /* :266 */
+                    float lscale = L.intensity * NdotL * attenuation * 10.0f;             /* :267 */
+                    rtr_v3 Lr = rtr_scale(lcol, lscale);
+                    rtr_v3 contrib = rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf);
+                    shadowedSample = rtr_madd(shadowedSample, contrib, currShadow);       /* :269 */
+                    unshadowedSample = rtr_add(unshadowedSample, contrib);                /* :270 */
+                }
+                float ns = (float)prm.numShadowRays;                                      /* :272-273 */
+                shadowedSample = rtr_mk(shadowedSample.x / ns, shadowedSample.y / ns, shadowedSample.z / ns);
+                unshadowedSample = rtr_mk(unshadowedSample.x / ns, unshadowedSample.y / ns, unshadowedSample.z / ns);
+                if (wantAnalytic) {                                                       /* :277-283 */
+                    bool twoSided = L.isTwoSided != 0;
+                    float diffuse = LTC_Evaluate(hitNormal, viewDir, hitPoint, true, t1, P, lightNormal, twoSided, D.ltc2);
+                    float spec = LTC_Evaluate(hitNormal, viewDir, hitPoint, false, t1, P, lightNormal, twoSided, D.ltc2);
+                    rtr_v3 fres = rtr_mk(rtr_fma(1.0f - mSpecular.x, t2[1], mSpecular.x * t2[0]),
+                                         rtr_fma(1.0f - mSpecular.y, t2[1], mSpecular.y * t2[0]),
+                                         rtr_fma(1.0f - mSpecular.z, t2[1], mSpecular.z * t2[0]));
+                    float li5 = L.intensity * 5.0f;
+                    o.analytic = rtr_add(o.analytic, rtr_mk(
+                        lcol.x * li5 * rtr_fma(mDiffuse.x, diffuse, spec * fres.x),
+                        lcol.y * li5 * rtr_fma(mDiffuse.y, diffuse, spec * fres.y),
+                        lcol.z * li5 * rtr_fma(mDiffuse.z, diffuse, spec * fres.z)));
+                }
+                o.shadowed = rtr_add(o.shadowed, shadowedSample);                         /* :284-285 */
+                o.unshadowed = rtr_add(o.unshadowed, unshadowedSample);
+            }
+        }
+        /* :289-338 directional light */
+        const rtr_v3 directLightDir = rtr_normalize(rtr_mk(-1.0f, 1.0f, -0.5f));
+        const rtr_v3 directLightColor = rtr_mk(1.0f, 1.0f, 0.5f);
+        const float directLightIntensity = 0.2f;
+        if (rtr_dot(hitNormal, directLightDir) <= 0.0f) continue;                         /* :293 */
+        Hit sh = trace(sc, shadowOrigin, directLightDir, 0.001f, 10000.0f, true, c);      /* :303-313 */
+        float currShadow = sh.hit ? 0.0f : 1.0f;                                          /* :316 */
+        rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, directLightDir));              /* :318 */
+        float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);             /* :321 */
+        float Dg = GGX_Distribution(hitNormal, halfVector, roughness);                    /* :323 */
+        float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
+                  GGX_PartialGeometryTerm(directLightDir, hitNormal, halfVector, roughness);
+        rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
+        float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 5.0f);                         /* :327 (quirk Q6) */
+        float NdotL = rtr_max(rtr_dot(hitNormal, directLightDir), 0.0001f);               /* :328 */
+        float den = 4.0f * NdotV * NdotL;
+        float DG = Dg * G;
+        rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+        rtr_v3 currDiffuse = rtr_mk((om * color.x) / PI_F, (om * color.y) / PI_F, (om * color.z) / PI_F);
+        rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
+        float lscale = directLightIntensity * NdotL * 20.0f;                              /* :334 */
+        rtr_v3 Lr = rtr_scale(directLightColor, lscale);
+        rtr_v3 contrib = rtr_mul(BRDF, Lr);
+        o.shadowed = rtr_madd(o.shadowed, contrib, currShadow);                           /* :336-338 */
+        o.unshadowed = rtr_add(o.unshadowed, contrib);
+        o.analytic = rtr_add(o.analytic, contrib);
+    }
+    float n = (float)prm.spp;                                                             /* :341-343 */
+    o.shadowed = rtr_mk(o.shadowed.x / n, o.shadowed.y / n, o.shadowed.z / n);
+    o.unshadowed = rtr_mk(o.unshadowed.x / n, o.unshadowed.y / n, o.unshadowed.z / n);
+    o.analytic = rtr_mk(o.analytic.x / n, o.analytic.y / n, o.analytic.z / n);
+    return o;
+}
+
+inline uint32_t tonemap_pack(rtr_v3 c) {                                                  /* :345-357 */
+    return rtr_pack_bgra8(rtr_to_srgb(rtr_aces(c.x)), rtr_to_srgb(rtr_aces(c.y)), rtr_to_srgb(rtr_aces(c.z)));
+}
+
+bool prepare(const oracle_scene* s, Scene& sc) {
+    const rtr_scene_desc& D = s->desc;
+    sc.s = s;
+    sc.byCustom.assign(D.numInstances, nullptr);
+    sc.normalMat.assign(9 * (size_t)D.numInstances, 0.0f);
+    for (uint32_t i = 0; i < D.numInstances; ++i) {
+        const RtrInstance& in = D.instances[i];
+        if (in.customIndex >= D.numInstances || in.meshIndex >= D.numMeshes) return false;
+        sc.byCustom[in.customIndex] = &in;
+        rtr_normal_matrix(in.transform, &sc.normalMat[9 * (size_t)in.customIndex]);
+    }
+    for (auto p : sc.byCustom) if (!p) return false;
+    sc.skyLinear = rtr_mk(rtr_to_linear(D.skyColor[0]), rtr_to_linear(D.skyColor[1]), rtr_to_linear(D.skyColor[2]));
+    if (!s->nodes) {
+        /* world-space triangle soup in (instance, primitive) order; same formulas as the product's
+         * packer: world v = M * v_local, e1 = v1w - v0w, e2 = v2w - v0w */
+        for (uint32_t i = 0; i < D.numInstances; ++i) {
+            const RtrInstance& in = D.instances[i];
+            const RtrMesh& m = D.meshes[in.meshIndex];
+            for (uint32_t t = 0; t < m.indexCount / 3; ++t) {
+                rtr_v3 w[3];
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t idx = D.indices[m.indexOffset + 3 * t + k] + m.vertexOffset;
+                    w[k] = rtr_xform_point34(in.transform, rtr_ld3(D.vertices[idx].position));
+                }
+                WorldTri wt;
+                wt.v0 = w[0]; wt.e1 = rtr_sub(w[1], w[0]); wt.e2 = rtr_sub(w[2], w[0]);
+                wt.custom = in.customIndex; wt.prim = t;
+                sc.brute.push_back(wt);
+            }
+        }
+    }
+    return true;
+}
+
+struct BandMap {
+    uint32_t bandRows, shardIndex, shardCount, height;
+    /* local row -> global y, or -1 when the (padded) local row has no pixel */
+    int64_t global_y(uint32_t localRow) const {
+        uint32_t lb = localRow / bandRows, r = localRow % bandRows;
+        uint64_t y = ((uint64_t)lb * shardCount + shardIndex) * bandRows + r;
+        return y < height ? (int64_t)y : -1;
+    }
+};
+
+template <class F>
+void parallel_rows(uint32_t rows, int threads, F&& fn) {
+    if (threads <= 1) { for (uint32_t r = 0; r < rows; ++r) fn(r, 0); return; }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t]() { for (;;) { uint32_t r = next.fetch_add(1); if (r >= rows) break; fn(r, t); } });
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+static uint32_t shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount) {
+    uint32_t bands = (height + bandRows - 1) / bandRows;
+    uint32_t per = (bands + shardCount - 1) / shardCount;
+    return per * bandRows;
+}
+
+int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info,
+                  const rtr_render_params* prmIn, oracle_out* out, int threads) {
+    if (!s || !cam || !info || !prmIn || !out) return -1;
+    rtr_render_params prm = *prmIn;
+    if (prm.bandRows == 0) prm.bandRows = 8;
+    if (prm.shardCount == 0) prm.shardCount = 1;
+    if (prm.spp == 0 || prm.width == 0 || prm.height == 0 || prm.shardIndex >= prm.shardCount) return -1;
+    if (info->numAreaLights > s->desc.numLights) return -1;
+    bool wantAnalytic = out->analytic != nullptr;
+    if (wantAnalytic && (!s->desc.ltc1 || !s->desc.ltc2)) return -4;
+    Scene sc;
+    if (!prepare(s, sc)) return -1;
+    const uint32_t rows = shard_rows(prm.height, prm.bandRows, prm.shardCount);
+    const uint32_t W = prm.width;
+    BandMap bm{prm.bandRows, prm.shardIndex, prm.shardCount, prm.height};
+    int nthreads = threads < 1 ? 1 : threads;
+    std::vector<Counters> counters((size_t)nthreads);
+    const float invFrames = (float)(prm.accumulatedFrames + 1u);
+
+    parallel_rows(rows, nthreads, [&](uint32_t lr, int tid) {
+        int64_t gy = bm.global_y(lr);
+        for (uint32_t x = 0; x < W; ++x) {
+            size_t p = (size_t)lr * W + x;
+            if (gy < 0) {   /* padded row: defined as zero */
+                if (out->analytic) out->analytic[p] = 0;
+                if (out->shadowed) out->shadowed[p] = 0;
+                if (out->unshadowed) out->unshadowed[p] = 0;
+                if (out->normal) out->normal[p] = 0;
+                if (out->position) out->position[p] = 0;
+                if (out->hdr && !prm.accumulate) { out->hdr[4 * p] = out->hdr[4 * p + 1] = out->hdr[4 * p + 2] = out->hdr[4 * p + 3] = 0; }
+                continue;
+            }
+            PixelOut po = shade_pixel(sc, *cam, *info, prm, x, (uint32_t)gy, wantAnalytic, counters[(size_t)tid]);
+            rtr_v3 sh = po.shadowed;
+            if (out->hdr) {
+                float* h = out->hdr + 4 * p;
+                if (prm.accumulate) {
+                    h[0] += sh.x; h[1] += sh.y; h[2] += sh.z; h[3] += 1.0f;
+                    sh = rtr_mk(h[0] / invFrames, h[1] / invFrames, h[2] / invFrames);
+                } else {
+                    h[0] = sh.x; h[1] = sh.y; h[2] = sh.z; h[3] = 1.0f;
+                }
+            }
+            if (out->shadowed) out->shadowed[p] = tonemap_pack(sh);
+            if (out->unshadowed) out->unshadowed[p] = tonemap_pack(po.unshadowed);
+            if (out->analytic) out->analytic[p] = tonemap_pack(po.analytic);
+            if (out->normal) {                                                            /* raygen.rgen:359,363 */
+                float n = (float)prm.spp;
+                rtr_v3 an = rtr_normalize(rtr_mk(po.avgNormal.x / n, po.avgNormal.y / n, po.avgNormal.z / n));
+                out->normal[p] = rtr_pack_bgra8(an.x, an.y, an.z);
+            }
+            if (out->position) {                                                          /* raygen.rgen:360-364 */
+                float n = (float)prm.spp;
+                out->position[p] = rtr_pack_bgra8(po.avgPosition.x / n, po.avgPosition.y / n, po.avgPosition.z / n);
+            }
+        }
+    });
+
+    Counters tot;
+    for (auto& c : counters) tot.add(c);
+    rtr_frame_stats& st = out->stats;
+    memset(&st, 0, sizeof st);
+    st.numRays = tot.rays; st.numPrimaryRays = tot.primary; st.numShadowRays = tot.shadow;
+    st.numNodeVisits = tot.nodes; st.numTriTests = tot.tris; st.numHits = tot.hits;
+    st.numLightFetches = tot.lightFetch; st.numLightTriFetches = tot.lightTriFetch;
+    st.localRows = rows; st.localPixels = rows * W;
+    uint32_t k = 0;
+    k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;
+    k += out->normal ? 1u : 0u; k += out->position ? 1u : 0u;
+    st.algorithmicBytes = 64 * tot.nodes + 48 * tot.tris + 236 * tot.hits + 96 * tot.lightFetch + 156 * tot.lightTriFetch +
+                          4ull * k * st.localPixels + (out->hdr ? (prm.accumulate ? 32ull : 16ull) * st.localPixels : 0ull);
+    return 0;
+}
+
+int oracle_primary_hits(const oracle_scene* s, const RtrCameraData* cam, const rtr_render_params* prm,
+                        float* t, float* u, float* v, uint32_t* customIndex, uint32_t* primitiveId, int threads) {
+    if (!s || !cam || !prm) return -1;
+    Scene sc;
+    if (!prepare(s, sc)) return -1;
+    const uint32_t W = prm->width, H = prm->height, S = prm->spp;
+    const rtr_v3 camPos = rtr_ld3(cam->position);
+    const rtr_v3 TL = rtr_ld3(cam->topLeftViewportCorner);
+    const rtr_v3 dH = rtr_ld3(cam->horizontalViewportDelta);
+    const rtr_v3 dV = rtr_ld3(cam->verticalViewportDelta);
+    int nthreads = threads < 1 ? 1 : threads;
+    std::vector<Counters> counters((size_t)nthreads);
+    parallel_rows(H, nthreads, [&](uint32_t py, int tid) {
+        for (uint32_t px = 0; px < W; ++px)
+            for (uint32_t i = 0; i < S; ++i) {
+                float jx = rtr_random(px + i), jy = rtr_random(px + i * 322u);
+                float offx = ((float)px + jx) - 0.5f, offy = ((float)py + jy) - 0.5f;
+                rtr_v3 pw = rtr_madd(rtr_madd(TL, dH, offx), dV, offy);
+                rtr_v3 rayDir = rtr_normalize(rtr_sub(pw, camPos));
+                Hit h = trace(sc, camPos, rayDir, 0.001f, 10000.0f, false, counters[(size_t)tid]);
+                size_t k = ((size_t)py * W + px) * S + i;
+                if (t) t[k] = h.hit ? h.t : -1.0f;
+                if (u) u[k] = h.hit ? h.u : 0.0f;
+                if (v) v[k] = h.hit ? h.v : 0.0f;
+                if (customIndex) customIndex[k] = h.hit ? h.custom : 0xffffffffu;
+                if (primitiveId) primitiveId[k] = h.hit ? h.prim : 0xffffffffu;
+            }
+    });
+    return 0;
+}
+
+uint32_t oracle_pcg_hash(uint32_t seed) { return rtr_pcg_hash(seed); }
+float oracle_random(uint32_t seed) { return rtr_random(seed); }
+float oracle_pow(float x, float y) { return rtr_pow(x, y); }
+float oracle_log2(float x) { return rtr_log2(x); }
+float oracle_exp2(float x) { return rtr_exp2(x); }
+uint32_t oracle_pack_bgra8(float r, float g, float b) { return rtr_pack_bgra8(r, g, b); }
+int oracle_mt(const float* o, const float* d, const float* v0, const float* e1, const float* e2, float tmin, float* tuv) {
+    return rtr_mt_intersect(rtr_ld3(o), rtr_ld3(d), rtr_ld3(v0), rtr_ld3(e1), rtr_ld3(e2), tmin, &tuv[0], &tuv[1], &tuv[2]);
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+"""ctypes mirror of include/rtr_types.h and include/rtr.h, and the loader of the two in-tree
+shared libraries.  This is harness plumbing (tests, bench, smoke drive the C ABI through it); the
+product is librtr_hip.so.  There is NO fallback: if librtr_hip.so is missing or a symbol of
+include/rtr.h is not exported, import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_HIP_PATH = os.path.join(_HERE, "librtr_hip.so")
+LIB_HOST_PATH = os.path.join(_HERE, "librtr_host.so")
+
+f32, u32, u64, i32 = C.c_float, C.c_uint32, C.c_uint64, C.c_int32
+
+
+class RtrVertex(C.Structure):
+    _fields_ = [("position", f32 * 3), ("pad0", f32), ("normal", f32 * 3), ("pad1", f32), ("uv", f32 * 2), ("pad2", f32 * 2)]
+
+
+class RtrCameraData(C.Structure):
+    _fields_ = [("position", f32 * 3), ("_pad0", f32), ("topLeftViewportCorner", f32 * 3), ("_pad1", f32),
+                ("horizontalViewportDelta", f32 * 3), ("_pad2", f32), ("verticalViewportDelta", f32 * 3), ("_pad3", f32)]
+
+
+class RtrSceneInfo(C.Structure):
+    _fields_ = [("frame", u32), ("numAreaLights", u32), ("_pad0", u32), ("_pad1", u32), ("camPosition", f32 * 3), ("pad2_", f32)]
+
+
+class RtrObjectInfo(C.Structure):
+    _fields_ = [("vertexOffset", u32), ("indexOffset", u32), ("pad0_", f32 * 2),
+                ("usesColorMap", u32), ("usesSpecularMap", u32), ("usesMetallicMap", u32), ("usesOpacityMap", u32),
+                ("colorIndex", u32), ("specularIndex", u32), ("metallicIndex", u32), ("opacityIndex", u32),
+                ("color", f32 * 3), ("pad1_", f32), ("specular", f32), ("metallic", f32), ("pad3_", f32 * 2)]
+
+
+class RtrAreaLightInfo(C.Structure):
+    _fields_ = [("color", f32 * 3), ("intensity", f32), ("vertexOffset", u32), ("indexOffset", u32),
+                ("numTriangles", u32), ("isTwoSided", u32), ("transform", f32 * 16)]
+
+
+class RtrMesh(C.Structure):
+    _fields_ = [("vertexOffset", u32), ("indexOffset", u32), ("vertexCount", u32), ("indexCount", u32),
+                ("isOpaque", u32), ("_pad", u32 * 3)]
+
+
+class RtrInstance(C.Structure):
+    _fields_ = [("meshIndex", u32), ("customIndex", u32), ("_pad", u32 * 2), ("transform", f32 * 12)]
+
+
+class RtrBvhNode(C.Structure):
+    _fields_ = [("f", f32 * 12), ("child", i32 * 2), ("_pad", i32 * 2)]
+
+
+class RtrBvhTri(C.Structure):
+    _fields_ = [("v0", f32 * 3), ("customIndex", u32), ("e1", f32 * 3), ("primitiveId", u32), ("e2", f32 * 3), ("flags", u32)]
+
+
+class rtr_scene_desc(C.Structure):
+    _fields_ = [("vertices", C.POINTER(RtrVertex)), ("numVertices", u32),
+                ("indices", C.POINTER(u32)), ("numIndices", u32),
+                ("meshes", C.POINTER(RtrMesh)), ("numMeshes", u32),
+                ("instances", C.POINTER(RtrInstance)), ("numInstances", u32),
+                ("objects", C.POINTER(RtrObjectInfo)), ("numObjects", u32),
+                ("lights", C.POINTER(RtrAreaLightInfo)), ("numLights", u32),
+                ("ltc1", C.POINTER(f32)), ("ltc2", C.POINTER(f32)),
+                ("skyColor", f32 * 3), ("_pad", f32)]
+
+
+class rtr_scene_stats(C.Structure):
+    _fields_ = [("numTriangles", u32), ("numNodes", u32), ("maxDepth", u32), ("maxLeafSize", u32),
+                ("bvhLayoutVersion", u32), ("stackEntries", u32), ("buildMs", f32), ("sahCost", f32),
+                ("boundsMin", f32 * 3), ("boundsMax", f32 * 3), ("boxPad", f32), ("_pad", f32)]
+
+
+class rtr_render_params(C.Structure):
+    _fields_ = [("width", u32), ("height", u32), ("spp", u32), ("numShadowRays", u32), ("images", u32),
+                ("bandRows", u32), ("shardIndex", u32), ("shardCount", u32), ("accumulate", u32),
+                ("accumulatedFrames", u32), ("collectStats", u32), ("pipeline", u32)]
+
+
+class rtr_frame_stats(C.Structure):
+    _fields_ = [("numRays", u64), ("numPrimaryRays", u64), ("numShadowRays", u64), ("numNodeVisits", u64),
+                ("numTriTests", u64), ("numHits", u64), ("numLightFetches", u64), ("numLightTriFetches", u64),
+                ("algorithmicBytes", u64), ("totalMs", f32), ("traceMs", f32), ("shadeMs", f32), ("resolveMs", f32),
+                ("localRows", u32), ("localPixels", u32)]
+
+
+assert C.sizeof(RtrVertex) == 48 and C.sizeof(RtrCameraData) == 64 and C.sizeof(RtrSceneInfo) == 32
+assert C.sizeof(RtrObjectInfo) == 80 and C.sizeof(RtrAreaLightInfo) == 96
+assert C.sizeof(RtrBvhNode) == 64 and C.sizeof(RtrBvhTri) == 48
+
+# enum rtr_image
+IMAGE_ANALYTIC, IMAGE_SHADOWED, IMAGE_UNSHADOWED = 0, 1, 2
+IMAGE_DENOISED_SHADOWED, IMAGE_DENOISED_UNSHADOWED, IMAGE_FINAL, IMAGE_NORMAL, IMAGE_POSITION = 3, 4, 5, 6, 7
+IMAGE_HDR = 16
+
+
+def IMG_BIT(which):
+    return 1 << which
+
+
+IMAGES_FRAMEBUFFER = IMG_BIT(IMAGE_SHADOWED)
+IMAGES_RAYGEN5 = IMG_BIT(0) | IMG_BIT(1) | IMG_BIT(2) | IMG_BIT(6) | IMG_BIT(7)
+IMAGES_DENOISE = IMG_BIT(3) | IMG_BIT(4) | IMG_BIT(5)
+
+P = C.POINTER
+VP = C.c_void_p
+
+# every entry point include/rtr.h declares: name -> (restype, argtypes)
+RTR_SYMBOLS = {
+    "rtr_ctx_create": (C.c_int, [C.c_int, P(VP)]),
+    "rtr_ctx_destroy": (None, [VP]),
+    "rtr_ctx_set_stream": (C.c_int, [VP, VP]),
+    "rtr_ctx_device_name": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
+    "rtr_scene_create": (C.c_int, [VP, P(rtr_scene_desc), P(VP)]),
+    "rtr_scene_destroy": (None, [VP]),
+    "rtr_scene_get_stats": (C.c_int, [VP, P(rtr_scene_stats)]),
+    "rtr_scene_export_bvh": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
+    "rtr_host_build_bvh": (C.c_int, [P(rtr_scene_desc), P(rtr_scene_stats), VP, C.c_size_t, VP, C.c_size_t]),
+    "rtr_scene_update_lights": (C.c_int, [VP, P(RtrAreaLightInfo), u32]),
+    "rtr_frame_create": (C.c_int, [VP, u32, u32, u32, P(VP)]),
+    "rtr_frame_destroy": (None, [VP]),
+    "rtr_frame_bind_external": (C.c_int, [VP, C.c_int, VP, C.c_size_t]),
+    "rtr_frame_device_ptr": (C.c_int, [VP, C.c_int, P(VP), P(C.c_size_t)]),
+    "rtr_frame_download": (C.c_int, [VP, C.c_int, VP, C.c_size_t]),
+    "rtr_frame_clear": (C.c_int, [VP]),
+    "rtr_frame_get_stats": (C.c_int, [VP, P(rtr_frame_stats)]),
+    "rtr_shard_rows": (u32, [u32, u32, u32]),
+    "rtr_render": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
+    "rtr_render_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
+    "rtr_frame_wait": (C.c_int, [VP]),
+    "rtr_deinterleave_bands": (C.c_int, [VP, VP, VP, u32, u32, u32, u32]),
+    "rtr_last_error": (C.c_char_p, []),
+    "rtr_status_string": (C.c_char_p, [C.c_int]),
+    "rtr_abi_version": (C.c_int, []),
+}
+
+RTRH_SYMBOLS = {
+    "rtrh_last_error": (C.c_char_p, []),
+    "rtrh_scene_new": (VP, []),
+    "rtrh_scene_free": (None, [VP]),
+    "rtrh_add_light": (C.c_int, [VP, f32, P(f32), C.c_int, C.c_int, C.c_char_p]),
+    "rtrh_light_move": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_light_scale": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_light_rotate": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_light_transform": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_add_object": (C.c_int, [VP, C.c_char_p]),
+    "rtrh_object_move": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_object_scale": (C.c_int, [VP, C.c_int, f32]),
+    "rtrh_object_rotate": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_object_set_color": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_object_set_color_map": (C.c_int, [VP, C.c_int, C.c_char_p]),
+    "rtrh_object_set_specular": (C.c_int, [VP, C.c_int, f32]),
+    "rtrh_object_set_metallic": (C.c_int, [VP, C.c_int, f32]),
+    "rtrh_object_transform": (C.c_int, [VP, C.c_int, P(f32)]),
+    "rtrh_num_objects": (C.c_int, [VP]),
+    "rtrh_num_lights": (C.c_int, [VP]),
+    "rtrh_add_obj_mtl_pair": (C.c_int, [VP, C.c_char_p, C.c_char_p]),
+    "rtrh_set_ltc": (C.c_int, [VP, P(f32), P(f32)]),
+    "rtrh_set_sky": (C.c_int, [VP, P(f32)]),
+    "rtrh_build": (C.c_int, [VP]),
+    "rtrh_get_desc": (C.c_int, [VP, P(rtr_scene_desc)]),
+    "rtrh_object_info": (C.c_int, [VP, C.c_int, P(u32), P(u32), P(u32)]),
+    "rtrh_load_model": (C.c_int, [VP, C.c_char_p]),
+    "rtrh_camera_new": (VP, [f32, P(f32), P(f32), P(f32), C.c_int, C.c_int]),
+    "rtrh_camera_free": (None, [VP]),
+    "rtrh_camera_get": (C.c_int, [VP, P(RtrCameraData)]),
+    "rtrh_camera_set_position": (C.c_int, [VP, P(f32)]),
+    "rtrh_camera_rotate_y": (C.c_int, [VP, f32]),
+    "rtrh_camera_mouse": (C.c_int, [VP, f32, f32]),
+    "rtrh_camera_state": (C.c_int, [VP, P(f32)]),
+}
+
+
+def _bind(path, table, what):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{what} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C realtimeraytracer_amd/csrc`). There is no pure-Python / CPU fallback for the ray-tracing path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in table.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{path} does not export {name} (declared in include/rtr.h)") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """librtr_hip.so (the product).  Loaded on first use; raises ImportError if absent/incomplete."""
+    global _hip
+    if _hip is None:
+        _hip = _bind(LIB_HIP_PATH, RTR_SYMBOLS, "librtr_hip.so")
+    return _hip
+
+
+def host_lib():
+    """librtr_host.so (C shim over the C++ scene layer; no HIP dependency)."""
+    global _host
+    if _host is None:
+        _host = _bind(LIB_HOST_PATH, RTRH_SYMBOLS, "librtr_host.so")
+    return _host

@@ -1,0 +1,472 @@
+/* rtr_device.h — device-side building blocks of the gfx950 ray-tracing path.
+ *
+ *   trace<ANY,STATS,BLOCK>() : BVH2 traversal, per-lane node stack in LDS laid out
+ *                        stack[depth * BLOCK + tid] (lane-interleaved: one ds_read/write_b32 per
+ *                        push/pop, 32 consecutive lanes -> 32 distinct banks, conflict-free),
+ *                        64-B children-in-parent nodes fetched as dwordx4 loads, Moeller-Trumbore on
+ *                        48-B {v0,e1,e2} records.  Replaces traceRayEXT (reference raygen.rgen:99,231,303).
+ *   shade_sample<Policy>() : the per-sample body of reference raygen.rgen:81-339 with the hit-shader
+ *                        fetch of closesthit.rchit:45-110 inlined; the shadow-ray query is a
+ *                        policy so the same loop structure serves the megakernel (trace inline),
+ *                        the wavefront generator (enqueue with ballot compaction) and the
+ *                        wavefront resolve (look the visibility bit up).
+ *
+ * All float arithmetic goes through include/rtr_math.h (the numerical contract shared with the
+ * CPU oracle); compile with -ffp-contract=off.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/rtr_types.h"
+#include "../../../include/rtr_math.h"
+
+namespace rtrdev {
+
+struct DeviceScene {
+    const float4* nodes;             /* RtrBvhNode as 4 x float4 */
+    const float4* tris;              /* RtrBvhTri  as 3 x float4 */
+    const RtrVertex* vertices;
+    const uint32_t* indices;
+    const RtrObjectInfo* objects;
+    const RtrAreaLightInfo* lights;
+    const float* xforms;             /* 12 floats (3x4 row-major object->world) per customIndex */
+    const float* nmats;              /* 12 floats (9 used: transpose(inverse(mat3))) per customIndex */
+    const float* ltc1;               /* 64x64x4 or null */
+    const float* ltc2;
+    float skyLinear[3];
+    uint32_t numLights;
+};
+
+struct Counters {                    /* device mirror of rtr_frame_stats' counters */
+    unsigned long long rays, primary, shadow, nodes, tris, hits, lightFetch, lightTriFetch;
+};
+
+struct LocalStats {
+    uint32_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
+    __device__ void flush(Counters* c) const {
+        if (rays) atomicAdd(&c->rays, (unsigned long long)rays);
+        if (primary) atomicAdd(&c->primary, (unsigned long long)primary);
+        if (shadow) atomicAdd(&c->shadow, (unsigned long long)shadow);
+        if (nodes) atomicAdd(&c->nodes, (unsigned long long)nodes);
+        if (tris) atomicAdd(&c->tris, (unsigned long long)tris);
+        if (hits) atomicAdd(&c->hits, (unsigned long long)hits);
+        if (lightFetch) atomicAdd(&c->lightFetch, (unsigned long long)lightFetch);
+        if (lightTriFetch) atomicAdd(&c->lightTriFetch, (unsigned long long)lightTriFetch);
+    }
+};
+
+struct HitRec { float t, u, v; uint32_t custom, prim; };   /* custom == 0xffffffff: miss */
+#define RTR_MISS 0xffffffffu
+
+__device__ __forceinline__ rtr_v3 f4xyz(const float4& a) { return rtr_mk(a.x, a.y, a.z); }
+
+/* ------------------------------------------------------------------------------------------
+ * BVH traversal.  Restates, operation for operation, the algorithm of oracle/oracle_render.cpp
+ * trace_bvh(): ordered descent (near child first, ties -> left), far child pushed, box culled iff
+ * entry > current best t (with the conservative widening of rtr_slab), leaf triangles tested in
+ * storage order, closest = min over (t, customIndex, primitiveID).
+ * `stack` points at this lane's slot 0; consecutive depths are `BLOCK` ints apart.
+ * ------------------------------------------------------------------------------------------ */
+template <bool ANY, bool STATS, int BLOCK>
+__device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict__ stack,
+                                      rtr_v3 o, rtr_v3 d, float tmin, float tmax, HitRec& best, LocalStats& st) {
+    if (STATS) { st.rays++; if (ANY) st.shadow++; else st.primary++; }
+    best.custom = RTR_MISS; best.prim = RTR_MISS; best.t = tmax; best.u = 0.f; best.v = 0.f;
+    if (!(tmax > tmin)) return false;
+    const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+    const rtr_v3 ood = rtr_mk(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+    bool found = false;
+    float limit = tmax;
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* n = sc.nodes + (size_t)cur * 4;
+            const float4 a = n[0], b = n[1], c = n[2];
+            const int2 ch = *reinterpret_cast<const int2*>(n + 3);
+            if (STATS) st.nodes++;
+            const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {a.w, b.x, b.y};
+            const float rmn[3] = {b.z, b.w, c.x}, rmx[3] = {c.y, c.z, c.w};
+            float tl, tr;
+            const int hl = rtr_slab(lmn, lmx, idir, ood, tmin, limit, &tl);
+            const int hr = rtr_slab(rmn, rmx, idir, ood, tmin, limit, &tr);
+            if (hl && hr) {
+                const bool swap = tr < tl;
+                const int32_t nearC = swap ? ch.y : ch.x;
+                const int32_t farC = swap ? ch.x : ch.y;
+                stack[sp * BLOCK] = farC; ++sp;
+                cur = nearC;
+                continue;
+            } else if (hl) { cur = ch.x; continue; }
+            else if (hr) { cur = ch.y; continue; }
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4* tp = sc.tris + (size_t)(first + i) * 3;
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (STATS) st.tris++;
+                float t, u, v;
+                if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v)) {
+                    if (t < tmax) {
+                        const uint32_t cu = __float_as_uint(q0.w), pr = __float_as_uint(q1.w);
+                        bool take;
+                        if (!found) take = true;
+                        else take = t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)));
+                        if (take) {
+                            found = true; best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                            limit = t;
+                            if (ANY) return true;
+                        }
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stack[sp * BLOCK];
+    }
+    return found;
+}
+
+/* ---- cook-torrance.glsl (reference src/shaders/cook-torrance.glsl:1-61) ---------------------- */
+#define RTR_PI_F 3.14159265359f
+__device__ __forceinline__ float chiGGX(float v) { return v > 0.0f ? 1.0f : 0.0f; }
+__device__ __forceinline__ float GGX_Distribution(rtr_v3 n, rtr_v3 h, float alpha) {
+    const float NoH = rtr_dot(n, h);
+    const float alpha2 = alpha * alpha;
+    const float NoH2 = NoH * NoH;
+    const float den = rtr_max(rtr_fma(NoH2, alpha2, 1.0f - NoH2), 0.001f);
+    return (chiGGX(NoH) * alpha2) / (RTR_PI_F * den * den);
+}
+__device__ __forceinline__ float GGX_PartialGeometryTerm(rtr_v3 v, rtr_v3 n, rtr_v3 h, float alpha) {
+    float VoH2 = rtr_clamp(rtr_dot(v, h), 0.001f, 1.0f);
+    const float chi = chiGGX(VoH2 / rtr_clamp(rtr_dot(v, n), 0.001f, 1.0f));
+    VoH2 = VoH2 * VoH2;
+    const float tan2 = (1.0f - VoH2) / VoH2;
+    return (chi * 2.0f) / (1.0f + rtr_sqrt(rtr_fma(alpha * alpha, tan2, 1.0f)));
+}
+__device__ __forceinline__ rtr_v3 Fresnel_Schlick(float cosT, rtr_v3 F0) {
+    const float p = rtr_pow(1.0f - cosT, 5.0f);
+    return rtr_mk(rtr_fma(1.0f - F0.x, p, F0.x), rtr_fma(1.0f - F0.y, p, F0.y), rtr_fma(1.0f - F0.z, p, F0.z));
+}
+
+/* ---- LTC.glsl (reference src/shaders/LTC.glsl:2-69) + the sampler of image_sampler.cppm:26-42 -- */
+#define RTR_LUT_SIZE 64.0f
+#define RTR_LUT_SCALE ((RTR_LUT_SIZE - 1.0f) / RTR_LUT_SIZE)
+#define RTR_LUT_BIAS (0.5f / RTR_LUT_SIZE)
+
+__device__ __forceinline__ float4 sample_lut(const float* __restrict__ lut, float u, float v) {
+    float x = rtr_fma(u, RTR_LUT_SIZE, -0.5f), y = rtr_fma(v, RTR_LUT_SIZE, -0.5f);
+    if (!(x >= -1.0e6f && x <= 1.0e6f)) x = 0.0f;      /* NaN / huge coordinates sample texel (0,0) */
+    if (!(y >= -1.0e6f && y <= 1.0e6f)) y = 0.0f;
+    const float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const int x0 = ((int)x0f) & 63, y0 = ((int)y0f) & 63;
+    const int x1 = (x0 + 1) & 63, y1 = (y0 + 1) & 63;
+    const float4 t00 = *reinterpret_cast<const float4*>(lut + (y0 * 64 + x0) * 4);
+    const float4 t10 = *reinterpret_cast<const float4*>(lut + (y0 * 64 + x1) * 4);
+    const float4 t01 = *reinterpret_cast<const float4*>(lut + (y1 * 64 + x0) * 4);
+    const float4 t11 = *reinterpret_cast<const float4*>(lut + (y1 * 64 + x1) * 4);
+    float4 r;
+    { const float a = rtr_fma(t10.x - t00.x, fx, t00.x), b = rtr_fma(t11.x - t01.x, fx, t01.x); r.x = rtr_fma(b - a, fy, a); }
+    { const float a = rtr_fma(t10.y - t00.y, fx, t00.y), b = rtr_fma(t11.y - t01.y, fx, t01.y); r.y = rtr_fma(b - a, fy, a); }
+    { const float a = rtr_fma(t10.z - t00.z, fx, t00.z), b = rtr_fma(t11.z - t01.z, fx, t01.z); r.z = rtr_fma(b - a, fy, a); }
+    { const float a = rtr_fma(t10.w - t00.w, fx, t00.w), b = rtr_fma(t11.w - t01.w, fx, t01.w); r.w = rtr_fma(b - a, fy, a); }
+    return r;
+}
+
+__device__ __forceinline__ rtr_v3 IntegrateEdgeVec(rtr_v3 v1, rtr_v3 v2) {
+    const float x = rtr_dot(v1, v2);
+    const float y = rtr_abs(x);
+    const float a = rtr_fma(rtr_fma(0.0145206f, y, 0.4965155f), y, 0.8543985f);
+    const float b = rtr_fma(4.1616724f + y, y, 3.4175940f);
+    const float v = a / b;
+    const float theta_sintheta = (x > 0.0f) ? v : 0.5f * (1.0f / rtr_sqrt(rtr_max(rtr_fma(-x, x, 1.0f), 1e-7f))) - v;
+    return rtr_scale(rtr_cross(v1, v2), theta_sintheta);
+}
+
+__device__ __forceinline__ float LTC_Evaluate(rtr_v3 N, rtr_v3 V, rtr_v3 P, bool identity, float4 t1,
+                                              const rtr_v3* points, rtr_v3 lightNormal, bool twoSided,
+                                              const float* __restrict__ ltc2) {
+    const rtr_v3 T1 = rtr_normalize(rtr_sub(V, rtr_scale(N, rtr_dot(V, N))));
+    const rtr_v3 T2 = rtr_cross(N, T1);
+    rtr_v3 L[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const rtr_v3 w = rtr_sub(points[k], P);
+        const rtr_v3 q = rtr_mk(rtr_dot(T1, w), rtr_dot(T2, w), rtr_dot(N, w));
+        rtr_v3 l;
+        if (identity) l = q;
+        else l = rtr_mk(rtr_fma(t1.z, q.z, t1.x * q.x), q.y, rtr_fma(t1.w, q.z, t1.y * q.x));
+        L[k] = rtr_normalize(l);
+    }
+    const rtr_v3 dir = rtr_sub(points[0], P);
+    const bool behind = rtr_dot(dir, lightNormal) < 0.0f;
+    rtr_v3 vsum = IntegrateEdgeVec(L[0], L[1]);
+    vsum = rtr_add(vsum, IntegrateEdgeVec(L[1], L[2]));
+    vsum = rtr_add(vsum, IntegrateEdgeVec(L[2], L[0]));
+    const float len = rtr_length(vsum);
+    float z = vsum.z / len;
+    if (behind) z = -z;
+    const float uvx = rtr_fma(rtr_fma(z, 0.5f, 0.5f), RTR_LUT_SCALE, RTR_LUT_BIAS);
+    const float uvy = rtr_fma(len, RTR_LUT_SCALE, RTR_LUT_BIAS);
+    const float4 tex = sample_lut(ltc2, uvx, uvy);
+    float sum = len * tex.w;
+    if (!behind && !twoSided) sum = 0.0f;
+    return sum;
+}
+
+/* ---- per-frame arguments -------------------------------------------------------------------- */
+struct RenderArgs {
+    RtrCameraData cam;        /* 64-B UBO of raygen.rgen:19-21 */
+    RtrSceneInfo info;        /* 32-B push constant of raygen.rgen:35-43 */
+    uint32_t width, height;   /* full frame */
+    uint32_t spp, numShadowRays;
+    uint32_t bandRows, shardIndex, shardCount;
+    uint32_t localRows;       /* rows of the local (shard) image */
+    uint32_t tilesPerRow;     /* ceil(width / 8) */
+    uint32_t maxRaysPerSample;/* slots per (pixel,sample) in the wavefront visibility array */
+    uint32_t images;          /* RTR_IMG_BIT mask */
+    uint32_t accumulate, accumulatedFrames;
+};
+
+/* Canonical pixel order: 8x8 tiles, row-major inside a tile, tiles left->right inside a band of 8
+ * local rows, bands top->bottom.  q -> (x, localRow); returns false for padding. */
+__device__ __forceinline__ bool pixel_of(const RenderArgs& ra, uint32_t q, uint32_t& x, uint32_t& lrow, uint32_t& gy) {
+    const uint32_t lane = q & 63u, tile = q >> 6;
+    const uint32_t tx = tile % ra.tilesPerRow, band8 = tile / ra.tilesPerRow;
+    x = tx * 8u + (lane & 7u);
+    lrow = band8 * 8u + (lane >> 3);
+    const uint32_t lb = lrow / ra.bandRows, r = lrow % ra.bandRows;
+    gy = (lb * ra.shardCount + ra.shardIndex) * ra.bandRows + r;
+    return x < ra.width && lrow < ra.localRows && gy < ra.height;
+}
+
+/* raygen.rgen:83-92 */
+__device__ __forceinline__ rtr_v3 primary_dir(const RenderArgs& ra, uint32_t px, uint32_t py, uint32_t i) {
+    const float jx = rtr_random(px + i), jy = rtr_random(px + i * 322u);
+    const float offx = ((float)px + jx) - 0.5f, offy = ((float)py + jy) - 0.5f;
+    const rtr_v3 pw = rtr_madd(rtr_madd(rtr_ld3(ra.cam.topLeftViewportCorner), rtr_ld3(ra.cam.horizontalViewportDelta), offx),
+                               rtr_ld3(ra.cam.verticalViewportDelta), offy);
+    return rtr_normalize(rtr_sub(pw, rtr_ld3(ra.cam.position)));
+}
+
+struct Accum { rtr_v3 analytic, shadowed, unshadowed, avgNormal, avgPosition; };
+
+/* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110,
+ * miss.rmiss:15-27 with the constant sky).  Policy::occluded(origin, dir, tmax) answers the
+ * shadow query; Policy::kShade == false (generator) skips the BRDF arithmetic but keeps the
+ * exact sequence of queries. */
+template <class Policy, bool STATS>
+__device__ __forceinline__ void shade_sample(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
+                                             const HitRec& h, rtr_v3 rayDir, bool wantAnalytic, Accum& o,
+                                             Policy& pol, LocalStats& st) {
+    if (h.custom == RTR_MISS) {                                                           /* :110-115 */
+        if (Policy::kShade) {
+            const rtr_v3 sky = rtr_ld3(sc.skyLinear);
+            o.analytic = rtr_add(o.analytic, sky); o.unshadowed = rtr_add(o.unshadowed, sky); o.shadowed = rtr_add(o.shadowed, sky);
+        }
+        return;
+    }
+    if (h.custom < sc.numLights) {                                                        /* :116-121 */
+        if (Policy::kShade) {
+            const rtr_v3 lc = rtr_ld3(sc.lights[h.custom].color);
+            o.analytic = rtr_add(o.analytic, lc); o.unshadowed = rtr_add(o.unshadowed, lc); o.shadowed = rtr_add(o.shadowed, lc);
+        }
+        return;
+    }
+    const rtr_v3 camPos = rtr_ld3(ra.cam.position);
+    /* closesthit.rchit:53-106 */
+    if (STATS) st.hits++;
+    const RtrObjectInfo* oi = sc.objects + (h.custom - sc.numLights);
+    const uint32_t vOff = oi->vertexOffset, iOff = oi->indexOffset;
+    const uint32_t i0 = sc.indices[3u * h.prim + 0u + iOff];
+    const uint32_t i1 = sc.indices[3u * h.prim + 1u + iOff];
+    const uint32_t i2 = sc.indices[3u * h.prim + 2u + iOff];
+    const float4* va = reinterpret_cast<const float4*>(sc.vertices + (i0 + vOff));
+    const float4* vb = reinterpret_cast<const float4*>(sc.vertices + (i1 + vOff));
+    const float4* vc = reinterpret_cast<const float4*>(sc.vertices + (i2 + vOff));
+    const rtr_v3 p0 = f4xyz(va[0]), p1 = f4xyz(vb[0]), p2 = f4xyz(vc[0]);
+    const rtr_v3 n0 = f4xyz(va[1]), n1 = f4xyz(vb[1]), n2 = f4xyz(vc[1]);
+    const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+    const rtr_v3 localPos = rtr_madd(rtr_madd(rtr_scale(p0, b0), p1, b1), p2, b2);
+    const rtr_v3 hitPoint = rtr_xform_point34(sc.xforms + 12u * h.custom, localPos);
+    const rtr_v3 nsum = rtr_madd(rtr_madd(rtr_scale(n0, b0), n1, b1), n2, b2);
+    const float* nm = sc.nmats + 12u * h.custom;
+    rtr_v3 hitNormal;
+    if (rtr_dot(nsum, nsum) > 0.0f) {
+        hitNormal = rtr_normalize(rtr_mul33(nm, rtr_normalize(nsum)));
+    } else {
+        const rtr_v3 g = rtr_cross(rtr_sub(p1, p0), rtr_sub(p2, p0));
+        rtr_v3 n = rtr_normalize(rtr_mul33(nm, rtr_normalize(g)));
+        if (rtr_dot(n, rayDir) > 0.0f) n = rtr_neg(n);
+        hitNormal = n;
+    }
+    const float metallic = oi->metallic;
+    const float roughness = 1.0f - oi->specular;
+    rtr_v3 color = rtr_mk(0, 0, 0);
+    if (Policy::kShade) color = rtr_mk(rtr_to_linear(oi->color[0]), rtr_to_linear(oi->color[1]), rtr_to_linear(oi->color[2]));
+
+    const rtr_v3 viewDir = rtr_normalize(rtr_sub(camPos, hitPoint));
+    const float om = 1.0f - metallic;
+    rtr_v3 mDiffuse = rtr_mk(0, 0, 0), mSpecular = rtr_mk(0, 0, 0);
+    float4 t1 = make_float4(1, 0, 0, 1), t2 = make_float4(0, 0, 0, 0);
+    if (Policy::kShade) {
+        o.avgNormal = rtr_add(o.avgNormal, hitNormal);
+        o.avgPosition = rtr_add(o.avgPosition, hitPoint);
+        mDiffuse = rtr_scale(color, om);
+        mSpecular = rtr_mk(rtr_fma(color.x, metallic, 0.04f * om), rtr_fma(color.y, metallic, 0.04f * om),
+                           rtr_fma(color.z, metallic, 0.04f * om));
+        if (wantAnalytic) {
+            const float dotNV = rtr_clamp(rtr_dot(hitNormal, viewDir), 0.0f, 1.0f);
+            const float lu = rtr_fma(roughness, RTR_LUT_SCALE, RTR_LUT_BIAS);
+            const float lv = rtr_fma(rtr_sqrt(1.0f - dotNV), RTR_LUT_SCALE, RTR_LUT_BIAS);
+            t1 = sample_lut(sc.ltc1, lu, lv);
+            t2 = sample_lut(sc.ltc2, lu, lv);
+        }
+    }
+    const rtr_v3 shadowOrigin = rtr_madd(hitPoint, hitNormal, 0.01f);
+
+    for (uint32_t li = 0; li < ra.info.numAreaLights; ++li) {                             /* :165 */
+        const RtrAreaLightInfo* L = sc.lights + li;
+        if (STATS) st.lightFetch++;
+        const rtr_v3 lcol = rtr_ld3(L->color);
+        const float lintensity = L->intensity;
+        const uint32_t lvOff = L->vertexOffset, liOff = L->indexOffset, lnt = L->numTriangles;
+        const bool twoSided = L->isTwoSided != 0u;
+        for (uint32_t ti = 0; ti < lnt; ++ti) {                                           /* :172 */
+            if (STATS) st.lightTriFetch++;
+            const uint32_t j0 = sc.indices[ti * 3u + 0u + liOff];
+            const uint32_t j1 = sc.indices[ti * 3u + 1u + liOff];
+            const uint32_t j2 = sc.indices[ti * 3u + 2u + liOff];
+            rtr_v3 P[3];
+            P[0] = rtr_xform_point44cm(L->transform, rtr_ld3(sc.vertices[j0 + lvOff].position));
+            P[1] = rtr_xform_point44cm(L->transform, rtr_ld3(sc.vertices[j1 + lvOff].position));
+            P[2] = rtr_xform_point44cm(L->transform, rtr_ld3(sc.vertices[j2 + lvOff].position));
+            rtr_v3 lightNormal = rtr_cross(rtr_sub(P[2], P[1]), rtr_sub(P[0], P[1]));
+            const float area = rtr_length(lightNormal) * 0.5f;
+            const float pdf = 1.0f / (area * 0.7f);
+            lightNormal = rtr_normalize(lightNormal);
+            if (!twoSided) {
+                if (rtr_dot(lightNormal, rtr_sub(hitPoint, P[0])) < 0.0f) continue;
+            }
+            rtr_v3 shadowedSample = rtr_mk(0, 0, 0), unshadowedSample = rtr_mk(0, 0, 0);
+            for (uint32_t s = 0; s < ra.numShadowRays; ++s) {                             /* :206 */
+                const uint32_t seed = s + px * 733u + py * 1933u + ra.info.frame;
+                float r1 = rtr_random(seed), r2 = rtr_random(seed + 100u);
+                if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }
+                const rtr_v3 lightSamplePos = rtr_madd(rtr_madd(P[0], rtr_sub(P[1], P[0]), r1), rtr_sub(P[2], P[0]), r2);
+                const rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
+                const rtr_v3 sampledLightDir = rtr_normalize(lightVec);
+                const float lightDistance = rtr_length(lightVec);
+                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f);
+                if (Policy::kShade) {
+                    const float currShadow = occ ? 0.0f : 1.0f;
+                    const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir));
+                    const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
+                    const float Dg = GGX_Distribution(hitNormal, halfVector, roughness);
+                    const float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
+                                    GGX_PartialGeometryTerm(sampledLightDir, hitNormal, halfVector, roughness);
+                    const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
+                    const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 0.1f);
+                    const float NdotL = rtr_max(rtr_dot(hitNormal, sampledLightDir), 0.1f);
+                    const float den = 4.0f * NdotV * NdotL;
+                    const float DG = Dg * G;
+                    const rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+                    const rtr_v3 currDiffuse = rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
+                    const float attenuation = 1.0f / (lightDistance * lightDistance);
+                    const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
+                    const float lscale = lintensity * NdotL * attenuation * 10.0f;
+                    const rtr_v3 Lr = rtr_scale(lcol, lscale);
+                    const rtr_v3 contrib = rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf);
+                    shadowedSample = rtr_madd(shadowedSample, contrib, currShadow);
+                    unshadowedSample = rtr_add(unshadowedSample, contrib);
+                }
+            }
+            if (Policy::kShade) {
+                const float ns = (float)ra.numShadowRays;
+                shadowedSample = rtr_mk(shadowedSample.x / ns, shadowedSample.y / ns, shadowedSample.z / ns);
+                unshadowedSample = rtr_mk(unshadowedSample.x / ns, unshadowedSample.y / ns, unshadowedSample.z / ns);
+                if (wantAnalytic) {
+                    const float diffuse = LTC_Evaluate(hitNormal, viewDir, hitPoint, true, t1, P, lightNormal, twoSided, sc.ltc2);
+                    const float spec = LTC_Evaluate(hitNormal, viewDir, hitPoint, false, t1, P, lightNormal, twoSided, sc.ltc2);
+                    const rtr_v3 fres = rtr_mk(rtr_fma(1.0f - mSpecular.x, t2.y, mSpecular.x * t2.x),
+                                               rtr_fma(1.0f - mSpecular.y, t2.y, mSpecular.y * t2.x),
+                                               rtr_fma(1.0f - mSpecular.z, t2.y, mSpecular.z * t2.x));
+                    const float li5 = lintensity * 5.0f;
+                    o.analytic = rtr_add(o.analytic, rtr_mk(lcol.x * li5 * rtr_fma(mDiffuse.x, diffuse, spec * fres.x),
+                                                            lcol.y * li5 * rtr_fma(mDiffuse.y, diffuse, spec * fres.y),
+                                                            lcol.z * li5 * rtr_fma(mDiffuse.z, diffuse, spec * fres.z)));
+                }
+                o.shadowed = rtr_add(o.shadowed, shadowedSample);
+                o.unshadowed = rtr_add(o.unshadowed, unshadowedSample);
+            }
+        }
+    }
+    /* directional light, raygen.rgen:289-338 */
+    const rtr_v3 directLightDir = rtr_normalize(rtr_mk(-1.0f, 1.0f, -0.5f));
+    if (rtr_dot(hitNormal, directLightDir) <= 0.0f) return;
+    const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f);
+    if (Policy::kShade) {
+        const rtr_v3 directLightColor = rtr_mk(1.0f, 1.0f, 0.5f);
+        const float directLightIntensity = 0.2f;
+        const float currShadow = occ ? 0.0f : 1.0f;
+        const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, directLightDir));
+        const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
+        const float Dg = GGX_Distribution(hitNormal, halfVector, roughness);
+        const float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
+                        GGX_PartialGeometryTerm(directLightDir, hitNormal, halfVector, roughness);
+        const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
+        const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 5.0f);
+        const float NdotL = rtr_max(rtr_dot(hitNormal, directLightDir), 0.0001f);
+        const float den = 4.0f * NdotV * NdotL;
+        const float DG = Dg * G;
+        const rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+        const rtr_v3 currDiffuse = rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
+        const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
+        const float lscale = directLightIntensity * NdotL * 20.0f;
+        const rtr_v3 Lr = rtr_scale(directLightColor, lscale);
+        const rtr_v3 contrib = rtr_mul(BRDF, Lr);
+        o.shadowed = rtr_madd(o.shadowed, contrib, currShadow);
+        o.unshadowed = rtr_add(o.unshadowed, contrib);
+        o.analytic = rtr_add(o.analytic, contrib);
+    }
+}
+
+__device__ __forceinline__ uint32_t tonemap_pack(rtr_v3 c) {                              /* raygen.rgen:345-357 */
+    return rtr_pack_bgra8(rtr_to_srgb(rtr_aces(c.x)), rtr_to_srgb(rtr_aces(c.y)), rtr_to_srgb(rtr_aces(c.z)));
+}
+
+struct FrameOut {
+    uint32_t* img[8];     /* indexed by rtr_image binding; null when absent */
+    float4* hdr;
+};
+
+/* raygen.rgen:341-364 + the HDR accumulation extension */
+__device__ __forceinline__ void write_pixel(const RenderArgs& ra, const FrameOut& fo, size_t p, Accum o) {
+    const float n = (float)ra.spp;
+    rtr_v3 sh = rtr_mk(o.shadowed.x / n, o.shadowed.y / n, o.shadowed.z / n);
+    const rtr_v3 un = rtr_mk(o.unshadowed.x / n, o.unshadowed.y / n, o.unshadowed.z / n);
+    const rtr_v3 an = rtr_mk(o.analytic.x / n, o.analytic.y / n, o.analytic.z / n);
+    if (fo.hdr) {
+        if (ra.accumulate) {
+            float4 h = fo.hdr[p];
+            h.x += sh.x; h.y += sh.y; h.z += sh.z; h.w += 1.0f;
+            fo.hdr[p] = h;
+            const float inv = (float)(ra.accumulatedFrames + 1u);
+            sh = rtr_mk(h.x / inv, h.y / inv, h.z / inv);
+        } else {
+            fo.hdr[p] = make_float4(sh.x, sh.y, sh.z, 1.0f);
+        }
+    }
+    if (fo.img[1]) fo.img[1][p] = tonemap_pack(sh);
+    if (fo.img[2]) fo.img[2][p] = tonemap_pack(un);
+    if (fo.img[0]) fo.img[0][p] = tonemap_pack(an);
+    if (fo.img[6]) {
+        const rtr_v3 a = rtr_normalize(rtr_mk(o.avgNormal.x / n, o.avgNormal.y / n, o.avgNormal.z / n));
+        fo.img[6][p] = rtr_pack_bgra8(a.x, a.y, a.z);
+    }
+    if (fo.img[7]) fo.img[7][p] = rtr_pack_bgra8(o.avgPosition.x / n, o.avgPosition.y / n, o.avgPosition.z / n);
+}
+
+}  // namespace rtrdev

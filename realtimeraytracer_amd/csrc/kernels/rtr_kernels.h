@@ -1,0 +1,33 @@
+/* rtr_kernels.h — host-callable launchers of the HIP kernels (internal to librtr_hip.so). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rtr_device.h"
+
+namespace rtrdev {
+
+/* Scratch of the wavefront (staged) pipeline, owned by an rtr_frame. */
+struct Workspace {
+    float4*   hitTuvp = nullptr;     /* per (pixel,sample): t,u,v,bits(primitiveID) */
+    uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
+    float4*   rayQueue = nullptr;    /* 2 x float4 per queued shadow ray: (o.xyz,tmax) (d.xyz,bits(slot)) */
+    uint8_t*  vis = nullptr;         /* per slot: 1 = occluded */
+    uint32_t* queueCount = nullptr;  /* device counter of queued rays */
+    size_t    capPixelSamples = 0;
+    size_t    capRays = 0;
+};
+
+struct LaunchTimes { float traceMs = 0.f, shadeMs = 0.f, resolveMs = 0.f; };
+
+/* stackEntries must be one of 16, 32, 64. */
+hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, int stackEntries,
+                             Counters* stats, hipStream_t stream);
+
+/* Staged pipeline: primary trace -> shadow-ray generation (ballot-compacted queue) -> any-hit trace
+ * -> resolve.  `ev` (5 events, may be null) are recorded between stages for per-stage timing. */
+hipError_t launch_wavefront(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, const Workspace& ws,
+                            int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev);
+
+hipError_t launch_deinterleave(const uint32_t* gathered, uint32_t* dst, uint32_t width, uint32_t height,
+                               uint32_t bandRows, uint32_t shardCount, uint32_t localRows, hipStream_t stream);
+
+}  // namespace rtrdev

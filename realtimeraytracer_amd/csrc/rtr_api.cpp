@@ -1,0 +1,601 @@
+/* rtr_api.cpp — implementation of the C ABI in include/rtr.h (host side of librtr_hip.so).
+ * HIP runtime for device memory / streams / events; kernels in kernels/rtr_kernels.hip.
+ * There is NO CPU rendering fallback in this library: without a HIP device every entry point
+ * that needs one fails with RTR_ERR_NO_DEVICE / RTR_ERR_HIP. */
+#include "../../include/rtr.h"
+#include "../../include/rtr_math.h"
+#include "bvh_build.h"
+#include "kernels/rtr_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using rtrdev::Counters;
+using rtrdev::DeviceScene;
+using rtrdev::FrameOut;
+using rtrdev::RenderArgs;
+using rtrdev::Workspace;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? RTR_ERR_OUT_OF_MEMORY : RTR_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const T* src, size_t count, hipStream_t s) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess) return e;
+        if (count == 0 || !src) return hipSuccess;
+        e = hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(s);
+    }
+};
+
+}  // namespace
+
+struct rtr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    hipDeviceProp_t prop;
+};
+
+struct rtr_scene {
+    rtr_ctx* ctx = nullptr;
+    DevBuf<float4> nodes, tris;
+    DevBuf<RtrVertex> vertices;
+    DevBuf<uint32_t> indices;
+    DevBuf<RtrObjectInfo> objects;
+    DevBuf<RtrAreaLightInfo> lights;
+    DevBuf<float> xforms, nmats, ltc1, ltc2;
+    std::vector<RtrBvhNode> hostNodes;
+    std::vector<RtrBvhTri> hostTris;
+    std::vector<RtrAreaLightInfo> hostLights;
+    rtr_scene_stats stats{};
+    DeviceScene dev{};
+    uint32_t numLights = 0, numObjects = 0, numVertices = 0, numIndices = 0;
+    bool hasLtc = false;
+};
+
+struct rtr_frame {
+    rtr_ctx* ctx = nullptr;
+    uint32_t width = 0, rows = 0, images = 0;
+    DevBuf<uint32_t> img[8];
+    uint32_t* ext[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf<float4> hdr;
+    /* wavefront scratch */
+    DevBuf<float4> hitTuvp, rayQueue;
+    DevBuf<uint32_t> hitCustom, queueCount;
+    DevBuf<uint8_t> vis;
+    DevBuf<Counters> counters;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evMega[2] = {nullptr, nullptr};
+    rtr_frame_stats stats{};
+    bool pendingStats = false, pendingWave = false, pendingCounters = false;
+    uint32_t pendingImagesK = 0; bool pendingHdr = false, pendingAccum = false;
+    uint32_t* image_ptr(int which) const { return ext[which] ? ext[which] : img[which].p; }
+};
+
+extern "C" {
+
+const char* rtr_last_error(void) { return g_err.c_str(); }
+
+const char* rtr_status_string(int s) {
+    switch (s) {
+        case RTR_OK: return "RTR_OK";
+        case RTR_ERR_INVALID_ARGUMENT: return "RTR_ERR_INVALID_ARGUMENT";
+        case RTR_ERR_HIP: return "RTR_ERR_HIP";
+        case RTR_ERR_NO_DEVICE: return "RTR_ERR_NO_DEVICE";
+        case RTR_ERR_UNSUPPORTED: return "RTR_ERR_UNSUPPORTED";
+        case RTR_ERR_OUT_OF_MEMORY: return "RTR_ERR_OUT_OF_MEMORY";
+        case RTR_ERR_BVH_TOO_DEEP: return "RTR_ERR_BVH_TOO_DEEP";
+        case RTR_ERR_IO: return "RTR_ERR_IO";
+        default: return "RTR_ERR_UNKNOWN";
+    }
+}
+
+int rtr_abi_version(void) { return RTR_ABI_VERSION; }
+
+uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount) {
+    if (bandRows == 0) bandRows = 8;
+    if (shardCount == 0) shardCount = 1;
+    uint32_t bands = (height + bandRows - 1) / bandRows;
+    uint32_t per = (bands + shardCount - 1) / shardCount;
+    return per * bandRows;
+}
+
+/* ---- context ------------------------------------------------------------------------------ */
+int rtr_ctx_create(int ordinal, rtr_ctx** out) {
+    if (!out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RTR_ERR_NO_DEVICE, "rtr_ctx_create: no HIP device (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (ordinal < 0 || ordinal >= count) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_create: ordinal %d not in [0,%d)", ordinal, count);
+    HIP_TRY(hipSetDevice(ordinal));
+    rtr_ctx* c = new rtr_ctx();
+    c->device = ordinal;
+    e = hipGetDeviceProperties(&c->prop, ordinal);
+    if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->ownStream = true;
+    *out = c;
+    return RTR_OK;
+}
+
+void rtr_ctx_destroy(rtr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rtr_ctx_set_stream(rtr_ctx* c, void* s) {
+    if (!c) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_set_stream: ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->ownStream && c->stream) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipStreamDestroy(c->stream); }
+    if (s) { c->stream = (hipStream_t)s; c->ownStream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
+    return RTR_OK;
+}
+
+int rtr_ctx_device_name(rtr_ctx* c, char* buf, size_t bytes) {
+    if (!c || !buf || bytes == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_device_name: bad argument");
+    snprintf(buf, bytes, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    return RTR_OK;
+}
+
+/* ---- scene -------------------------------------------------------------------------------- */
+static int validate_desc(const rtr_scene_desc* d) {
+    if (!d) return fail(RTR_ERR_INVALID_ARGUMENT, "scene desc is null");
+    if ((d->numVertices && !d->vertices) || (d->numIndices && !d->indices) || (d->numMeshes && !d->meshes) ||
+        (d->numInstances && !d->instances) || (d->numObjects && !d->objects) || (d->numLights && !d->lights))
+        return fail(RTR_ERR_INVALID_ARGUMENT, "scene desc: null array with non-zero count");
+    if ((d->ltc1 == nullptr) != (d->ltc2 == nullptr)) return fail(RTR_ERR_INVALID_ARGUMENT, "scene desc: ltc1 and ltc2 must both be given or both null");
+    for (uint32_t m = 0; m < d->numMeshes; ++m) {
+        const RtrMesh& me = d->meshes[m];
+        if (me.indexCount % 3u) return fail(RTR_ERR_INVALID_ARGUMENT, "mesh %u: indexCount %u not a multiple of 3", m, me.indexCount);
+        if ((uint64_t)me.indexOffset + me.indexCount > d->numIndices) return fail(RTR_ERR_INVALID_ARGUMENT, "mesh %u: index range exceeds the index array", m);
+        if ((uint64_t)me.vertexOffset + me.vertexCount > d->numVertices) return fail(RTR_ERR_INVALID_ARGUMENT, "mesh %u: vertex range exceeds the vertex array", m);
+        for (uint32_t i = 0; i < me.indexCount; ++i)
+            if (d->indices[me.indexOffset + i] >= me.vertexCount)
+                return fail(RTR_ERR_INVALID_ARGUMENT, "mesh %u: index %u (= %u) outside its %u vertices", m, i, d->indices[me.indexOffset + i], me.vertexCount);
+    }
+    std::vector<uint8_t> seen(d->numInstances, 0);
+    for (uint32_t i = 0; i < d->numInstances; ++i) {
+        const RtrInstance& in = d->instances[i];
+        if (in.meshIndex >= d->numMeshes) return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: meshIndex %u >= %u", i, in.meshIndex, d->numMeshes);
+        if (in.customIndex >= d->numInstances || seen[in.customIndex]) return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: customIndex %u out of range or duplicated", i, in.customIndex);
+        seen[in.customIndex] = 1;
+        if (in.customIndex >= d->numLights && in.customIndex - d->numLights >= d->numObjects)
+            return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: customIndex %u has no ObjectInfo (numLights %u, numObjects %u)", i, in.customIndex, d->numLights, d->numObjects);
+        for (int k = 0; k < 12; ++k)
+            if (!(in.transform[k] == in.transform[k]) || in.transform[k] > 3.0e38f || in.transform[k] < -3.0e38f)
+                return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: non-finite transform", i);
+    }
+    if (d->numLights > d->numInstances) return fail(RTR_ERR_INVALID_ARGUMENT, "numLights %u > numInstances %u (lights are the first instances)", d->numLights, d->numInstances);
+    for (uint32_t o = 0; o < d->numObjects; ++o) {
+        const RtrObjectInfo& oi = d->objects[o];
+        if (oi.usesColorMap || oi.usesSpecularMap || oi.usesMetallicMap || oi.usesOpacityMap)
+            return fail(RTR_ERR_UNSUPPORTED, "object %u uses a texture map; textures are a 'next' row of SURVEY §8f and not built yet", o);
+    }
+    for (uint32_t l = 0; l < d->numLights; ++l) {
+        const RtrAreaLightInfo& li = d->lights[l];
+        if ((uint64_t)li.indexOffset + 3ull * li.numTriangles > d->numIndices) return fail(RTR_ERR_INVALID_ARGUMENT, "light %u: triangle range exceeds the index array", l);
+        for (uint32_t i = 0; i < 3u * li.numTriangles; ++i)
+            if ((uint64_t)li.vertexOffset + d->indices[li.indexOffset + i] >= d->numVertices)
+                return fail(RTR_ERR_INVALID_ARGUMENT, "light %u: vertex reference outside the vertex array", l);
+    }
+    return RTR_OK;
+}
+
+/* flatten TLAS instances to one world-space triangle soup (instance order, then primitive order),
+ * fill the per-customIndex transform tables, build the BVH */
+static int flatten_and_build(const rtr_scene_desc* d, rtr::BvhResult& bvh, std::vector<float>& xforms, std::vector<float>& nmats,
+                             uint32_t* stackEntries, size_t* numTris) {
+    std::vector<rtr::WorldTriangle> soup;
+    size_t total = 0;
+    for (uint32_t i = 0; i < d->numInstances; ++i) total += d->meshes[d->instances[i].meshIndex].indexCount / 3u;
+    soup.reserve(total);
+    xforms.assign(12 * (size_t)d->numInstances, 0.f);
+    nmats.assign(12 * (size_t)d->numInstances, 0.f);
+    for (uint32_t i = 0; i < d->numInstances; ++i) {
+        const RtrInstance& in = d->instances[i];
+        const RtrMesh& me = d->meshes[in.meshIndex];
+        memcpy(&xforms[12 * (size_t)in.customIndex], in.transform, 12 * sizeof(float));
+        rtr_normal_matrix(in.transform, &nmats[12 * (size_t)in.customIndex]);
+        for (uint32_t t = 0; t < me.indexCount / 3u; ++t) {
+            rtr::WorldTriangle w;
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t idx = d->indices[me.indexOffset + 3u * t + k] + me.vertexOffset;
+                const rtr_v3 p = rtr_xform_point34(in.transform, rtr_ld3(d->vertices[idx].position));
+                w.v[k][0] = p.x; w.v[k][1] = p.y; w.v[k][2] = p.z;
+            }
+            w.customIndex = in.customIndex; w.primitiveId = t; w.flags = 0;
+            soup.push_back(w);
+        }
+    }
+    std::string err;
+    if (!rtr::build_bvh(soup, bvh, &err)) return fail(RTR_ERR_INVALID_ARGUMENT, "BVH build: %s", err.c_str());
+    if (bvh.maxDepth > 64)
+        return fail(RTR_ERR_BVH_TOO_DEEP, "BVH depth %u exceeds the 64-entry LDS traversal stack", bvh.maxDepth);
+    *stackEntries = bvh.maxDepth <= 16 ? 16 : (bvh.maxDepth <= 32 ? 32 : 64);
+    *numTris = soup.size();
+    return RTR_OK;
+}
+
+static void fill_stats(rtr_scene_stats& st, const rtr::BvhResult& bvh, uint32_t stackEntries, size_t numTris) {
+    memset(&st, 0, sizeof st);
+    st.numTriangles = (uint32_t)numTris;
+    st.numNodes = (uint32_t)bvh.nodes.size();
+    st.maxDepth = bvh.maxDepth;
+    st.maxLeafSize = bvh.maxLeafSize;
+    st.bvhLayoutVersion = RTR_BVH_LAYOUT_VERSION;
+    st.stackEntries = stackEntries;
+    st.buildMs = bvh.buildMs;
+    st.sahCost = bvh.sahCost;
+    for (int k = 0; k < 3; ++k) { st.boundsMin[k] = bvh.boundsMin[k]; st.boundsMax[k] = bvh.boundsMax[k]; }
+    st.boxPad = bvh.boxPad;
+}
+
+int rtr_host_build_bvh(const rtr_scene_desc* d, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes) {
+    int rc = validate_desc(d);
+    if (rc != RTR_OK) return rc;
+    rtr::BvhResult bvh; std::vector<float> xf, nm; uint32_t stackEntries = 0; size_t numTris = 0;
+    rc = flatten_and_build(d, bvh, xf, nm, &stackEntries, &numTris);
+    if (rc != RTR_OK) return rc;
+    if (stats) fill_stats(*stats, bvh, stackEntries, numTris);
+    if (nodes) {
+        if (nodeBytes != bvh.nodes.size() * sizeof(RtrBvhNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_host_build_bvh: nodeBytes %zu != %zu", nodeBytes, bvh.nodes.size() * sizeof(RtrBvhNode));
+        memcpy(nodes, bvh.nodes.data(), nodeBytes);
+    }
+    if (tris) {
+        if (triBytes != bvh.tris.size() * sizeof(RtrBvhTri)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_host_build_bvh: triBytes %zu != %zu", triBytes, bvh.tris.size() * sizeof(RtrBvhTri));
+        memcpy(tris, bvh.tris.data(), triBytes);
+    }
+    return RTR_OK;
+}
+
+int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
+    if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: null ctx/out");
+    *out = nullptr;
+    int rc = validate_desc(d);
+    if (rc != RTR_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    rtr::BvhResult bvh; std::vector<float> xforms, nmats; uint32_t stackEntries = 0; size_t numTris = 0;
+    rc = flatten_and_build(d, bvh, xforms, nmats, &stackEntries, &numTris);
+    if (rc != RTR_OK) return rc;
+
+    rtr_scene* s = new rtr_scene();
+    s->ctx = ctx;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    static_assert(sizeof(RtrBvhNode) == 4 * sizeof(float4) && sizeof(RtrBvhTri) == 3 * sizeof(float4), "layout");
+    chk(s->nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() * 4, st));
+    chk(s->tris.upload(reinterpret_cast<const float4*>(bvh.tris.data()), bvh.tris.size() * 3, st));
+    chk(s->vertices.upload(d->vertices, d->numVertices, st));
+    chk(s->indices.upload(d->indices, d->numIndices, st));
+    chk(s->objects.upload(d->objects, d->numObjects, st));
+    chk(s->lights.upload(d->lights, d->numLights, st));
+    chk(s->xforms.upload(xforms.data(), xforms.size(), st));
+    chk(s->nmats.upload(nmats.data(), nmats.size(), st));
+    if (d->ltc1) {
+        chk(s->ltc1.upload(d->ltc1, 64 * 64 * 4, st));
+        chk(s->ltc2.upload(d->ltc2, 64 * 64 * 4, st));
+        s->hasLtc = true;
+    }
+    if (e != hipSuccess) {
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? RTR_ERR_OUT_OF_MEMORY : RTR_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+    s->numLights = d->numLights; s->numObjects = d->numObjects; s->numVertices = d->numVertices; s->numIndices = d->numIndices;
+    if (d->numLights) s->hostLights.assign(d->lights, d->lights + d->numLights);
+    fill_stats(s->stats, bvh, stackEntries, numTris);
+    s->hostNodes.swap(bvh.nodes);
+    s->hostTris.swap(bvh.tris);
+
+    DeviceScene& dv = s->dev;
+    dv.nodes = s->nodes.p; dv.tris = s->tris.p;
+    dv.vertices = s->vertices.p; dv.indices = s->indices.p;
+    dv.objects = s->objects.p; dv.lights = s->lights.p;
+    dv.xforms = s->xforms.p; dv.nmats = s->nmats.p;
+    dv.ltc1 = s->hasLtc ? s->ltc1.p : nullptr; dv.ltc2 = s->hasLtc ? s->ltc2.p : nullptr;
+    for (int k = 0; k < 3; ++k) dv.skyLinear[k] = rtr_to_linear(d->skyColor[k]);
+    dv.numLights = d->numLights;
+    *out = s;
+    return RTR_OK;
+}
+
+void rtr_scene_destroy(rtr_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    delete s;
+}
+
+int rtr_scene_get_stats(const rtr_scene* s, rtr_scene_stats* out) {
+    if (!s || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_get_stats: null argument");
+    *out = s->stats;
+    return RTR_OK;
+}
+
+int rtr_scene_export_bvh(const rtr_scene* s, RtrBvhNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes) {
+    if (!s) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_bvh: null scene");
+    if (nodes) {
+        if (nodeBytes != s->hostNodes.size() * sizeof(RtrBvhNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_bvh: nodeBytes %zu != %zu", nodeBytes, s->hostNodes.size() * sizeof(RtrBvhNode));
+        memcpy(nodes, s->hostNodes.data(), nodeBytes);
+    }
+    if (tris) {
+        if (triBytes != s->hostTris.size() * sizeof(RtrBvhTri)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_bvh: triBytes %zu != %zu", triBytes, s->hostTris.size() * sizeof(RtrBvhTri));
+        memcpy(tris, s->hostTris.data(), triBytes);
+    }
+    return RTR_OK;
+}
+
+int rtr_scene_update_lights(rtr_scene* s, const RtrAreaLightInfo* lights, uint32_t n) {
+    if (!s || (!lights && n)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_lights: null argument");
+    if (n != s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_lights: %u lights given, scene has %u (light geometry is part of the BVH)", n, s->numLights);
+    for (uint32_t l = 0; l < n; ++l) {
+        if (lights[l].vertexOffset != s->hostLights[l].vertexOffset || lights[l].indexOffset != s->hostLights[l].indexOffset ||
+            lights[l].numTriangles != s->hostLights[l].numTriangles || memcmp(lights[l].transform, s->hostLights[l].transform, sizeof lights[l].transform))
+            return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_lights: light %u geometry/transform changed; only colour, intensity and sidedness may be updated without a rebuild", l);
+    }
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(s->lights.p, lights, n * sizeof(RtrAreaLightInfo), hipMemcpyHostToDevice, s->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        s->hostLights.assign(lights, lights + n);
+    }
+    return RTR_OK;
+}
+
+/* ---- frame -------------------------------------------------------------------------------- */
+int rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t images, rtr_frame** out) {
+    if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: null ctx/out");
+    *out = nullptr;
+    if (width == 0 || rows == 0 || width > 65536 || rows > 65536) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: bad extent %ux%u", width, rows);
+    if (images == 0) images = RTR_IMAGES_FRAMEBUFFER;
+    const uint32_t known = 0xffu | RTR_IMG_BIT(RTR_IMAGE_HDR);
+    if (images & ~known) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: unknown image bits 0x%x", images & ~known);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rtr_frame* f = new rtr_frame();
+    f->ctx = ctx; f->width = width; f->rows = rows; f->images = images;
+    const size_t px = (size_t)width * rows;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 8 && e == hipSuccess; ++i)
+        if (images & RTR_IMG_BIT(i)) { e = f->img[i].alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->img[i].p, 0, px * 4, ctx->stream); }
+    if (e == hipSuccess && (images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { e = f->hdr.alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->hdr.p, 0, px * 16, ctx->stream); }
+    if (e == hipSuccess) e = f->counters.alloc(1);
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&f->ev[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&f->evMega[i]);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { rtr_frame_destroy(f); return fail(e == hipErrorOutOfMemory ? RTR_ERR_OUT_OF_MEMORY : RTR_ERR_HIP, "rtr_frame_create: %s", hipGetErrorString(e)); }
+    *out = f;
+    return RTR_OK;
+}
+
+void rtr_frame_destroy(rtr_frame* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : f->evMega) if (e) (void)hipEventDestroy(e);
+    delete f;
+}
+
+int rtr_frame_bind_external(rtr_frame* f, int which, void* dptr, size_t bytes) {
+    if (!f || which < 0 || which > 7) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_bind_external: bad argument");
+    if (dptr && bytes != (size_t)f->width * f->rows * 4) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_bind_external: %zu bytes given, image is %zu", bytes, (size_t)f->width * f->rows * 4);
+    if (dptr && ((uintptr_t)dptr & 3u)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_bind_external: pointer not 4-byte aligned");
+    f->ext[which] = (uint32_t*)dptr;
+    if (dptr) f->images |= RTR_IMG_BIT(which);
+    return RTR_OK;
+}
+
+int rtr_frame_device_ptr(const rtr_frame* f, int which, void** dptr, size_t* bytes) {
+    if (!f || !dptr) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_device_ptr: null argument");
+    if (which == RTR_IMAGE_HDR) {
+        if (!f->hdr.p) return fail(RTR_ERR_INVALID_ARGUMENT, "frame has no HDR image");
+        *dptr = f->hdr.p; if (bytes) *bytes = (size_t)f->width * f->rows * 16; return RTR_OK;
+    }
+    if (which < 0 || which > 7 || !f->image_ptr(which)) return fail(RTR_ERR_INVALID_ARGUMENT, "frame has no image %d", which);
+    *dptr = f->image_ptr(which); if (bytes) *bytes = (size_t)f->width * f->rows * 4;
+    return RTR_OK;
+}
+
+int rtr_frame_download(const rtr_frame* f, int which, void* dst, size_t bytes) {
+    if (!f || !dst) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_download: null argument");
+    void* src = nullptr; size_t need = 0;
+    int rc = rtr_frame_device_ptr(f, which, &src, &need);
+    if (rc != RTR_OK) return rc;
+    if (bytes != need) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_download: %zu bytes given, image %d is %zu", bytes, which, need);
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, f->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    return RTR_OK;
+}
+
+int rtr_frame_clear(rtr_frame* f) {
+    if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_clear: null frame");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    const size_t px = (size_t)f->width * f->rows;
+    for (int i = 0; i < 8; ++i) if (f->image_ptr(i)) HIP_TRY(hipMemsetAsync(f->image_ptr(i), 0, px * 4, f->ctx->stream));
+    if (f->hdr.p) HIP_TRY(hipMemsetAsync(f->hdr.p, 0, px * 16, f->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    return RTR_OK;
+}
+
+/* ---- dispatch ------------------------------------------------------------------------------ */
+static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* pin, rtr_frame* f) {
+    if (!s || !cam || !info || !pin || !f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: null argument");
+    if (s->ctx != f->ctx) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: scene and frame belong to different contexts");
+    rtr_render_params p = *pin;
+    if (p.bandRows == 0) p.bandRows = 8;
+    if (p.shardCount == 0) p.shardCount = 1;
+    if (p.images == 0) p.images = RTR_IMAGES_FRAMEBUFFER;
+    if (p.width == 0 || p.height == 0 || p.spp == 0 || p.spp > 1024 || p.numShadowRays > 1024)
+        return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: bad width/height/spp/numShadowRays (%u,%u,%u,%u)", p.width, p.height, p.spp, p.numShadowRays);
+    if (p.bandRows % 8u) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: bandRows %u must be a multiple of 8 (one wave = one 8x8 tile)", p.bandRows);
+    if (p.shardIndex >= p.shardCount) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: shardIndex %u >= shardCount %u", p.shardIndex, p.shardCount);
+    if (info->numAreaLights > s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: SceneInfo.numAreaLights %u > scene lights %u", info->numAreaLights, s->numLights);
+    const uint32_t rows = rtr_shard_rows(p.height, p.bandRows, p.shardCount);
+    if (f->width != p.width || f->rows != rows) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame is %ux%u, this shard needs %ux%u", f->width, f->rows, p.width, rows);
+    if (p.images & RTR_IMAGES_DENOISE) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: denoise/combine images are produced by rtr_denoise_combine, not by the ray-gen dispatch");
+    if ((p.images & RTR_IMG_BIT(RTR_IMAGE_ANALYTIC)) && !s->hasLtc) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: RTR_IMAGE_ANALYTIC needs the LTC tables (rtr_scene_desc.ltc1/ltc2)");
+    const bool wantHdr = (p.images & RTR_IMG_BIT(RTR_IMAGE_HDR)) != 0 || p.accumulate;
+    if (wantHdr && !f->hdr.p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: HDR accumulation requested but the frame has no RTR_IMAGE_HDR");
+    FrameOut fo{};
+    uint32_t k = 0;
+    for (int i = 0; i < 8; ++i) {
+        fo.img[i] = nullptr;
+        if (p.images & RTR_IMG_BIT(i)) {
+            if (!f->image_ptr(i)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: image %d requested but not in the frame", i);
+            fo.img[i] = f->image_ptr(i); ++k;
+        }
+    }
+    fo.hdr = wantHdr ? f->hdr.p : nullptr;
+
+    RenderArgs ra{};
+    ra.cam = *cam; ra.info = *info;
+    ra.width = p.width; ra.height = p.height; ra.spp = p.spp; ra.numShadowRays = p.numShadowRays;
+    ra.bandRows = p.bandRows; ra.shardIndex = p.shardIndex; ra.shardCount = p.shardCount;
+    ra.localRows = rows; ra.tilesPerRow = (p.width + 7u) / 8u;
+    ra.images = p.images; ra.accumulate = p.accumulate; ra.accumulatedFrames = p.accumulatedFrames;
+    uint64_t maxRays = 1;
+    for (uint32_t l = 0; l < info->numAreaLights; ++l) maxRays += (uint64_t)s->hostLights[l].numTriangles * p.numShadowRays;
+    ra.maxRaysPerSample = (uint32_t)maxRays;
+
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    Counters* dstats = nullptr;
+    if (p.collectStats) { HIP_TRY(hipMemsetAsync(f->counters.p, 0, sizeof(Counters), st)); dstats = f->counters.p; }
+
+    const uint64_t paddedPixels = (uint64_t)((rows + 7u) / 8u) * ra.tilesPerRow * 64u;
+    const uint64_t blocks = (paddedPixels + 255u) / 256u;
+    const uint64_t nPS = blocks * 256u * p.spp;
+    const uint64_t nSlots = nPS * maxRays;
+    bool wave = p.pipeline != 1;
+    if (wave && (nSlots >= (1ull << 31) || maxRays > 4096)) {
+        if (p.pipeline == 2) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: wavefront scratch would need %llu visibility slots", (unsigned long long)nSlots);
+        wave = false;
+    }
+    if (blocks >= (1ull << 31)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame too large");
+
+    f->pendingWave = wave; f->pendingCounters = p.collectStats != 0;
+    f->pendingImagesK = k; f->pendingHdr = wantHdr; f->pendingAccum = p.accumulate != 0;
+    memset(&f->stats, 0, sizeof f->stats);
+    f->stats.localRows = rows; f->stats.localPixels = rows * p.width;
+    hipError_t e;
+    if (wave) {
+        if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); }
+        if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); }
+        if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(1));
+        Workspace ws;
+        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
+        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots;
+        e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev);
+    } else {
+        (void)hipEventRecord(f->evMega[0], st);
+        e = rtrdev::launch_megakernel(s->dev, ra, fo, (int)s->stats.stackEntries, dstats, st);
+        (void)hipEventRecord(f->evMega[1], st);
+    }
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    f->pendingStats = true;
+    return RTR_OK;
+}
+
+int rtr_frame_wait(rtr_frame* f) {
+    if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_wait: null frame");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    if (!f->pendingStats) return RTR_OK;
+    f->pendingStats = false;
+    rtr_frame_stats& s = f->stats;
+    if (f->pendingWave) {
+        float a = 0, b = 0, c = 0, d = 0;
+        (void)hipEventElapsedTime(&a, f->ev[0], f->ev[1]);
+        (void)hipEventElapsedTime(&b, f->ev[1], f->ev[2]);
+        (void)hipEventElapsedTime(&c, f->ev[2], f->ev[3]);
+        (void)hipEventElapsedTime(&d, f->ev[3], f->ev[4]);
+        s.traceMs = a + c; s.shadeMs = b; s.resolveMs = d; s.totalMs = a + b + c + d;
+    } else {
+        float a = 0;
+        (void)hipEventElapsedTime(&a, f->evMega[0], f->evMega[1]);
+        s.traceMs = a; s.totalMs = a;
+    }
+    if (f->pendingCounters) {
+        Counters h;
+        HIP_TRY(hipMemcpy(&h, f->counters.p, sizeof h, hipMemcpyDeviceToHost));
+        s.numRays = h.rays; s.numPrimaryRays = h.primary; s.numShadowRays = h.shadow;
+        s.numNodeVisits = h.nodes; s.numTriTests = h.tris; s.numHits = h.hits;
+        s.numLightFetches = h.lightFetch; s.numLightTriFetches = h.lightTriFetch;
+        s.algorithmicBytes = 64ull * h.nodes + 48ull * h.tris + 236ull * h.hits + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
+                             4ull * f->pendingImagesK * s.localPixels + (f->pendingHdr ? (f->pendingAccum ? 32ull : 16ull) * s.localPixels : 0ull);
+    }
+    return RTR_OK;
+}
+
+int rtr_render_async(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, rtr_frame* f) {
+    return enqueue_render(s, cam, info, p, f);
+}
+
+int rtr_render(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, rtr_frame* f) {
+    int rc = enqueue_render(s, cam, info, p, f);
+    if (rc != RTR_OK) return rc;
+    return rtr_frame_wait(f);
+}
+
+int rtr_frame_get_stats(const rtr_frame* f, rtr_frame_stats* out) {
+    if (!f || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_get_stats: null argument");
+    *out = f->stats;
+    return RTR_OK;
+}
+
+int rtr_deinterleave_bands(rtr_ctx* ctx, const void* gathered, void* dst, uint32_t width, uint32_t height, uint32_t bandRows, uint32_t shardCount) {
+    if (!ctx || !gathered || !dst || width == 0 || height == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_deinterleave_bands: bad argument");
+    if (bandRows == 0) bandRows = 8;
+    if (shardCount == 0) shardCount = 1;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t localRows = rtr_shard_rows(height, bandRows, shardCount);
+    hipError_t e = rtrdev::launch_deinterleave((const uint32_t*)gathered, (uint32_t*)dst, width, height, bandRows, shardCount, localRows, ctx->stream);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "deinterleave launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RTR_OK;
+}
+
+}  // extern "C"

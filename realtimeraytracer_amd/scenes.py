@@ -1,0 +1,426 @@
+"""Synthetic scenes of BASELINE.json's configs, written as OBJ+MTL files so they go through the same
+ingest path a real asset would (core::file::loadOBJandMTL), plus the camera / light set-ups.
+
+No asset ships with the reference (its /assets is git-ignored) and there is no network,
+so: the Cornell box is re-authored from the public Cornell measurement data (same numbers as the
+model tinyobjloader's test-suite carries: 8 shapes, 36 triangles); "bunny"-class is a displaced
+icosphere (81,920 triangles, smooth normals); "Sponza"-class is a procedural atrium with colonnades,
+arches and draped cloth (~262 k triangles, 20+ shapes/materials).  A real OBJ can be substituted with
+`custom_obj()`.
+"""
+import hashlib
+import os
+import tempfile
+
+import numpy as np
+
+from . import host
+
+
+def _cache_dir():
+    d = os.environ.get("RTR_SCENE_CACHE") or os.path.join(tempfile.gettempdir(), "rtr_scene_cache")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+# ---------------------------------------------------------------------------------------------
+# Cornell box (configs 1, 2)
+# ---------------------------------------------------------------------------------------------
+_CORNELL_MTL = """newmtl white
+Ka 0 0 0
+Kd 1 1 1
+Ks 0 0 0
+
+newmtl red
+Ka 0 0 0
+Kd 1 0 0
+Ks 0 0 0
+
+newmtl green
+Ka 0 0 0
+Kd 0 1 0
+Ks 0 0 0
+
+newmtl blue
+Ka 0 0 0
+Kd 0 0 1
+Ks 0 0 0
+
+newmtl light
+Ka 20 20 20
+Kd 1 1 1
+Ks 0 0 0
+"""
+
+
+def _quad(pts):
+    return "".join("v %s %s %s\n" % tuple(repr(float(c)) for c in p) for p in pts) + "f -4 -3 -2 -1\n"
+
+
+def cornell_obj_text():
+    """Cornell box geometry (Cornell University Program of Computer Graphics measured data):
+    floor with the two block footprints, light, ceiling, back wall, (face-less front wall),
+    green wall, red wall, short block, tall block."""
+    o = ["# Cornell box, re-authored from the public Cornell measurement data\n", "mtllib cornell_box.mtl\n\n"]
+    o.append("o floor\nusemtl white\n")
+    floor = [(552.8, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 559.2), (549.6, 0.0, 559.2),
+             (130.0, 0.0, 65.0), (82.0, 0.0, 225.0), (240.0, 0.0, 272.0), (290.0, 0.0, 114.0),
+             (423.0, 0.0, 247.0), (265.0, 0.0, 296.0), (314.0, 0.0, 456.0), (472.0, 0.0, 406.0)]
+    o.append("".join("v %r %r %r\n" % p for p in floor))
+    o.append("f 1 2 3 4\nf 8 7 6 5\nf 12 11 10 9\n\n")
+    o.append("o light\nusemtl light\n" + _quad([(343.0, 548.0, 227.0), (343.0, 548.0, 332.0), (213.0, 548.0, 332.0), (213.0, 548.0, 227.0)]) + "\n")
+    o.append("o ceiling\nusemtl white\n" + _quad([(556.0, 548.8, 0.0), (556.0, 548.8, 559.2), (0.0, 548.8, 559.2), (0.0, 548.8, 0.0)]) + "\n")
+    o.append("o back_wall\nusemtl white\n" + _quad([(549.6, 0.0, 559.2), (0.0, 0.0, 559.2), (0.0, 548.8, 559.2), (556.0, 548.8, 559.2)]) + "\n")
+    o.append("o front_wall\nusemtl blue\n" + "".join("v %r %r %r\n" % p for p in [(549.6, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 548.8, 0.0), (556.0, 548.8, 0.0)]) + "\n")
+    o.append("o green_wall\nusemtl green\n" + _quad([(0.0, 0.0, 559.2), (0.0, 0.0, 0.0), (0.0, 548.8, 0.0), (0.0, 548.8, 559.2)]) + "\n")
+    o.append("o red_wall\nusemtl red\n" + _quad([(552.8, 0.0, 0.0), (549.6, 0.0, 559.2), (556.0, 548.8, 559.2), (556.0, 548.8, 0.0)]) + "\n")
+    sb = [(130.0, 65.0), (82.0, 225.0), (240.0, 272.0), (290.0, 114.0)]
+    o.append("o short_block\nusemtl white\n")
+    o.append(_quad([(x, 165.0, z) for x, z in sb]))
+    for a, b in ((3, 2), (0, 3), (1, 0), (2, 1)):
+        (xa, za), (xb, zb) = sb[a], sb[b]
+        o.append(_quad([(xa, 0.0, za), (xa, 165.0, za), (xb, 165.0, zb), (xb, 0.0, zb)]))
+    tb = [(423.0, 247.0), (265.0, 296.0), (314.0, 456.0), (472.0, 406.0)]
+    o.append("\no tall_block\nusemtl white\n")
+    o.append(_quad([(x, 330.0, z) for x, z in tb]))
+    for a, b in ((0, 3), (3, 2), (2, 1), (1, 0)):
+        (xa, za), (xb, zb) = tb[a], tb[b]
+        o.append(_quad([(xa, 0.0, za), (xa, 330.0, za), (xb, 330.0, zb), (xb, 0.0, zb)]))
+    return "".join(o)
+
+
+def write_cornell(directory=None):
+    d = directory or _cache_dir()
+    obj, mtl = os.path.join(d, "cornell_box.obj"), os.path.join(d, "cornell_box.mtl")
+    with open(obj, "w") as f:
+        f.write(cornell_obj_text())
+    with open(mtl, "w") as f:
+        f.write(_CORNELL_MTL)
+    return obj, d + "/"
+
+
+# ---------------------------------------------------------------------------------------------
+# OBJ writer for the procedural meshes
+# ---------------------------------------------------------------------------------------------
+class ObjWriter:
+    """Accumulates shapes (positions + per-vertex normals + triangles) and writes OBJ + MTL."""
+
+    def __init__(self):
+        self.shapes = []
+        self.materials = {}
+
+    def material(self, name, kd, ks=0.0, metallic=None):
+        self.materials[name] = (tuple(kd), float(ks), metallic)
+
+    def shape(self, name, material, verts, normals, tris):
+        self.shapes.append((name, material, np.asarray(verts, np.float64), np.asarray(normals, np.float64), np.asarray(tris, np.int64)))
+
+    def num_triangles(self):
+        return int(sum(len(s[4]) for s in self.shapes))
+
+    def write(self, obj_path, mtl_name):
+        lines = ["mtllib %s\n" % mtl_name]
+        base = 0
+        for name, mat, v, n, t in self.shapes:
+            lines.append("o %s\nusemtl %s\n" % (name, mat))
+            lines.append("".join("v %.6f %.6f %.6f\n" % tuple(p) for p in v))
+            lines.append("".join("vn %.6f %.6f %.6f\n" % tuple(p) for p in n))
+            tt = t + 1 + base
+            lines.append("".join("f %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c) for a, b, c in tt))
+            base += len(v)
+        with open(obj_path, "w") as f:
+            f.write("".join(lines))
+        with open(os.path.join(os.path.dirname(obj_path), mtl_name), "w") as f:
+            for name, (kd, ks, metallic) in self.materials.items():
+                f.write("newmtl %s\nKa 0 0 0\nKd %.4f %.4f %.4f\nKs %.4f %.4f %.4f\n" % (name, kd[0], kd[1], kd[2], ks, ks, ks))
+                if metallic is not None:
+                    f.write("metallic %.4f\n" % metallic)
+                f.write("\n")
+
+
+def _normalize(v):
+    return v / np.maximum(np.linalg.norm(v, axis=-1, keepdims=True), 1e-30)
+
+
+def grid_patch(fn, nu, nv):
+    """Tessellate a parametric surface fn(u,v)->(pos, normal), u,v in [0,1], into nu x nv quads."""
+    u, v = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    p, n = fn(u.ravel(), v.ravel())
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+    return p, _normalize(n), tris
+
+
+def icosphere(subdiv):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = _normalize(np.array(v, np.float64))
+    f = np.array(f, np.int64)
+    for _ in range(subdiv):
+        edges = {}
+        verts = list(v)
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in edges:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                edges[key] = len(verts) - 1
+            return edges[key]
+        nf = []
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        v, f = np.array(verts), np.array(nf, np.int64)
+    return v, f
+
+
+def _vertex_normals(v, f):
+    n = np.zeros_like(v)
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    for k in range(3):
+        np.add.at(n, f[:, k], fn)
+    return _normalize(n)
+
+
+def write_bunny_class(directory=None, subdiv=6):
+    """'bunny'-class stand-in (config 3): icosphere subdivided `subdiv` times (6 -> 81,920 triangles),
+    displaced by a few low-frequency lobes so the BVH is not a perfect sphere, on a ground slab."""
+    d = directory or _cache_dir()
+    obj = os.path.join(d, "bunny_class_%d.obj" % subdiv)
+    if os.path.exists(obj):
+        return obj, d + "/"
+    v, f = icosphere(subdiv)
+    r = 1.0 + 0.18 * np.sin(3.0 * v[:, 0] + 1.0) * np.sin(2.0 * v[:, 1]) + 0.10 * np.sin(5.0 * v[:, 2] + 0.5) + 0.05 * np.sin(9.0 * v[:, 0] * v[:, 1])
+    p = v * r[:, None] * 100.0
+    p[:, 1] += 130.0
+    w = ObjWriter()
+    w.material("clay", (0.75, 0.6, 0.45), ks=0.3)
+    w.material("ground", (0.6, 0.6, 0.6), ks=0.1)
+    w.shape("bunny", "clay", p, _vertex_normals(p, f), f)
+    gp, gn, gt = grid_patch(lambda u, vv: (np.stack([(u - 0.5) * 1200.0, np.zeros_like(u), (vv - 0.5) * 1200.0], 1),
+                                           np.stack([np.zeros_like(u), np.ones_like(u), np.zeros_like(u)], 1)), 16, 16)
+    w.shape("ground", "ground", gp, gn, gt[:, ::-1])
+    w.write(obj, "bunny_class.mtl")
+    return obj, d + "/"
+
+
+def write_sponza_class(directory=None):
+    """'Sponza'-class stand-in (configs 4, 5): an atrium 3000 x 1300 x 1400 (cm-like units) with a
+    tessellated floor and walls, two storeys of colonnades, arches, balcony slabs, draped cloth, vases
+    and a centre piece; ~262 k triangles, 20+ shapes with their own materials."""
+    d = directory or _cache_dir()
+    obj = os.path.join(d, "sponza_class.obj")
+    if os.path.exists(obj):
+        return obj, d + "/"
+    w = ObjWriter()
+    mats = {"floor": (0.55, 0.5, 0.45), "wall": (0.7, 0.65, 0.55), "column": (0.8, 0.78, 0.7), "arch": (0.72, 0.7, 0.62),
+            "slab": (0.5, 0.5, 0.5), "cloth_red": (0.7, 0.12, 0.1), "cloth_green": (0.15, 0.5, 0.2), "cloth_blue": (0.15, 0.2, 0.6),
+            "vase": (0.3, 0.5, 0.55), "bronze": (0.8, 0.5, 0.2)}
+    for k, c in mats.items():
+        w.material(k, c, ks=0.6 if k in ("vase", "bronze") else 0.15, metallic=0.9 if k == "bronze" else None)
+    LX, LY, LZ = 3000.0, 1300.0, 1400.0
+
+    def plane(origin, du, dv, nu, nv, flip=False):
+        o, du, dv = np.array(origin, float), np.array(du, float), np.array(dv, float)
+        nrm = np.cross(du, dv)
+        nrm = nrm / np.linalg.norm(nrm)
+        p, n, t = grid_patch(lambda u, v: (o + u[:, None] * du + v[:, None] * dv, np.tile(nrm, (len(u), 1))), nu, nv)
+        return (p, -n, t[:, ::-1]) if flip else (p, n, t)
+
+    # floor (normal +Y) and the four walls (normals inward); roof open to the sky
+    w.shape("floor", "floor", *plane((-LX / 2, 0, -LZ / 2), (0, 0, LZ), (LX, 0, 0), 64, 128))
+    w.shape("wall_back", "wall", *plane((-LX / 2, 0, -LZ / 2), (LX, 0, 0), (0, LY, 0), 64, 32, flip=True))
+    w.shape("wall_front", "wall", *plane((-LX / 2, 0, LZ / 2), (LX, 0, 0), (0, LY, 0), 64, 32))
+    w.shape("wall_left", "wall", *plane((-LX / 2, 0, -LZ / 2), (0, 0, LZ), (0, LY, 0), 64, 32))
+    w.shape("wall_right", "wall", *plane((LX / 2, 0, -LZ / 2), (0, 0, LZ), (0, LY, 0), 64, 32, flip=True))
+
+    def cylinder(cx, cz, y0, y1, radius, nseg, nring, bulge=0.0):
+        def fn(u, v):
+            ang = 2 * np.pi * u
+            rr = radius * (1.0 + bulge * np.sin(np.pi * v))
+            p = np.stack([cx + rr * np.cos(ang), y0 + (y1 - y0) * v, cz + rr * np.sin(ang)], 1)
+            n = np.stack([np.cos(ang), np.zeros_like(u), np.sin(ang)], 1)
+            return p, n
+        p, n, t = grid_patch(fn, nseg, nring)
+        return p, n, t[:, ::-1]
+
+    # two storeys of colonnades along both long sides
+    xs = np.linspace(-LX / 2 + 200, LX / 2 - 200, 12)
+    for storey, (y0, y1, rad) in enumerate(((0.0, 520.0, 38.0), (580.0, 1040.0, 30.0))):
+        for side, z in enumerate((-LZ / 2 + 260, LZ / 2 - 260)):
+            P, N, T, base = [], [], [], 0
+            for cx in xs:
+                p, n, t = cylinder(cx, z, y0, y1, rad, 32, 24, bulge=0.06)
+                P.append(p); N.append(n); T.append(t + base); base += len(p)
+            w.shape("columns_s%d_%d" % (storey, side), "column", np.concatenate(P), np.concatenate(N), np.concatenate(T))
+
+    # arches between neighbouring columns (half tori)
+    def arch(cx0, cx1, z, ybase, tube, nseg, ntube):
+        cxm, R = 0.5 * (cx0 + cx1), 0.5 * (cx1 - cx0)
+
+        def fn(u, v):
+            a, b = np.pi * u, 2 * np.pi * v
+            cxr, cyr = np.cos(a), np.sin(a)
+            p = np.stack([cxm + (R + tube * np.cos(b)) * cxr, ybase + (R + tube * np.cos(b)) * cyr, z + tube * np.sin(b)], 1)
+            n = np.stack([np.cos(b) * cxr, np.cos(b) * cyr, np.sin(b)], 1)
+            return p, n
+        return grid_patch(fn, nseg, ntube)
+    for storey, (ybase, tube) in enumerate(((520.0, 26.0), (1040.0, 20.0))):
+        for side, z in enumerate((-LZ / 2 + 260, LZ / 2 - 260)):
+            P, N, T, base = [], [], [], 0
+            for i in range(len(xs) - 1):
+                p, n, t = arch(xs[i], xs[i + 1], z, ybase, tube, 24, 16)
+                P.append(p); N.append(n); T.append(t + base); base += len(p)
+            w.shape("arches_s%d_%d" % (storey, side), "arch", np.concatenate(P), np.concatenate(N), np.concatenate(T))
+
+    # balcony slabs of the upper storey
+    for side, z0 in enumerate((-LZ / 2, LZ / 2 - 260)):
+        w.shape("slab_%d" % side, "slab", *plane((-LX / 2, 560.0, z0), (0, 0, 260.0), (LX, 0, 0), 8, 32))
+
+    # draped cloth: wavy sheets hanging across the nave
+    def cloth(x0, width, ytop, drop, z0, z1, nu, nv, phase):
+        def fn(u, v):
+            x = x0 + width * u + 25.0 * np.sin(6 * np.pi * v + phase) * np.sin(np.pi * u)
+            sag = drop * (1.0 - (2 * v - 1) ** 2)
+            y = ytop - sag + 18.0 * np.sin(10 * np.pi * u + phase) * np.sin(np.pi * v)
+            z = z0 + (z1 - z0) * v
+            p = np.stack([x, y, z], 1)
+            e = 1e-3
+            # numeric normal
+            x2 = x0 + width * (u + e) + 25.0 * np.sin(6 * np.pi * v + phase) * np.sin(np.pi * (u + e))
+            y2 = ytop - sag + 18.0 * np.sin(10 * np.pi * (u + e) + phase) * np.sin(np.pi * v)
+            pu = np.stack([x2, y2, z], 1) - p
+            sag3 = drop * (1.0 - (2 * (v + e) - 1) ** 2)
+            x3 = x0 + width * u + 25.0 * np.sin(6 * np.pi * (v + e) + phase) * np.sin(np.pi * u)
+            y3 = ytop - sag3 + 18.0 * np.sin(10 * np.pi * u + phase) * np.sin(np.pi * (v + e))
+            pv = np.stack([x3, y3, z0 + (z1 - z0) * (v + e)], 1) - p
+            return p, np.cross(pv, pu)
+        return grid_patch(fn, nu, nv)
+    cloth_mats = ["cloth_red", "cloth_green", "cloth_blue", "cloth_red", "cloth_blue", "cloth_green"]
+    for i in range(6):
+        x0 = -LX / 2 + 300 + i * 420.0
+        w.shape("cloth_%d" % i, cloth_mats[i], *cloth(x0, 260.0, 1180.0, 260.0 + 30.0 * (i % 3), -LZ / 2 + 300, LZ / 2 - 300, 96, 96, 0.7 * i))
+
+    # vases (lathe) along the nave and a bronze centre piece
+    def vase(cx, cz, h, nseg, nring):
+        def fn(u, v):
+            ang = 2 * np.pi * u
+            prof = 22.0 + 26.0 * np.sin(np.pi * v) ** 2 + 8.0 * np.sin(3 * np.pi * v)
+            p = np.stack([cx + prof * np.cos(ang), h * v, cz + prof * np.sin(ang)], 1)
+            n = np.stack([np.cos(ang), 0.3 * np.cos(np.pi * v), np.sin(ang)], 1)
+            return p, n
+        p, n, t = grid_patch(fn, nseg, nring)
+        return p, n, t[:, ::-1]
+    for i in range(8):
+        cx = -LX / 2 + 380 + (i // 2) * 760.0
+        cz = -140.0 if i % 2 == 0 else 140.0
+        w.shape("vase_%d" % i, "vase", *vase(cx, cz, 120.0, 16, 20))
+    v, f = icosphere(4)
+    r = 1.0 + 0.25 * np.sin(4 * v[:, 0]) * np.sin(3 * v[:, 1] + 1.0)
+    p = v * r[:, None] * 90.0 + np.array([0.0, 140.0, 0.0])
+    w.shape("centre_piece", "bronze", p, _vertex_normals(p, f), f)
+    w.write(obj, "sponza_class.mtl")
+    return obj, d + "/"
+
+
+# ---------------------------------------------------------------------------------------------
+# Scene set-ups (host scene + camera), one per BASELINE config family
+# ---------------------------------------------------------------------------------------------
+class SceneSetup:
+    def __init__(self, name, hscene, camera, cam_pos, width, height):
+        self.name, self.host, self.camera_obj, self.cam_pos = name, hscene, camera, cam_pos
+        self.width, self.height = width, height
+        self.desc = hscene.desc
+        self.camera = camera.getGPUData()
+        self.num_lights = hscene.numLights()
+
+    def scene_info(self, frame=0):
+        return host.scene_info(frame, self.num_lights, self.cam_pos)
+
+
+def synthetic_ltc():
+    """Deterministic stand-ins for the 64x64 RGBA32F LTC tables (texSamplers[0], [1]) used when the real
+    ltc_matrix.h data is not supplied by the caller: smooth, positive, in the value range of the real
+    tables (Minv parameters near identity at low roughness; Fresnel scale/bias; sphere form factor in .w)."""
+    a = (np.arange(64, dtype=np.float64) + 0.5) / 64.0
+    r, t = np.meshgrid(a, a, indexing="xy")        # x = roughness, y = sqrt(1-cos)
+    l1 = np.stack([1.0 + 0.6 * r * t, 0.35 * r * t * t, 0.15 * t * r, 1.0 - 0.45 * r * r * (1.0 - 0.5 * t)], -1)
+    l2 = np.stack([0.9 - 0.5 * r * (1 - t), 0.1 + 0.6 * (1 - t) ** 3 * (1 - 0.5 * r), np.zeros_like(r), np.clip(0.5 + 0.5 * (r * 2 - 1) * (1 - t) + 0.45 * t, 0.0, 1.0)], -1)
+    return l1.astype(np.float32), l2.astype(np.float32)
+
+
+def cornell_box(width=256, height=256, directory=None, ltc=None):
+    """Configs 1/2: camera (278,273,-800) -> (278,273,0), fovY 40; one one-sided 'square'
+    area light scaled to the OBJ light quad, 1 unit below it, facing -Y; constant sky."""
+    obj, mtldir = write_cornell(directory)
+    hs = host.HostScene()
+    light = hs.addAreaLight(20.0, (1.0, 0.85, 0.6), False)
+    light.move((278.0, 547.0, 279.5)).scale((130.0, 105.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    hs.addObjMtlPair(obj, mtldir)
+    hs.setSky((0.5, 0.7, 1.0))
+    if ltc is not None:
+        hs.setLTC(*ltc)
+    hs.build()
+    pos = (278.0, 273.0, -800.0)
+    cam = host.Camera(40.0, pos, (278.0, 273.0, 0.0), (0.0, 1.0, 0.0), width, height)
+    return SceneSetup("cornell", hs, cam, pos, width, height)
+
+
+def bunny_class(width=1920, height=1080, directory=None, subdiv=6, ltc=None):
+    """Config 3: displaced icosphere (81,920 tris at subdiv 6) + ground, one area light above."""
+    obj, mtldir = write_bunny_class(directory, subdiv)
+    hs = host.HostScene()
+    light = hs.addAreaLight(30.0, (1.0, 0.95, 0.9), False)
+    light.move((150.0, 520.0, -120.0)).scale((300.0, 300.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    hs.addObjMtlPair(obj, mtldir)
+    hs.setSky((0.45, 0.6, 0.9))
+    if ltc is not None:
+        hs.setLTC(*ltc)
+    hs.build()
+    pos = (0.0, 220.0, -520.0)
+    cam = host.Camera(45.0, pos, (0.0, 120.0, 0.0), (0.0, 1.0, 0.0), width, height)
+    return SceneSetup("bunny_class", hs, cam, pos, width, height)
+
+
+def sponza_class(width=1920, height=1080, directory=None, ltc=None):
+    """Configs 4/5: the procedural atrium, two one-sided area lights (as the reference's shipped scene has,
+    application.cppm:184-196) + the shader's built-in directional light through the open roof."""
+    obj, mtldir = write_sponza_class(directory)
+    hs = host.HostScene()
+    l1 = hs.addAreaLight(9.0, (0.8, 0.5, 0.2), False)
+    l1.move((-600.0, 1150.0, 0.0)).scale((700.0, 500.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    l2 = hs.addAreaLight(3.0, (0.3, 0.3, 0.5), False)
+    l2.move((900.0, 900.0, 0.0)).scale((500.0, 400.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    hs.addObjMtlPair(obj, mtldir)
+    hs.setSky((0.5, 0.7, 1.0))
+    if ltc is not None:
+        hs.setLTC(*ltc)
+    hs.build()
+    pos = (-1250.0, 420.0, 60.0)
+    cam = host.Camera(60.0, pos, (300.0, 380.0, -20.0), (0.0, 1.0, 0.0), width, height)
+    return SceneSetup("sponza_class", hs, cam, pos, width, height)
+
+
+def custom_obj(obj_path, mtl_dir, cam_pos, look_at, fov_y=60.0, width=1920, height=1080, lights=()):
+    """A real asset (e.g. sponza.obj / bunny.obj supplied on the GPU box)."""
+    hs = host.HostScene()
+    for (intensity, color, move, scale, rotate) in lights:
+        hs.addAreaLight(intensity, color, False).move(move).scale(scale).rotate(rotate)
+    hs.addObjMtlPair(obj_path, mtl_dir)
+    hs.setSky((0.5, 0.7, 1.0))
+    hs.build()
+    cam = host.Camera(fov_y, cam_pos, look_at, (0.0, 1.0, 0.0), width, height)
+    return SceneSetup(os.path.basename(obj_path), hs, cam, cam_pos, width, height)
+
+
+def file_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
