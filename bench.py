@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ray-tracing hot path (BASELINE.json metric:
+Mrays/sec and ms/frame at 1920x1080, 1 spp, on 1/2/4/8 MI355X).
+
+A "step" is one frame: the hot path over one batch of synthetic input (the procedural Sponza-class
+atrium, ~262 k triangles, 2 area lights; BASELINE config 4), i.e. k_primary -> k_shadow_gen ->
+k_shadow_trace -> k_resolve through the C ABI, scene resident in HBM.  With N > 1 the SAME frame is
+band-sharded over the ranks (strong scaling), gathered to rank 0 with one RCCL gather over xGMI and
+de-interleaved there; all of that is inside the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = all rays traced per second (primary + shadow, exact count
+from the kernels' own counters in an untimed stats pass), whole job.  `roofline` is for the dominant
+kernel (k_shadow_trace): algorithmic bytes per launch / its average launch duration measured with HIP
+events on the render stream inside the timed steps.  `cpu_baseline` is the CPU oracle (a scalar C++
+port, oracle/) timed on the host cores on a bounded sample of the same workload — reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sponza_class", choices=["sponza_class", "cornell", "bunny_class"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--shadow-rays", type=int, default=3)
+    ap.add_argument("--pipeline", type=int, default=0, help="0 default, 1 megakernel, 2 wavefront")
+    ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run (see docstring)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("RTR_SCENE_CACHE", os.path.join("/tmp", f"rtr_scene_cache_rank{rank}"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from realtimeraytracer_amd import _abi as A
+    from realtimeraytracer_amd import api, mgpu, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the ray-tracing path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    W, H, S = args.width, args.height, args.spp
+    setup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
+    ctx = api.Context(local_rank)
+    stream = torch.cuda.Stream(device=device)
+    ctx.set_stream(stream.cuda_stream)
+    scene = api.Scene(ctx, setup.desc)
+    sstats = scene.stats()
+    rows = api.shard_rows(H, args.band_rows, world)
+    frame = api.Frame(ctx, W, rows, A.IMAGES_FRAMEBUFFER)
+    local = torch.zeros((rows, W), dtype=torch.int32, device=device)           # RGBA8 framebuffer of this shard
+    frame.bind_external(A.IMAGE_SHADOWED, local.data_ptr(), local.numel() * 4)
+    full = torch.zeros((H, W), dtype=torch.int32, device=device) if rank == 0 else None
+
+    def params(collect=0):
+        return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=rank,
+                               shard_count=world, collect_stats=collect, pipeline=args.pipeline)
+
+    # ---- untimed stats pass: exact ray / node / triangle counts of one frame -------------------------
+    api.render(scene, setup.camera, setup.scene_info(0), params(collect=1), frame)
+    fs = frame.stats()
+    counts = torch.tensor([fs.numRays, fs.numPrimaryRays, fs.numShadowRays, fs.algorithmicBytes, fs.shadowTraceBytes],
+                          dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    rays_per_frame, primary_per_frame = int(counts[0].item()), int(counts[1].item())
+    pipeline_used = fs.pipelineUsed
+
+    p_run = params(0)
+    kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0}
+
+    def step(i):
+        info = setup.scene_info(i)
+        with torch.cuda.stream(stream):
+            if world == 1:
+                api.render(scene, setup.camera, info, p_run, frame)             # synchronous: per-launch event times
+                st = frame.stats()
+                kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
+                kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
+            else:
+                api.render(scene, setup.camera, info, p_run, frame, asynchronous=True)
+                gathered = mgpu.gather_to_root(dist, local, world, rank)        # the one exchange step (RCCL over xGMI)
+                if rank == 0:
+                    api.deinterleave_bands(ctx, gathered.data_ptr(), full.data_ptr(), W, H, args.band_rows, world)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0})
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        frame.wait()
+        st = frame.stats()   # last step's launches (async mode keeps only those)
+        kern.update({"primary": st.primaryMs, "shadow_gen": st.shadowGenMs, "shadow_trace": st.shadowTraceMs,
+                     "resolve": st.resolveMs, "n": 1})
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    mrays = rays_per_frame * args.steps / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        n = max(kern["n"], 1)
+        trace_ms = kern["shadow_trace"] / n
+        trace_bytes = fs.shadowTraceBytes                         # rank 0's launch
+        roofline = None
+        if pipeline_used == 2 and trace_ms > 0:
+            achieved = trace_bytes / (trace_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
+                    traffic = tj.get(key, {}).get("k_shadow_trace_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "k_shadow_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": int(trace_bytes), "avg_launch_ms": round(trace_ms, 4),
+                        "bvh_layout_version": int(sstats.bvhLayoutVersion)}
+        elif trace_ms == 0 and kern["primary"] > 0:
+            mk_ms = kern["primary"] / n
+            achieved = fs.algorithmicBytes / (mk_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_megakernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(fs.algorithmicBytes), "avg_launch_ms": round(mk_ms, 4),
+                        "bvh_layout_version": int(sstats.bvhLayoutVersion)}
+        out = {
+            "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S) == (1920, 1080, 1) else f"Mrays/sec at {W}x{H} {S}spp",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {W}x{H} {S}spp, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
+                                   f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{world}",
+                       "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame,
+                       "pipeline": "wavefront" if pipeline_used == 2 else "megakernel",
+                       "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries),
+                               "build_ms": round(float(sstats.buildMs), 1)}},
+            "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
+            "kernels_ms": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
+            "algorithmic_gbps_all_kernels": round(counts[3].item() / (ms_per_step * 1e-3) / 1e9, 2),
+            "roofline": roofline,
+        }
+
+    # ---- reported CPU baseline (rank 0, N=1 only): the oracle on a bounded sample --------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_py as O
+        threads = min(os.cpu_count() or 1, 16)
+        bvh = scene.export_bvh()
+        sample_shards = 2
+        pc = api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=0,
+                             shard_count=sample_shards, collect_stats=1)
+        t1 = time.perf_counter()
+        r = O.render(setup.desc, setup.camera, setup.scene_info(0), pc, bvh=bvh, threads=threads)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(r.stats.numRays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": f"every {sample_shards}nd 8-row band of the same frame ({r.stats.numRays} rays, {dt:.1f} s), scalar C++ oracle, "
+                                         f"{threads} std::threads over rows, -O2 -ffp-contract=off"}
+        if args.verify:
+            gpu = full.cpu().numpy().view(np.uint32) if world > 1 else local.cpu().numpy().view(np.uint32)
+            ys = mgpu.global_rows_of_shard(H, args.band_rows, sample_shards, 0)
+            # the verify render used frame index = last step; re-render that frame on the GPU for the comparison
+            api.render(scene, setup.camera, setup.scene_info(0), params(0), frame)
+            gpu = local.cpu().numpy().view(np.uint32)
+            ok = ys >= 0
+            bad = int((gpu[ys[ok]] != r.images[A.IMAGE_SHADOWED][ok]).sum())
+            out["verify"] = {"rows_checked": int(ok.sum()), "pixels_differing": bad}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,13 +129,19 @@ typedef struct rtr_frame_stats {
     uint64_t numLightFetches;  /* N_lightfetch: LightInfo reads (96 B each) */
     uint64_t numLightTriFetches;/* light triangle vertex fetches (3 idx + 3 x 48 B = 156 B each) */
     uint64_t algorithmicBytes; /* B = 64 N_node + 48 N_tri + 236 N_hit + 96 N_lf + 156 N_ltf + 4 k P (+32 P if HDR RMW) */
+    /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
+    uint64_t numShadowNodeVisits;
+    uint64_t numShadowTriTests;
+    uint64_t shadowTraceBytes; /* 64 N_node_shadow + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
     /* timings of the last render (HIP events on the render stream), milliseconds */
     float    totalMs;
-    float    traceMs;          /* sum over the traversal kernels (the dominant kernels) */
-    float    shadeMs;
-    float    resolveMs;
+    float    primaryMs;        /* k_primary (wavefront) or the whole megakernel */
+    float    shadowGenMs;      /* k_shadow_gen */
+    float    shadowTraceMs;    /* k_shadow_trace: the dominant kernel */
+    float    resolveMs;        /* k_resolve */
     uint32_t localRows;        /* rows this shard rendered */
     uint32_t localPixels;
+    uint32_t pipelineUsed;     /* 1 megakernel, 2 wavefront */
 } rtr_frame_stats;
 
 /* ---- context -------------------------------------------------------------------------- */
@@ -193,7 +199,7 @@ int  rtr_frame_wait(rtr_frame* frame);
 
 /* Rank-0 step after the RCCL gather: `gathered` holds shardCount blocks of (localRows x width)
  * RGBA8 pixels in rank order; writes the de-interleaved (height x width) image to `dst`.
- * Both are device pointers; runs on the ctx stream. */
+ * Both are device pointers; ENQUEUED on the ctx stream (asynchronous; synchronise the stream to read). */
 int  rtr_deinterleave_bands(rtr_ctx* ctx, const void* gathered, void* dst, uint32_t width, uint32_t height,
                             uint32_t bandRows, uint32_t shardCount);
 

@@ -27,7 +27,9 @@ namespace {
 
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
+    uint64_t shadowNodes = 0, shadowTris = 0;
     void add(const Counters& o) {
+        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
     }
@@ -65,7 +67,7 @@ Hit trace_brute(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, boo
     Hit best{}; best.hit = false; best.t = tmax;
     for (const WorldTri& w : sc.brute) {
         float t, u, v;
-        c.tris++;
+        c.tris++; if (anyHit) c.shadowTris++;
         if (rtr_mt_intersect(o, d, w.v0, w.e1, w.e2, tmin, &t, &u, &v)) {
             consider(best, t, u, v, w.custom, w.prim, tmax);
             if (anyHit && best.hit) return best;
@@ -86,7 +88,7 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
     for (;;) {
         if (cur >= 0) {
             const RtrBvhNode& n = nodes[cur];
-            c.nodes++;
+            c.nodes++; if (anyHit) c.shadowNodes++;
             float tl, tr;
             float limit = best.hit ? best.t : tmax;
             int hl = rtr_slab(&n.f[0], &n.f[3], idir, ood, tmin, limit, &tl);
@@ -105,7 +107,7 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
             for (uint32_t i = 0; i < count; ++i) {
                 const RtrBvhTri& tr = tris[first + i];
                 float t, u, v;
-                c.tris++;
+                c.tris++; if (anyHit) c.shadowTris++;
                 if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
                     consider(best, t, u, v, tr.customIndex, tr.primitiveId, tmax);
                     if (anyHit && best.hit) return best;
@@ -552,6 +554,8 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.numRays = tot.rays; st.numPrimaryRays = tot.primary; st.numShadowRays = tot.shadow;
     st.numNodeVisits = tot.nodes; st.numTriTests = tot.tris; st.numHits = tot.hits;
     st.numLightFetches = tot.lightFetch; st.numLightTriFetches = tot.lightTriFetch;
+    st.numShadowNodeVisits = tot.shadowNodes; st.numShadowTriTests = tot.shadowTris;
+    st.shadowTraceBytes = 64 * tot.shadowNodes + 48 * tot.shadowTris + 33 * tot.shadow;
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;

@@ -81,8 +81,9 @@ class rtr_render_params(C.Structure):
 class rtr_frame_stats(C.Structure):
     _fields_ = [("numRays", u64), ("numPrimaryRays", u64), ("numShadowRays", u64), ("numNodeVisits", u64),
                 ("numTriTests", u64), ("numHits", u64), ("numLightFetches", u64), ("numLightTriFetches", u64),
-                ("algorithmicBytes", u64), ("totalMs", f32), ("traceMs", f32), ("shadeMs", f32), ("resolveMs", f32),
-                ("localRows", u32), ("localPixels", u32)]
+                ("algorithmicBytes", u64), ("numShadowNodeVisits", u64), ("numShadowTriTests", u64), ("shadowTraceBytes", u64),
+                ("totalMs", f32), ("primaryMs", f32), ("shadowGenMs", f32), ("shadowTraceMs", f32), ("resolveMs", f32),
+                ("localRows", u32), ("localPixels", u32), ("pipelineUsed", u32)]
 
 
 assert C.sizeof(RtrVertex) == 48 and C.sizeof(RtrCameraData) == 64 and C.sizeof(RtrSceneInfo) == 32

@@ -38,12 +38,15 @@ struct DeviceScene {
 };
 
 struct Counters {                    /* device mirror of rtr_frame_stats' counters */
-    unsigned long long rays, primary, shadow, nodes, tris, hits, lightFetch, lightTriFetch;
+    unsigned long long rays, primary, shadow, nodes, tris, hits, lightFetch, lightTriFetch, shadowNodes, shadowTris;
 };
 
 struct LocalStats {
     uint32_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
+    uint32_t shadowNodes = 0, shadowTris = 0;
     __device__ void flush(Counters* c) const {
+        if (shadowNodes) atomicAdd(&c->shadowNodes, (unsigned long long)shadowNodes);
+        if (shadowTris) atomicAdd(&c->shadowTris, (unsigned long long)shadowTris);
         if (rays) atomicAdd(&c->rays, (unsigned long long)rays);
         if (primary) atomicAdd(&c->primary, (unsigned long long)primary);
         if (shadow) atomicAdd(&c->shadow, (unsigned long long)shadow);
@@ -84,7 +87,7 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
             const float4* n = sc.nodes + (size_t)cur * 4;
             const float4 a = n[0], b = n[1], c = n[2];
             const int2 ch = *reinterpret_cast<const int2*>(n + 3);
-            if (STATS) st.nodes++;
+            if (STATS) { st.nodes++; if (ANY) st.shadowNodes++; }
             const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {a.w, b.x, b.y};
             const float rmn[3] = {b.z, b.w, c.x}, rmx[3] = {c.y, c.z, c.w};
             float tl, tr;
@@ -105,7 +108,7 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
             for (uint32_t i = 0; i < count; ++i) {
                 const float4* tp = sc.tris + (size_t)(first + i) * 3;
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (STATS) st.tris++;
+                if (STATS) { st.tris++; if (ANY) st.shadowTris++; }
                 float t, u, v;
                 if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v)) {
                     if (t < tmax) {

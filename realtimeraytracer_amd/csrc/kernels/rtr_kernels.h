@@ -16,8 +16,6 @@ struct Workspace {
     size_t    capRays = 0;
 };
 
-struct LaunchTimes { float traceMs = 0.f, shadeMs = 0.f, resolveMs = 0.f; };
-
 /* stackEntries must be one of 16, 32, 64. */
 hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, int stackEntries,
                              Counters* stats, hipStream_t stream);

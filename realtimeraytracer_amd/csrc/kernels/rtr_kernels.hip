@@ -34,18 +34,32 @@ struct InlinePolicy {
     }
 };
 
-/* Wave-level active-ray compaction: lanes that reach this call together (the current EXEC mask)
- * take consecutive queue entries; one atomic per wave. */
+/* Wave-level active-ray compaction, two phases so the global queue sees ONE atomic per wave
+ * (a single contended counter saturates near 88 atomics/us on this chip — with an atomic per
+ * emission step k_shadow_gen spent 4.5 ms of a 12 ms frame on it):
+ *   phase 1 (CountPolicy)  walks the shading loops and only counts this lane's shadow queries;
+ *                          a wave reduction + one atomicAdd reserves the wave's contiguous chunk;
+ *   phase 2 (EmitPolicy)   walks the same loops again; lanes that reach a query together (the
+ *                          current EXEC mask) take consecutive entries: ballot + mbcnt prefix on top of
+ *                          a per-wave running offset kept in LDS (lanes parked by divergence must see
+ *                          the offsets their siblings consumed).
+ * Entries of one emission step are contiguous, so k_shadow_trace's waves get rays of neighbouring
+ * pixels aimed at the same light triangle / sample index. */
+struct CountPolicy {
+    static constexpr bool kShade = false;
+    uint32_t n;
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float) { ++n; return false; }
+};
+
 struct EmitPolicy {
     static constexpr bool kShade = false;
-    float4* queue; uint32_t* count; uint32_t slot;
+    float4* queue; volatile uint32_t* waveOffset; uint32_t base; uint32_t slot;
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        uint32_t base = 0;
-        if (prefix == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        const size_t idx = (size_t)(base + prefix) * 2;
+        const uint32_t off = *waveOffset;                      /* same LDS word for the whole wave: broadcast read */
+        if (prefix == 0) *waveOffset = off + (uint32_t)__popcll(m);
+        const size_t idx = (size_t)(base + off + prefix) * 2;
         queue[idx] = make_float4(o.x, o.y, o.z, tmax);
         queue[idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
         ++slot;
@@ -112,36 +126,158 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
 }
 
 /* ---- wavefront stage 2: shadow-ray generation into the compacted queue ------------------------- */
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArgs ra, const float4* hitTuvp,
                                                        const uint32_t* hitCustom, float4* queue, uint32_t* count) {
+    __shared__ uint32_t s_off[kBlock / 64];
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t px, lrow, py;
-    if (!pixel_of(ra, q, px, lrow, py)) return;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t px = 0, lrow = 0, py = 0;
+    const bool live = pixel_of(ra, q, px, lrow, py);
     LocalStats st;
     Accum acc = zero_accum();
+    /* phase 1: count */
+    uint32_t n = 0;
+    if (live) {
+        CountPolicy cp{0};
+        for (uint32_t i = 0; i < ra.spp; ++i) {
+            const size_t k = (size_t)i * gridDim.x * kBlock + q;
+            const float4 r = hitTuvp[k];
+            HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
+            shade_sample<CountPolicy, false>(sc, ra, px, py, h, primary_dir(ra, px, py, i), false, acc, cp, st);
+        }
+        n = cp.n;
+    }
+    /* one reservation per wave (all 64 lanes take part in the reduction) */
+    const uint32_t total = wave_sum(n);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0) {
+        if (total) base = atomicAdd(count, total);
+        s_off[wave] = 0;
+    }
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (!live || n == 0) return;
+    /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
-        const rtr_v3 dir = primary_dir(ra, px, py, i);
-        EmitPolicy pol{queue, count, (uint32_t)(k * ra.maxRaysPerSample)};
-        shade_sample<EmitPolicy, false>(sc, ra, px, py, h, dir, false, acc, pol, st);
+        EmitPolicy pol{queue, &s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
+        shade_sample<EmitPolicy, false>(sc, ra, px, py, h, primary_dir(ra, px, py, i), false, acc, pol, st);
     }
 }
 
-/* ---- wavefront stage 3: any-hit traversal of the queue (the dominant kernel) ------------------- */
+/* ---- wavefront stage 3: any-hit traversal of the queue (the dominant kernel) -------------------
+ * Persistent waves with wavefront-ballot active-ray compaction.  Profiling the one-ray-per-lane form
+ * showed the SIMDs ~100 % busy issuing instructions at ~30 % lane utilisation: rays of one wave need
+ * very different numbers of node visits, and inner-node and leaf work alternated under divergent
+ * branches.  Here:
+ *   * a wave grabs BATCH consecutive queue entries with ONE atomic and keeps them in wave-uniform
+ *     cursors; whenever at least kRefill lanes are idle (ballot + popcount) the idle lanes take the next
+ *     entries (mbcnt prefix), so finished rays are replaced instead of waited for;
+ *   * "while-while": all lanes first descend inner nodes until every live lane sits on a leaf (or has
+ *     finished), then all leaves are intersected together;
+ * A lane's own sequence of node visits / triangle tests is exactly that of trace<true>() — and of the
+ * oracle's trace_bvh() — so visibility bits AND work counters are unchanged. */
+constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
+constexpr uint32_t kBatch = 1024;
+constexpr uint32_t kRefill = 20;
+
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* queue, const uint32_t* count,
-                                                         uint8_t* vis, Counters* stats) {
+__global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
+                                                         const uint32_t* __restrict__ count, uint32_t* nextBatch,
+                                                         uint8_t* __restrict__ vis, Counters* stats) {
     __shared__ int32_t s_stack[STACK * kBlock];
     int32_t* stack = s_stack + threadIdx.x;
     const uint32_t n = *count;
     LocalStats st;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 a = queue[(size_t)i * 2], b = queue[(size_t)i * 2 + 1];
-        HitRec h;
-        const bool occ = trace<true, STATS, kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
-        vis[__float_as_uint(b.w)] = occ ? 1 : 0;
+    uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
+    bool exhausted = false;                  /* wave-uniform */
+    int32_t cur = kDone;
+    int sp = 0;
+    rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), idir = rtr_mk(0, 0, 0), ood = rtr_mk(0, 0, 0);
+    float tmax = 0.f;
+    uint32_t slot = 0;
+    const float tmin = 0.001f;
+
+    for (;;) {
+        /* ---- refill idle lanes from the wave's batch ---- */
+        const unsigned long long idle = __ballot(cur == kDone);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (!exhausted && (nIdle >= kRefill || nIdle == 64u)) {
+            if (batchPos == batchEnd) {
+                uint32_t b = 0;
+                if ((threadIdx.x & 63u) == 0) b = atomicAdd(nextBatch, kBatch);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= n) { exhausted = true; }
+                else { batchPos = b; batchEnd = (b + kBatch < n) ? b + kBatch : n; }
+            }
+            if (!exhausted) {
+                const uint32_t avail = batchEnd - batchPos;
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (cur == kDone && prefix < avail) {
+                    const size_t i = (size_t)(batchPos + prefix) * 2;
+                    const float4 a = queue[i], b = queue[i + 1];
+                    o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
+                    if (STATS) { st.rays++; st.shadow++; }
+                    if (!(tmax > tmin)) {
+                        vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
+                    } else {
+                        idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+                        ood = rtr_mk(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+                        cur = 0; sp = 0;
+                    }
+                }
+                batchPos += (nIdle < avail) ? nIdle : avail;
+            }
+        }
+        if (__ballot(cur != kDone) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        /* ---- inner nodes: until every live lane is on a leaf ---- */
+        while (__ballot(cur >= 0) != 0ull) {
+            if (cur >= 0) {
+                const float4* nd = sc.nodes + (size_t)cur * 4;
+                const float4 a = nd[0], b = nd[1], c = nd[2];
+                const int2 ch = *reinterpret_cast<const int2*>(nd + 3);
+                if (STATS) { st.nodes++; st.shadowNodes++; }
+                const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {a.w, b.x, b.y};
+                const float rmn[3] = {b.z, b.w, c.x}, rmx[3] = {c.y, c.z, c.w};
+                float tl, tr;
+                const bool hl = rtr_slab(lmn, lmx, idir, ood, tmin, tmax, &tl) != 0;
+                const bool hr = rtr_slab(rmn, rmx, idir, ood, tmin, tmax, &tr) != 0;
+                const bool swap = tr < tl;
+                const int32_t nearC = swap ? ch.y : ch.x;
+                const int32_t farC = swap ? ch.x : ch.y;
+                if (hl && hr) { stack[sp * kBlock] = farC; ++sp; cur = nearC; }
+                else if (hl) cur = ch.x;
+                else if (hr) cur = ch.y;
+                else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+                else { vis[slot] = 0; cur = kDone; }
+            }
+        }
+        /* ---- leaves ---- */
+        if (cur != kDone) {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            bool hit = false;
+            for (uint32_t i = 0; i < cnt && !hit; ++i) {
+                const float4* tp = sc.tris + (size_t)(first + i) * 3;
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (STATS) { st.tris++; st.shadowTris++; }
+                float t, u, v;
+                if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v)) hit = t < tmax;
+            }
+            if (hit) { vis[slot] = 1; cur = kDone; }
+            else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+            else { vis[slot] = 0; cur = kDone; }
+        }
     }
     if (STATS) st.flush(stats);
 }
@@ -210,21 +346,25 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
                          Counters* stats, hipStream_t s, hipEvent_t* ev) {
     const uint32_t blocks = (padded_pixels(ra) + kBlock - 1) / kBlock;
     hipError_t e;
-    if ((e = hipMemsetAsync(ws.queueCount, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ws.queueCount, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] batch cursor */
     if (ev) hipEventRecord(ev[0], s);
     if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
     else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
     if (ev) hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(k_shadow_gen, dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount);
     if (ev) hipEventRecord(ev[2], s);
-    /* persistent grid-stride over the queue: enough workgroups to fill 256 CUs several times over */
+    /* persistent waves: as many workgroups as stay resident (LDS stack: STACK*1 KiB per workgroup of the
+     * 160 KiB per CU, at most 8 x 256 threads per CU), each pulling batches until the queue is empty */
+    uint32_t perCU = 160u / (uint32_t)STACK;
+    if (perCU > 8u) perCU = 8u;
+    if (perCU == 0u) perCU = 1u;
     const size_t maxRays = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
-    uint32_t tblocks = (uint32_t)((maxRays + kBlock - 1) / kBlock);
-    const uint32_t cap = 256u * 16u;
-    if (tblocks > cap) tblocks = cap;
+    uint32_t tblocks = 256u * perCU;
+    const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
+    if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
-    if (stats) hipLaunchKernelGGL((k_shadow_trace<STACK, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.vis, stats);
-    else hipLaunchKernelGGL((k_shadow_trace<STACK, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.vis, stats);
+    if (stats) hipLaunchKernelGGL((k_shadow_trace<STACK, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats);
+    else hipLaunchKernelGGL((k_shadow_trace<STACK, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats);
     if (ev) hipEventRecord(ev[3], s);
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);

@@ -524,7 +524,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     if (wave) {
         if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); }
         if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); }
-        if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(1));
+        if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(2));
         Workspace ws;
         ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
         ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots;
@@ -552,11 +552,13 @@ int rtr_frame_wait(rtr_frame* f) {
         (void)hipEventElapsedTime(&b, f->ev[1], f->ev[2]);
         (void)hipEventElapsedTime(&c, f->ev[2], f->ev[3]);
         (void)hipEventElapsedTime(&d, f->ev[3], f->ev[4]);
-        s.traceMs = a + c; s.shadeMs = b; s.resolveMs = d; s.totalMs = a + b + c + d;
+        s.primaryMs = a; s.shadowGenMs = b; s.shadowTraceMs = c; s.resolveMs = d; s.totalMs = a + b + c + d;
+        s.pipelineUsed = 2;
     } else {
         float a = 0;
         (void)hipEventElapsedTime(&a, f->evMega[0], f->evMega[1]);
-        s.traceMs = a; s.totalMs = a;
+        s.primaryMs = a; s.totalMs = a;
+        s.pipelineUsed = 1;
     }
     if (f->pendingCounters) {
         Counters h;
@@ -564,6 +566,8 @@ int rtr_frame_wait(rtr_frame* f) {
         s.numRays = h.rays; s.numPrimaryRays = h.primary; s.numShadowRays = h.shadow;
         s.numNodeVisits = h.nodes; s.numTriTests = h.tris; s.numHits = h.hits;
         s.numLightFetches = h.lightFetch; s.numLightTriFetches = h.lightTriFetch;
+        s.numShadowNodeVisits = h.shadowNodes; s.numShadowTriTests = h.shadowTris;
+        s.shadowTraceBytes = 64ull * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
         s.algorithmicBytes = 64ull * h.nodes + 48ull * h.tris + 236ull * h.hits + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
                              4ull * f->pendingImagesK * s.localPixels + (f->pendingHdr ? (f->pendingAccum ? 32ull : 16ull) * s.localPixels : 0ull);
     }
@@ -594,8 +598,7 @@ int rtr_deinterleave_bands(rtr_ctx* ctx, const void* gathered, void* dst, uint32
     const uint32_t localRows = rtr_shard_rows(height, bandRows, shardCount);
     hipError_t e = rtrdev::launch_deinterleave((const uint32_t*)gathered, (uint32_t*)dst, width, height, bandRows, shardCount, localRows, ctx->stream);
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "deinterleave launch: %s", hipGetErrorString(e));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return RTR_OK;
+    return RTR_OK;   /* enqueued on the ctx stream; the caller synchronises (stream order is enough for a following copy) */
 }
 
 }  // extern "C"
