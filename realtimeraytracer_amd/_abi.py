@@ -163,6 +163,7 @@ RTRH_SYMBOLS = {
     "rtrh_get_desc": (C.c_int, [VP, P(rtr_scene_desc)]),
     "rtrh_object_info": (C.c_int, [VP, C.c_int, P(u32), P(u32), P(u32)]),
     "rtrh_load_model": (C.c_int, [VP, C.c_char_p]),
+    "rtrh_obj_dump": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "rtrh_camera_new": (VP, [f32, P(f32), P(f32), P(f32), C.c_int, C.c_int]),
     "rtrh_camera_free": (None, [VP]),
     "rtrh_camera_get": (C.c_int, [VP, P(RtrCameraData)]),

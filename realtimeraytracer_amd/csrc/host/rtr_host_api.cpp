@@ -2,6 +2,7 @@
 // Python tests / bench can drive scene::Camera, scene::Object, scene::AreaLight, core::file ingest and
 // app::setup::CreateScene exactly as reference src/app/application.cppm:181-230 does, then hand the
 // packed arrays to the C ABI (rtr_scene_create) and to the CPU oracle.  Built as librtr_host.so.
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -116,6 +117,51 @@ int rtrh_load_model(rtrh_scene* s, const char* path) {
         RtrMesh m{}; m.vertexCount = (uint32_t)g.vertices.size(); m.indexCount = (uint32_t)g.indices.size(); m.isOpaque = 1;
         g.meshes.push_back(m);
         s->isBuilt = true;
+    });
+}
+
+// Dump the raw OBJ reader output (rtr::obj::LoadObj) in EXACTLY the text format of
+// oracle/ref_tinyobj_dump.cpp, so the two files can be compared byte for byte.
+int rtrh_obj_dump(const char* objPath, const char* mtlDir, const char* outPath) {
+    return guarded([&] {
+        rtr::obj::attrib_t attrib; std::vector<rtr::obj::shape_t> shapes; std::vector<rtr::obj::material_t> materials;
+        std::string warn, err;
+        const char* mtl = mtlDir && *mtlDir ? mtlDir : nullptr;
+        if (!rtr::obj::LoadObj(&attrib, &shapes, &materials, &warn, &err, objPath, mtl)) throw std::runtime_error(warn + err);
+        FILE* f = std::fopen(outPath, "w");
+        if (!f) throw std::runtime_error(std::string("cannot open ") + outPath);
+        auto farr = [&](const char* name, const std::vector<float>& v) {
+            std::fprintf(f, "\"%s\":[", name);
+            for (size_t i = 0; i < v.size(); ++i) std::fprintf(f, "%s%.9g", i ? "," : "", v[i]);
+            std::fprintf(f, "],");
+        };
+        std::fprintf(f, "{");
+        farr("vertices", attrib.vertices); farr("normals", attrib.normals); farr("texcoords", attrib.texcoords);
+        std::fprintf(f, "\"shapes\":[");
+        for (size_t s2 = 0; s2 < shapes.size(); ++s2) {
+            const auto& m = shapes[s2].mesh;
+            std::fprintf(f, "%s{\"name\":\"%s\",\"indices\":[", s2 ? "," : "", shapes[s2].name.c_str());
+            for (size_t i = 0; i < m.indices.size(); ++i)
+                std::fprintf(f, "%s[%d,%d,%d]", i ? "," : "", m.indices[i].vertex_index, m.indices[i].normal_index, m.indices[i].texcoord_index);
+            std::fprintf(f, "],\"num_face_vertices\":[");
+            for (size_t i = 0; i < m.num_face_vertices.size(); ++i) std::fprintf(f, "%s%u", i ? "," : "", (unsigned)m.num_face_vertices[i]);
+            std::fprintf(f, "],\"material_ids\":[");
+            for (size_t i = 0; i < m.material_ids.size(); ++i) std::fprintf(f, "%s%d", i ? "," : "", m.material_ids[i]);
+            std::fprintf(f, "]}");
+        }
+        std::fprintf(f, "],\"materials\":[");
+        for (size_t i = 0; i < materials.size(); ++i) {
+            const auto& m = materials[i];
+            std::fprintf(f, "%s{\"name\":\"%s\",\"diffuse\":[%.9g,%.9g,%.9g],\"specular\":[%.9g,%.9g,%.9g],", i ? "," : "", m.name.c_str(),
+                         m.diffuse[0], m.diffuse[1], m.diffuse[2], m.specular[0], m.specular[1], m.specular[2]);
+            std::fprintf(f, "\"diffuse_texname\":\"%s\",\"specular_texname\":\"%s\",\"metallic_texname\":\"%s\",\"alpha_texname\":\"%s\",\"unknown\":{",
+                         m.diffuse_texname.c_str(), m.specular_texname.c_str(), m.metallic_texname.c_str(), m.alpha_texname.c_str());
+            size_t k = 0;
+            for (const auto& kv : m.unknown_parameter) std::fprintf(f, "%s\"%s\":\"%s\"", k++ ? "," : "", kv.first.c_str(), kv.second.c_str());
+            std::fprintf(f, "}}");
+        }
+        std::fprintf(f, "]}\n");
+        std::fclose(f);
     });
 }
 

@@ -59,3 +59,240 @@ def test_cornell_1080p_bit_exact(gpu_ctx, oracle, scene_cache):
     img = frame.download()
     assert img.shape == (1080, 1920)
     _assert_same(img, ref.images[A.IMAGE_SHADOWED], "cornell 1080p")
+
+
+# ---------------------------------------------------------------------------------------------------
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL5 = A.IMAGES_RAYGEN5 | A.IMG_BIT(A.IMAGE_HDR)
+NAMES = {0: "analytic", 1: "shadowed", 2: "unshadowed", 6: "normal", 7: "position"}
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_cornell_golden_five_images_and_hdr(gpu_ctx, scene_cache, pipeline):
+    """All five ray-gen images (k=5 mode, analytic through synthetic LTC tables) + HDR against the committed golden."""
+    from realtimeraytracer_amd import scenes as S
+    g = np.load(os.path.join(GOLD, "cornell_256_oracle.npz"))
+    s = S.cornell_box(256, 256, ltc=S.synthetic_ltc())
+    p = api.make_params(256, 256, spp=1, images=ALL5, collect_stats=1, pipeline=pipeline)
+    scene, frame = _gpu_render(gpu_ctx, s, p, images=ALL5)
+    for which, name in NAMES.items():
+        _assert_same(frame.download(which), g[name], f"golden {name} pipeline{pipeline}")
+    hdr = frame.download(A.IMAGE_HDR)
+    assert np.array_equal(hdr.view(np.uint32), g["hdr"].view(np.uint32)), "HDR float buffer must match bit for bit (tolerance 0)"
+    st = frame.stats()
+    assert (st.numRays, st.numPrimaryRays, st.numShadowRays, st.numHits) == tuple(int(x) for x in g["counters"][:4])
+
+
+def test_analytic_without_ltc_is_refused(gpu_ctx, scene_cache):
+    s = scenes.cornell_box(64, 64)
+    scene = api.Scene(gpu_ctx, s.desc)
+    frame = api.Frame(gpu_ctx, 64, 64, A.IMAGES_RAYGEN5)
+    with pytest.raises(api.RtrError) as e:
+        api.render(scene, s.camera, s.scene_info(0), api.make_params(64, 64, images=A.IMAGES_RAYGEN5), frame)
+    assert e.value.status == -4
+
+
+def test_error_paths(gpu_ctx, scene_cache):
+    s = scenes.cornell_box(64, 64)
+    scene = api.Scene(gpu_ctx, s.desc)
+    frame = api.Frame(gpu_ctx, 64, 64)
+    with pytest.raises(api.RtrError):                              # frame extent mismatch
+        api.render(scene, s.camera, s.scene_info(0), api.make_params(128, 64), frame)
+    with pytest.raises(api.RtrError):                              # more lights than the scene has
+        from realtimeraytracer_amd import host
+        api.render(scene, s.camera, host.scene_info(0, 5, s.cam_pos), api.make_params(64, 64), frame)
+    with pytest.raises(api.RtrError):                              # HDR accumulation without an HDR image
+        api.render(scene, s.camera, s.scene_info(0), api.make_params(64, 64, accumulate=1), frame)
+    with pytest.raises(api.RtrError):                              # bandRows must be a multiple of 8
+        api.render(scene, s.camera, s.scene_info(0), api.make_params(64, 64, band_rows=4), frame)
+    with pytest.raises(api.RtrError):
+        frame.download(A.IMAGE_FINAL)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_band_sharding_reassembles_bit_exact(gpu_ctx, scene_cache, shards):
+    """Multi-GPU semantics on one device: N logical shards == the unsharded frame (pixels are independent)."""
+    import torch
+    from realtimeraytracer_amd import mgpu
+    W, H = 320, 180                                                 # 22.5 bands: ragged last band + padding rows
+    s = scenes.cornell_box(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    _, full_frame = _gpu_render(gpu_ctx, s, api.make_params(W, H, spp=2), scene=scene)
+    full = full_frame.download()[:H]
+    rows = api.shard_rows(H, 8, shards)
+    gathered = np.zeros((shards, rows, W), np.uint32)
+    for r in range(shards):
+        p = api.make_params(W, H, spp=2, shard_index=r, shard_count=shards)
+        _, fr = _gpu_render(gpu_ctx, s, p, scene=scene)
+        gathered[r] = fr.download()
+    _assert_same(mgpu.assemble_numpy(gathered, H, 8), full, f"{shards} shards (host assembly)")
+    # the rank-0 de-interleave kernel, as bench.py uses it after the RCCL gather
+    g = torch.from_numpy(gathered.view(np.int32)).cuda()
+    dst = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    api.deinterleave_bands(gpu_ctx, g.data_ptr(), dst.data_ptr(), W, H, 8, shards)
+    full_frame.wait()                                               # same ctx stream: joins the enqueued kernel
+    torch.cuda.synchronize()
+    _assert_same(dst.cpu().numpy().view(np.uint32), full, f"{shards} shards (device de-interleave)")
+
+
+def test_hdr_accumulation_matches_oracle(gpu_ctx, oracle, scene_cache):
+    """'N spp accumulated' (BASELINE config 5 semantics): N frames summed in the float HDR buffer, tonemapped once."""
+    W, H, N = 160, 96, 4
+    s = scenes.cornell_box(W, H)
+    imgs = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_HDR)
+    scene = api.Scene(gpu_ctx, s.desc)
+    frame = api.Frame(gpu_ctx, W, H, imgs)
+    bvh = scene.export_bvh()
+    hdr = np.zeros((H, W, 4), np.float32)
+    ref = None
+    for f in range(N):
+        p = api.make_params(W, H, spp=1, images=imgs, accumulate=1, accumulated_frames=f)
+        api.render(scene, s.camera, s.scene_info(f), p, frame)
+        ref = oracle.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, images=imgs, hdr=hdr, threads=8)
+    g_hdr = frame.download(A.IMAGE_HDR)
+    assert np.all(g_hdr[..., 3] == N)
+    assert np.array_equal(g_hdr.view(np.uint32), hdr.view(np.uint32)), "accumulated HDR must match bit for bit"
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], "tonemapped accumulation")
+    frame.clear()
+    assert not frame.download(A.IMAGE_HDR).any()
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_bunny_class_parity(gpu_ctx, oracle, scene_cache, pipeline):
+    """BASELINE config 3 geometry (81,920-triangle displaced icosphere, smooth normals), 4 spp, reduced extent."""
+    W, H = 480, 272
+    s = scenes.bunny_class(W, H)
+    p = api.make_params(W, H, spp=4, collect_stats=1, pipeline=pipeline)
+    scene, frame = _gpu_render(gpu_ctx, s, p)
+    assert scene.stats().numTriangles == 81920 + 512 + 2
+    ref = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=scene.export_bvh(), threads=16)
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"bunny-class pipeline{pipeline}")
+    g = frame.stats()
+    assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits)
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_sponza_class_parity(gpu_ctx, oracle, scene_cache, pipeline):
+    """BASELINE config 4 geometry (262 k triangles, 2 area lights), 1 spp, reduced extent, full oracle compare."""
+    W, H = 640, 360
+    s = scenes.sponza_class(W, H)
+    p = api.make_params(W, H, spp=1, collect_stats=1, pipeline=pipeline)
+    scene, frame = _gpu_render(gpu_ctx, s, p, frame_no=5)
+    ref = oracle.render(s.desc, s.camera, s.scene_info(5), p, bvh=scene.export_bvh(), threads=16)
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"sponza-class pipeline{pipeline}")
+    g = frame.stats()
+    for f in ("numRays", "numShadowRays", "numNodeVisits", "numTriTests", "numShadowNodeVisits", "numShadowTriTests", "numHits", "shadowTraceBytes"):
+        assert getattr(g, f) == getattr(ref.stats, f), f
+
+
+def test_sponza_1080p_properties_and_sampled_oracle(gpu_ctx, oracle, scene_cache):
+    """BASELINE.json full size (config 4: 1920x1080, 1 spp).  Size-independent properties: megakernel == wavefront,
+    idempotence, 8-shard reassembly == unsharded; plus the oracle on every 8th band (1/8 of the frame)."""
+    from realtimeraytracer_amd import mgpu
+    W, H = 1920, 1080
+    s = scenes.sponza_class(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    _, fw = _gpu_render(gpu_ctx, s, api.make_params(W, H, collect_stats=1, pipeline=2), scene=scene)
+    wave = fw.download()
+    stw = fw.stats()
+    _, fm = _gpu_render(gpu_ctx, s, api.make_params(W, H, collect_stats=1, pipeline=1), scene=scene)
+    _assert_same(fm.download(), wave, "megakernel vs wavefront at 1080p")
+    stm = fm.stats()
+    assert stw.numPrimaryRays == W * H and stw.numRays == stm.numRays and stw.numNodeVisits == stm.numNodeVisits
+    api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, pipeline=2), fw)
+    _assert_same(fw.download(), wave, "idempotence")
+    rows = api.shard_rows(H, 8, 8)
+    gathered = np.zeros((8, rows, W), np.uint32)
+    for r in range(8):
+        _, fr = _gpu_render(gpu_ctx, s, api.make_params(W, H, shard_index=r, shard_count=8), scene=scene)
+        gathered[r] = fr.download()
+    _assert_same(mgpu.assemble_numpy(gathered, H, 8), wave, "8-shard reassembly at 1080p")
+    p8 = api.make_params(W, H, shard_index=0, shard_count=8)
+    ref = oracle.render(s.desc, s.camera, s.scene_info(0), p8, bvh=scene.export_bvh(), threads=16)
+    _assert_same(gathered[0], ref.images[A.IMAGE_SHADOWED], "shard 0 of 8 vs oracle at 1080p")
+
+
+def test_4k_accumulated_sample(gpu_ctx, oracle, scene_cache):
+    """BASELINE config 5 shape (3840x2160, frames accumulated in float HDR), checked on shard 0 of 32 against the oracle."""
+    W, H, N, SH = 3840, 2160, 3, 32
+    s = scenes.sponza_class(W, H)
+    imgs = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_HDR)
+    scene = api.Scene(gpu_ctx, s.desc)
+    rows = api.shard_rows(H, 8, SH)
+    frame = api.Frame(gpu_ctx, W, rows, imgs)
+    bvh = scene.export_bvh()
+    hdr = np.zeros((rows, W, 4), np.float32)
+    for f in range(N):
+        p = api.make_params(W, H, images=imgs, accumulate=1, accumulated_frames=f, shard_index=0, shard_count=SH)
+        api.render(scene, s.camera, s.scene_info(f), p, frame)
+        ref = oracle.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, images=imgs, hdr=hdr, threads=16)
+    assert np.array_equal(frame.download(A.IMAGE_HDR).view(np.uint32), hdr.view(np.uint32))
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], "4K accumulated shard")
+    # the whole 4K frame renders and every live pixel is opaque
+    full = api.Frame(gpu_ctx, W, H, A.IMAGES_FRAMEBUFFER)
+    api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H), full)
+    img = full.download()
+    assert np.all((img >> 24) == 0xff)
+
+
+def test_update_lights(gpu_ctx, oracle, scene_cache):
+    import copy
+    s = scenes.cornell_box(128, 128)
+    scene = api.Scene(gpu_ctx, s.desc)
+    frame = api.Frame(gpu_ctx, 128, 128)
+    lights = s.host.lightInfos()
+    new = A.RtrAreaLightInfo.from_buffer_copy(bytes(lights[0]))
+    new.color[0], new.color[1], new.color[2], new.intensity, new.isTwoSided = 0.2, 0.9, 0.4, 35.0, 1
+    scene.update_lights([new])
+    p = api.make_params(128, 128)
+    api.render(scene, s.camera, s.scene_info(0), p, frame)
+    # oracle with the same edit applied to a copy of the descriptor's light array
+    arr = (A.RtrAreaLightInfo * 1)(new)
+    d = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc))
+    import ctypes as C
+    d.lights = C.cast(arr, C.POINTER(A.RtrAreaLightInfo))
+    ref = oracle.render(d, s.camera, s.scene_info(0), p, bvh=scene.export_bvh(), threads=8)
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], "after rtr_scene_update_lights")
+    moved = A.RtrAreaLightInfo.from_buffer_copy(bytes(new))
+    moved.transform[12] += 10.0
+    with pytest.raises(api.RtrError):                              # geometry is baked into the BVH: refuse, do not ignore
+        scene.update_lights([moved])
+
+
+def test_async_render_into_external_torch_tensor(gpu_ctx, oracle, scene_cache):
+    """What bench.py does for the RCCL gather: the framebuffer lives in a torch tensor, work is enqueued on a torch stream."""
+    import torch
+    W, H = 256, 128
+    s = scenes.cornell_box(W, H)
+    ctx = api.Context(0)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    scene = api.Scene(ctx, s.desc)
+    frame = api.Frame(ctx, W, H)
+    t = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    frame.bind_external(A.IMAGE_SHADOWED, t.data_ptr(), t.numel() * 4)
+    p = api.make_params(W, H, spp=2)
+    with torch.cuda.stream(stream):
+        api.render(scene, s.camera, s.scene_info(2), p, frame, asynchronous=True)
+    frame.wait()
+    ref = oracle.render(s.desc, s.camera, s.scene_info(2), p, bvh=scene.export_bvh(), threads=8)
+    _assert_same(t.cpu().numpy().view(np.uint32), ref.images[A.IMAGE_SHADOWED], "external tensor / async")
+    assert frame.stats().totalMs > 0
+    for o in (frame, scene, ctx):
+        o.close()
+
+
+def test_empty_scene_renders_sky(gpu_ctx, oracle):
+    from realtimeraytracer_amd import host
+    d = A.rtr_scene_desc()
+    d.skyColor[0], d.skyColor[1], d.skyColor[2] = 0.5, 0.7, 1.0
+    scene = api.Scene(gpu_ctx, d)
+    frame = api.Frame(gpu_ctx, 40, 24)
+    cam = host.Camera(60, (0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 24).getGPUData()
+    p = api.make_params(40, 24, collect_stats=1)
+    api.render(scene, cam, host.scene_info(0, 0, (0, 0, 5)), p, frame)
+    ref = oracle.render(d, cam, host.scene_info(0, 0, (0, 0, 5)), p, bvh=scene.export_bvh(), threads=1)
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], "empty scene")
+    assert frame.stats().numRays == 40 * 24 and frame.stats().numHits == 0

@@ -1,0 +1,108 @@
+"""Host scene layer (csrc/host/): scene::Camera, scene::Object, scene::AreaLight, CreateScene — method names,
+argument meaning and quirks of the reference (src/scene/*.cppm)."""
+import math
+
+import numpy as np
+import pytest
+
+from realtimeraytracer_amd import _abi as A
+from realtimeraytracer_amd import host, scenes
+
+
+def test_camera_known_answer():
+    # fovY=60, pos=(0,0,5), lookAt=0, up=+Y, 1600x1200 (the reference's constructor call, application.cppm:74-81)
+    cam = host.Camera(60.0, (0, 0, 5), (0, 0, 0), (0, 1, 0), 1600, 1200)
+    st = cam.state()
+    assert abs(st["yaw"] + 90.0) < 1e-4 and abs(st["pitch"]) < 1e-4
+    d = cam.getGPUData()
+    np.testing.assert_allclose(d.horizontalViewportDelta[:], (9.6225052e-4, 0.0, 0.0), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(d.verticalViewportDelta[:], (0.0, -9.6225e-4, 0.0), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(d.topLeftViewportCorner[:], (-0.7698005, 0.5773503, 4.0), rtol=1e-6)
+    assert tuple(d.position[:]) == (0.0, 0.0, 5.0)
+    np.testing.assert_allclose(st["forward"], (0, 0, -1), atol=1e-6)
+    np.testing.assert_allclose(st["right"], (1, 0, 0), atol=1e-6)
+
+
+def test_camera_controls():
+    cam = host.Camera(60.0, (0, 0, 5), (0, 0, 0), (0, 1, 0), 800, 600)
+    cam.processMouseMovement(100.0, 1000.0)       # sensitivity 0.1, pitch clamped to 89 (camera.cppm:136-148)
+    st = cam.state()
+    assert abs(st["yaw"] - (-80.0)) < 1e-4 and st["pitch"] == 89.0
+    cam.rotateY(0.1)                              # adds to the DEGREES yaw, as the reference does (camera.cppm:149-154)
+    assert abs(cam.state()["yaw"] - (-79.9)) < 1e-4
+    cam.setPosition((1, 2, 3))
+    assert tuple(cam.getGPUData().position[:]) == (1.0, 2.0, 3.0)
+
+
+def test_object_transform_quirks():
+    hs = host.HostScene()
+    o = hs.addObject("square")
+    o.move((1, 2, 3)).scale(2.0)
+    m = o.getTransform()
+    np.testing.assert_array_equal(m, [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, 2, 3]])   # scale leaves the translation alone
+    o2 = hs.addObject("square")
+    o2.rotate((0.0, 0.0, 90.0))
+    r = o2.getTransform()[:, :3]
+    # quirk Q4: rotation[row][k] indexes a column-major mat3 -> the TRANSPOSE of Rz(90) is applied
+    np.testing.assert_allclose(r, [[0, 1, 0], [-1, 0, 0], [0, 0, 1]], atol=1e-6)
+
+
+def test_area_light_scale_is_diagonal_only_and_packing():
+    hs = host.HostScene()
+    l = hs.addAreaLight(9.0, (0.8, 0.5, 0.2), False)
+    l.move((-1600.0, 2500.5, -500.0)).scale((1300.0, 750.5, 100.0)).rotate((0.0, 90.0, 0.0)).rotate((0.0, 0.0, 55.0))  # application.cppm:184-188
+    hs.build()
+    li = hs.lightInfos()[0]
+    t = l.getTransform()
+    # PackTransformMatrix (core/utils.cppm:11-39): column-major mat4, last row 0 0 0 1
+    m = np.array(li.transform[:], dtype=np.float32).reshape(4, 4).T
+    np.testing.assert_array_equal(m[:3, :], t)
+    np.testing.assert_array_equal(m[3], [0, 0, 0, 1])
+    assert li.numTriangles == 2 and li.vertexOffset == 0 and li.indexOffset == 0 and li.isTwoSided == 0
+    assert abs(li.intensity - 9.0) < 1e-6
+    # quirk Q5: a later scale multiplies only the diagonal
+    before = l.getTransform().copy()
+    l.scale((2.0, 2.0, 2.0))
+    after = l.getTransform()
+    assert after[0, 0] == before[0, 0] * 2 and after[0, 1] == before[0, 1] and after[1, 0] == before[1, 0]
+
+
+def test_square_light_geometry_and_instance_order(scene_cache):
+    s = scenes.cornell_box(64, 64)
+    hs = s.host
+    inst = hs.instances()
+    assert [i.customIndex for i in inst] == list(range(len(inst)))          # tlas.cppm:63-82
+    assert inst[0].meshIndex == 0                                           # lights first
+    v = hs.vertices()
+    np.testing.assert_array_equal(v[:4, :3], [[-0.5, -0.5, 0], [-0.5, 0.5, 0], [0.5, 0.5, 0], [0.5, -0.5, 0]])   # area_light.cppm:79-82
+    np.testing.assert_array_equal(hs.indices()[:6], [0, 1, 2, 0, 2, 3])     # geometry_builder.cppm:88
+    assert hs.meshes()[0].isOpaque == 1 and hs.meshes()[1].isOpaque == 0    # quirk Q11: OBJ/MTL meshes are non-opaque
+
+
+def test_model_dedup_across_instances(scene_cache):
+    obj, _ = scenes.write_cornell(scene_cache)
+    hs = host.HostScene()
+    a = hs.addObject(obj)
+    b = hs.addObject(obj)
+    b.move((10, 0, 0))
+    hs.build()
+    assert hs.desc.numMeshes == 1 and hs.desc.numInstances == 2             # geometry_builder.cppm:67-76 path-keyed cache
+    assert a.info()["blasIndex"] == b.info()["blasIndex"] == 0
+    assert a.info()["numTriangles"] == 36
+    # loadModel de-duplicates across the whole file: 36 tris over the shared floor/wall corners
+    assert hs.desc.numIndices == 108
+
+
+def test_texture_named_objects_are_refused_loudly(scene_cache):
+    """Textures are a 'next' row: the product must say so, not render something else."""
+    obj, _ = scenes.write_cornell(scene_cache)
+    hs = host.HostScene()
+    o = hs.addObject(obj)
+    o.setColor("some/texture.png")
+    hs.build()
+    assert hs.objectInfos()[0].usesColorMap == 1
+    lib = A.hip_lib()
+    st = A.rtr_scene_stats()
+    import ctypes as C
+    rc = lib.rtr_host_build_bvh(C.byref(hs.desc), C.byref(st), None, 0, None, 0)
+    assert rc == -4 and b"texture" in lib.rtr_last_error()
