@@ -195,9 +195,20 @@ _host = None
 
 
 def hip_lib():
-    """librtr_hip.so (the product).  Loaded on first use; raises ImportError if absent/incomplete."""
+    """librtr_hip.so (the product).  Loaded on first use; raises ImportError if absent/incomplete.
+
+    PyTorch-ROCm wheels bundle their own copy of the HIP runtime (torch/lib/libamdhip64.so, loaded into the
+    global symbol scope).  A process must end up with ONE initialised HIP runtime: if this library were loaded
+    first it would bind to /opt/rocm's runtime and torch's copy would later find "No HIP GPUs".  The harness
+    (tests, bench) uses torch for device tensors and RCCL, so torch is imported first and librtr_hip.so then
+    resolves its hip* symbols against the runtime already in the process — which also makes a torch stream
+    handle valid for rtr_ctx_set_stream.  A C/C++ host without torch simply uses the ROCm runtime it links."""
     global _hip
     if _hip is None:
+        try:
+            import torch  # noqa: F401  (see docstring: load order matters, nothing else of torch is used here)
+        except ImportError:
+            pass
         _hip = _bind(LIB_HIP_PATH, RTR_SYMBOLS, "librtr_hip.so")
     return _hip
 
