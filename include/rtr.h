@@ -197,6 +197,14 @@ int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSc
                       const rtr_render_params* params, rtr_frame* frame);
 int  rtr_frame_wait(rtr_frame* frame);
 
+/* The passes that follow the ray-gen dispatch in the reference's frame loop (src/app/application.cppm:391-445):
+ * `iterations` (reference: NUM_DENOISING_ITERATIONS = 4) rounds of {a-trous pass on the unshadowed image, then on the
+ * shadowed image} ping-ponging between the sampled (1,2) and denoised (3,4) images with step (i+1), c_phi 1,
+ * n_phi = p_phi = 1e-3 (src/shaders/denoise.comp), then combine.comp: FINAL = ANALYTIC * shadowed / max(unshadowed, .001)
+ * reading the pair the ping-pong flag points at.  The frame must own images 0-7 and hold a full (unsharded) frame
+ * rendered with RTR_IMAGES_RAYGEN5.  Synchronous. */
+int  rtr_denoise_combine(rtr_frame* frame, int iterations);
+
 /* Rank-0 step after the RCCL gather: `gathered` holds shardCount blocks of (localRows x width)
  * RGBA8 pixels in rank order; writes the de-interleaved (height x width) image to `dst`.
  * Both are device pointers; ENQUEUED on the ctx stream (asynchronous; synchronise the stream to read). */

@@ -131,6 +131,7 @@ RTR_SYMBOLS = {
     "rtr_render_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
     "rtr_frame_wait": (C.c_int, [VP]),
     "rtr_deinterleave_bands": (C.c_int, [VP, VP, VP, u32, u32, u32, u32]),
+    "rtr_denoise_combine": (C.c_int, [VP, C.c_int]),
     "rtr_last_error": (C.c_char_p, []),
     "rtr_status_string": (C.c_char_p, [C.c_int]),
     "rtr_abi_version": (C.c_int, []),

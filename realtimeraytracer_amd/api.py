@@ -109,6 +109,10 @@ class Frame:
     def clear(self):
         _check(self.lib.rtr_frame_clear(self.h), "rtr_frame_clear")
 
+    def denoise_combine(self, iterations=4):
+        """reference frame loop tail (application.cppm:391-445): 4 x a-trous on both sampled images, then combine."""
+        _check(self.lib.rtr_denoise_combine(self.h, iterations), "rtr_denoise_combine")
+
     def wait(self):
         _check(self.lib.rtr_frame_wait(self.h), "rtr_frame_wait")
 

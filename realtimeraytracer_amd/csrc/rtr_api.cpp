@@ -6,6 +6,7 @@
 #include "../../include/rtr_math.h"
 #include "bvh_build.h"
 #include "kernels/rtr_kernels.h"
+#include "kernels/rtr_post.h"
 
 #include <hip/hip_runtime.h>
 
@@ -587,6 +588,37 @@ int rtr_render(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info,
 int rtr_frame_get_stats(const rtr_frame* f, rtr_frame_stats* out) {
     if (!f || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_get_stats: null argument");
     *out = f->stats;
+    return RTR_OK;
+}
+
+int rtr_denoise_combine(rtr_frame* f, int iterations) {
+    if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_denoise_combine: null frame");
+    if (iterations < 0 || iterations > 64) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_denoise_combine: iterations %d", iterations);
+    for (int i = 0; i < 8; ++i)
+        if (!f->image_ptr(i)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_denoise_combine: the frame lacks image %d (create it with all of images 0-7)", i);
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    uint32_t* sh = f->image_ptr(RTR_IMAGE_SHADOWED); uint32_t* un = f->image_ptr(RTR_IMAGE_UNSHADOWED);
+    uint32_t* dsh = f->image_ptr(RTR_IMAGE_DENOISED_SHADOWED); uint32_t* dun = f->image_ptr(RTR_IMAGE_DENOISED_UNSHADOWED);
+    const uint32_t* nrm = f->image_ptr(RTR_IMAGE_NORMAL); const uint32_t* pos = f->image_ptr(RTR_IMAGE_POSITION);
+    int denoisingOutput = 1;                                            /* application.cppm:392 */
+    for (int i = 0; i < iterations; ++i) {
+        const int step = (i + 1) * 1;                                   /* (i + 1) * DENOISING_STRENGTH */
+        hipError_t e;
+        if (denoisingOutput == 1) {
+            e = rtrdev::launch_denoise(un, dun, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
+            if (e == hipSuccess) e = rtrdev::launch_denoise(sh, dsh, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
+        } else {
+            e = rtrdev::launch_denoise(dun, un, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
+            if (e == hipSuccess) e = rtrdev::launch_denoise(dsh, sh, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
+        }
+        if (e != hipSuccess) return fail(RTR_ERR_HIP, "denoise launch: %s", hipGetErrorString(e));
+        denoisingOutput = 1 - denoisingOutput;
+    }
+    hipError_t e = rtrdev::launch_combine(f->image_ptr(RTR_IMAGE_ANALYTIC), denoisingOutput == 0 ? sh : dsh, denoisingOutput == 0 ? un : dun,
+                                          f->image_ptr(RTR_IMAGE_FINAL), f->width, f->rows, st);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "combine launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(st));
     return RTR_OK;
 }
 

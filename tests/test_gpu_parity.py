@@ -296,3 +296,26 @@ def test_empty_scene_renders_sky(gpu_ctx, oracle):
     ref = oracle.render(d, cam, host.scene_info(0, 0, (0, 0, 5)), p, bvh=scene.export_bvh(), threads=1)
     _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], "empty scene")
     assert frame.stats().numRays == 40 * 24 and frame.stats().numHits == 0
+
+
+@pytest.mark.parametrize("size", [(256, 256), (333, 187)])
+def test_denoise_combine_matches_oracle(gpu_ctx, oracle, scene_cache, size):
+    """the 8 a-trous dispatches + combine of the reference frame loop, bit-exact on all five
+    images they touch (sampled pair is overwritten by the ping-pong; quirks Q8-Q10 kept)."""
+    W, H = size
+    all8 = 0xff
+    s = scenes.cornell_box(W, H, ltc=scenes.synthetic_ltc())
+    scene = api.Scene(gpu_ctx, s.desc)
+    frame = api.Frame(gpu_ctx, W, H, all8)
+    p = api.make_params(W, H, spp=2, images=A.IMAGES_RAYGEN5)
+    api.render(scene, s.camera, s.scene_info(0), p, frame)
+    src = {k: frame.download(k) for k in (0, 1, 2, 6, 7)}
+    frame.denoise_combine(4)
+    ref = oracle.denoise_combine(src[0], src[1], src[2], src[6], src[7], iterations=4)
+    for which in (A.IMAGE_SHADOWED, A.IMAGE_UNSHADOWED, A.IMAGE_DENOISED_SHADOWED, A.IMAGE_DENOISED_UNSHADOWED, A.IMAGE_FINAL):
+        _assert_same(frame.download(which), ref[which], f"denoise/combine image {which} at {W}x{H}")
+    fin = frame.download(A.IMAGE_FINAL)
+    assert np.all((fin >> 24) == 0xff) and len(np.unique(fin)) > 100
+    small = api.Frame(gpu_ctx, W, H, A.IMAGES_RAYGEN5)
+    with pytest.raises(api.RtrError):
+        small.denoise_combine(4)

@@ -141,3 +141,27 @@ def test_empty_and_degenerate_scenes(oracle):
     assert st.numTriangles == 2
     r = oracle.render(hs.desc, cam, host.scene_info(0, 1, (0, 0, 5)), p, bvh=(nodes, tris), threads=1)
     assert r.stats.numHits == 0      # a == 0 triangles never pass Moeller-Trumbore
+
+
+def test_oracle_denoise_combine_properties(oracle):
+    """denoise.comp / combine.comp restatement: flat images are fixed points; combine formula; ping-pong protocol."""
+    H, W = 24, 40
+    def img(b, g, r):
+        return np.full((H, W), (255 << 24) | (r << 16) | (g << 8) | b, np.uint32)
+    an, sh, un = img(200, 100, 50), img(60, 60, 60), img(120, 120, 120)
+    no, po = img(128, 128, 255), img(10, 20, 30)
+    out = oracle.denoise_combine(an, sh, un, no, po, iterations=4)
+    assert np.array_equal(out[A.IMAGE_DENOISED_SHADOWED], sh) and np.array_equal(out[A.IMAGE_DENOISED_UNSHADOWED], un)
+    assert np.array_equal(out[A.IMAGE_SHADOWED], sh)            # 4th pass writes the sampled images back (quirk Q8)
+    # final = analytic * shadowed / unshadowed, per channel, alpha 1
+    f = out[A.IMAGE_FINAL].view(np.uint8).reshape(H, W, 4)[0, 0]
+    exp = [round(c / 255 * (60 / 255) / (120 / 255) * 255) for c in (200, 100, 50)]
+    assert list(f[:3]) == exp and f[3] == 255
+    # iterations = 0: combine reads the (untouched, zero) denoised pair -> 0/0.001 = 0
+    out0 = oracle.denoise_combine(an, sh, un, no, po, iterations=0)
+    assert np.all(out0[A.IMAGE_FINAL] == 0xff000000)
+    # an edge in the colour image is preserved better than a box blur would (edge-stopping weight)
+    sh2 = sh.copy(); sh2[:, W // 2:] = img(250, 250, 250)[:, W // 2:]
+    o2 = oracle.denoise_combine(an, sh2, un, no, po, iterations=1)
+    d = o2[A.IMAGE_DENOISED_SHADOWED].view(np.uint8).reshape(H, W, 4)[H // 2, :, 0].astype(int)
+    assert d[W // 2 - 3] < 80 and d[W // 2 + 2] > 230
