@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0, help="0 default, 1 megakernel, 2 wavefront")
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + RTR_BENCH_SAME_DEVICE=1 rehearses the N>1 control flow with several ranks on ONE GPU (shards staged through host memory)")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
     args = ap.parse_args()
 
@@ -64,10 +66,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the ray-tracing path has no CPU fallback")
+    if os.environ.get("RTR_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     W, H, S = args.width, args.height, args.spp
     setup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
@@ -77,14 +84,19 @@ def main():
     scene = api.Scene(ctx, setup.desc)
     sstats = scene.stats()
     rows = api.shard_rows(H, args.band_rows, world)
-    frame = api.Frame(ctx, W, rows, A.IMAGES_FRAMEBUFFER)
-    local = torch.zeros((rows, W), dtype=torch.int32, device=device)           # RGBA8 framebuffer of this shard
-    frame.bind_external(A.IMAGE_SHADOWED, local.data_ptr(), local.numel() * 4)
+    # N > 1 double-buffers the shard framebuffer so the RCCL gather of frame i overlaps the render of frame i+1
+    nbuf = 2 if world > 1 else 1
+    frames = [api.Frame(ctx, W, rows, A.IMAGES_FRAMEBUFFER) for _ in range(nbuf)]
+    locals_ = [torch.zeros((rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)]   # RGBA8 framebuffer of this shard
+    for fr, lo in zip(frames, locals_):
+        fr.bind_external(A.IMAGE_SHADOWED, lo.data_ptr(), lo.numel() * 4)
+    frame, local = frames[0], locals_[0]
+    gathered = [torch.zeros((world, rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if (rank == 0 and world > 1) else None
     full = torch.zeros((H, W), dtype=torch.int32, device=device) if rank == 0 else None
 
-    def params(collect=0):
-        return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=rank,
-                               shard_count=world, collect_stats=collect, pipeline=args.pipeline)
+    def params(collect=0, shard_index=rank, shard_count=world):
+        return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=shard_index,
+                               shard_count=shard_count, collect_stats=collect, pipeline=args.pipeline)
 
     # ---- untimed stats pass: exact ray / node / triangle counts of one frame -------------------------
     api.render(scene, setup.camera, setup.scene_info(0), params(collect=1), frame)
@@ -99,6 +111,37 @@ def main():
     p_run = params(0)
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0}
 
+    works = [None] * nbuf
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def gather_async(buf):
+        """the one exchange step (RCCL over xGMI): every rank's shard -> rank 0, asynchronous w.r.t. the render stream"""
+        if args.backend == "gloo":            # rehearsal only: stage through host memory
+            stream.synchronize()
+            host = locals_[buf].cpu()
+            if rank == 0:
+                hosts = [torch.empty_like(host) for _ in range(world)]
+                dist.gather(host, gather_list=hosts, dst=0)
+                gathered[buf].copy_(torch.stack(hosts))
+            else:
+                dist.gather(host, gather_list=None, dst=0)
+            return _Done()
+        if rank == 0:
+            return dist.gather(locals_[buf], gather_list=[gathered[buf][r] for r in range(world)], dst=0, async_op=True)
+        return dist.gather(locals_[buf], gather_list=None, dst=0, async_op=True)
+
+    def finish(buf):
+        """stream-level wait for gather `buf`, then (rank 0) de-interleave it into the full frame"""
+        if works[buf] is None:
+            return
+        works[buf].wait()
+        works[buf] = None
+        if rank == 0:
+            api.deinterleave_bands(ctx, gathered[buf].data_ptr(), full.data_ptr(), W, H, args.band_rows, world)
+
     def step(i):
         info = setup.scene_info(i)
         with torch.cuda.stream(stream):
@@ -108,10 +151,16 @@ def main():
                 kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
                 kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
             else:
-                api.render(scene, setup.camera, info, p_run, frame, asynchronous=True)
-                gathered = mgpu.gather_to_root(dist, local, world, rank)        # the one exchange step (RCCL over xGMI)
-                if rank == 0:
-                    api.deinterleave_bands(ctx, gathered.data_ptr(), full.data_ptr(), W, H, args.band_rows, world)
+                b = i & 1
+                finish(b)                                   # frame i-2 (same buffers) fully consumed
+                api.render(scene, setup.camera, info, p_run, frames[b], asynchronous=True)
+                works[b] = gather_async(b)                  # overlaps the next frame's kernels
+                finish(1 - b)                               # frame i-1: its gather ran under this frame's render
+
+    def drain():
+        if world > 1:
+            with torch.cuda.stream(stream):
+                finish(0); finish(1)
 
     def sync_all():
         if world > 1:
@@ -120,17 +169,20 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0})
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    drain()
     torch.cuda.synchronize()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        frame.wait()
-        st = frame.stats()   # last step's launches (async mode keeps only those)
+        last = frames[(args.warmup + args.steps - 1) & 1]
+        last.wait()
+        st = last.stats()    # last step's launches (async mode keeps only those)
         kern.update({"primary": st.primaryMs, "shadow_gen": st.shadowGenMs, "shadow_trace": st.shadowTraceMs,
                      "resolve": st.resolveMs, "n": 1})
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -200,7 +252,6 @@ def main():
                                "sample": f"every {sample_shards}nd 8-row band of the same frame ({r.stats.numRays} rays, {dt:.1f} s), scalar C++ oracle, "
                                          f"{threads} std::threads over rows, -O2 -ffp-contract=off"}
         if args.verify:
-            gpu = full.cpu().numpy().view(np.uint32) if world > 1 else local.cpu().numpy().view(np.uint32)
             ys = mgpu.global_rows_of_shard(H, args.band_rows, sample_shards, 0)
             # the verify render used frame index = last step; re-render that frame on the GPU for the comparison
             api.render(scene, setup.camera, setup.scene_info(0), params(0), frame)
@@ -210,6 +261,13 @@ def main():
             out["verify"] = {"rows_checked": int(ok.sum()), "pixels_differing": bad}
     elif rank == 0:
         out["cpu_baseline"] = None
+        # N > 1: the assembled frame of the last step must equal the same frame rendered unsharded on this GPU
+        last_i = args.warmup + args.steps - 1
+        whole = api.Frame(ctx, W, H, A.IMAGES_FRAMEBUFFER)
+        api.render(scene, setup.camera, setup.scene_info(last_i), params(0, 0, 1), whole)
+        torch.cuda.synchronize()
+        bad = int((full.cpu().numpy().view(np.uint32) != whole.download()).sum())
+        out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

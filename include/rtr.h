@@ -183,8 +183,8 @@ int  rtr_frame_download(const rtr_frame* frame, int which, void* dst, size_t byt
 int  rtr_frame_clear(rtr_frame* frame);
 int  rtr_frame_get_stats(const rtr_frame* frame, rtr_frame_stats* out);
 
-/* Number of local rows shard `shardIndex` of `shardCount` owns, padded so every shard has the
- * same count (equal-size shards for the gather). */
+/* Number of local rows a shard owns: `height` when unsharded, otherwise ceil(bands / shardCount) * bandRows so
+ * every shard has the same count (equal-size shards for the gather; padding rows stay zero). */
 uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount);
 
 /* ---- dispatch ------------------------------------------------------------------------- */

@@ -138,6 +138,8 @@ def denoise_combine(analytic, shadowed, unshadowed, normal, position, iterations
 
 
 def _shard_rows(height, band_rows, shard_count):
+    if shard_count <= 1:
+        return height
     bands = (height + band_rows - 1) // band_rows
     per = (bands + shard_count - 1) // shard_count
     return per * band_rows

@@ -484,6 +484,7 @@ void parallel_rows(uint32_t rows, int threads, F&& fn) {
 extern "C" {
 
 static uint32_t shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount) {
+    if (shardCount <= 1) return height;
     uint32_t bands = (height + bandRows - 1) / bandRows;
     uint32_t per = (bands + shardCount - 1) / shardCount;
     return per * bandRows;

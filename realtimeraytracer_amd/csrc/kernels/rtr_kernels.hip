@@ -20,6 +20,8 @@
  */
 #include "rtr_kernels.h"
 
+#include <cstdlib>
+
 namespace rtrdev {
 
 constexpr int kBlock = 256;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
  * showed the SIMDs ~100 % busy issuing instructions at ~30 % lane utilisation: rays of one wave need
  * very different numbers of node visits, and inner-node and leaf work alternated under divergent
  * branches.  Here:
- *   * a wave grabs BATCH consecutive queue entries with ONE atomic and keeps them in wave-uniform
+ *   * a wave grabs a batch of consecutive queue entries (256 by default; swept in profiles/r01/sweep_refill.log) with ONE atomic and keeps them in wave-uniform
  *     cursors; whenever at least kRefill lanes are idle (ballot + popcount) the idle lanes take the next
  *     entries (mbcnt prefix), so finished rays are replaced instead of waited for;
  *   * "while-while": all lanes first descend inner nodes until every live lane sits on a leaf (or has
@@ -185,13 +187,13 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
  * A lane's own sequence of node visits / triangle tests is exactly that of trace<true>() — and of the
  * oracle's trace_bvh() — so visibility bits AND work counters are unchanged. */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
-constexpr uint32_t kBatch = 1024;
-constexpr uint32_t kRefill = 20;
+constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
+constexpr uint32_t kRefillDefault = 16;    /* idle lanes that trigger a refill */
 
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
                                                          const uint32_t* __restrict__ count, uint32_t* nextBatch,
-                                                         uint8_t* __restrict__ vis, Counters* stats) {
+                                                         uint8_t* __restrict__ vis, Counters* stats, uint32_t kBatch, uint32_t kRefill) {
     __shared__ int32_t s_stack[STACK * kBlock];
     int32_t* stack = s_stack + threadIdx.x;
     const uint32_t n = *count;
@@ -318,6 +320,13 @@ __global__ __launch_bounds__(kBlock) void k_deinterleave(const uint32_t* __restr
 }
 
 /* ---- launchers ------------------------------------------------------------------------------- */
+static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    unsigned long x = strtoul(v, nullptr, 10);
+    return x < lo ? lo : (x > hi ? hi : (uint32_t)x);
+}
+
 static uint32_t padded_pixels(const RenderArgs& ra) {
     const uint32_t band8 = (ra.localRows + 7u) / 8u;
     return band8 * ra.tilesPerRow * 64u;
@@ -363,8 +372,10 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
-    if (stats) hipLaunchKernelGGL((k_shadow_trace<STACK, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats);
-    else hipLaunchKernelGGL((k_shadow_trace<STACK, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats);
+    static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
+    static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
+    if (stats) hipLaunchKernelGGL((k_shadow_trace<STACK, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill);
+    else hipLaunchKernelGGL((k_shadow_trace<STACK, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill);
     if (ev) hipEventRecord(ev[3], s);
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);

@@ -130,7 +130,7 @@ int rtr_abi_version(void) { return RTR_ABI_VERSION; }
 
 uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount) {
     if (bandRows == 0) bandRows = 8;
-    if (shardCount == 0) shardCount = 1;
+    if (shardCount <= 1) return height;               /* unsharded: no padding rows */
     uint32_t bands = (height + bandRows - 1) / bandRows;
     uint32_t per = (bands + shardCount - 1) / shardCount;
     return per * bandRows;

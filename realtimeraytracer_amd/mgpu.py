@@ -15,6 +15,8 @@ import numpy as np
 
 
 def shard_rows(height, band_rows, shard_count):
+    if shard_count <= 1:
+        return height
     bands = (height + band_rows - 1) // band_rows
     per = (bands + shard_count - 1) // shard_count
     return per * band_rows
