@@ -32,7 +32,7 @@ typedef enum rtr_status {
     RTR_ERR_INVALID_ARGUMENT = -1,
     RTR_ERR_HIP = -2,            /* a HIP runtime call failed (message has hipGetErrorString) */
     RTR_ERR_NO_DEVICE = -3,
-    RTR_ERR_UNSUPPORTED = -4,    /* feature on a "next" row (textures, HDRI) requested */
+    RTR_ERR_UNSUPPORTED = -4,    /* a feature that is not built (e.g. an image format the host loader cannot decode) */
     RTR_ERR_OUT_OF_MEMORY = -5,
     RTR_ERR_BVH_TOO_DEEP = -6,   /* traversal stack bound exceeded; fail loudly, never clamp */
     RTR_ERR_IO = -7
@@ -65,6 +65,17 @@ typedef enum rtr_image {
 #define RTR_IMAGES_DENOISE (RTR_IMG_BIT(RTR_IMAGE_DENOISED_SHADOWED) | RTR_IMG_BIT(RTR_IMAGE_DENOISED_UNSHADOWED) | \
                             RTR_IMG_BIT(RTR_IMAGE_FINAL))
 
+/* One entry of the reference's texSamplers[] array (src/app/setup/create_scene.cppm:71-141): 8-bit texels as
+ * core::file::createTextureImage produces them (src/core/file.cppm:272-311: stb_image, vertical flip,
+ * R8G8B8A8_UNORM or R8_UNORM), sampled with the reference's sampler — linear filter, repeat addressing, one mip
+ * (src/vulkan/memory/image_sampler.cppm:26-42).  Row 0 of `pixels` is v = 0. */
+typedef struct rtr_texture {
+    const uint8_t* pixels;     /* width*height*channels bytes; NULL for an unused slot (indices 0,1 = LTC tables) */
+    uint32_t       width, height;
+    uint32_t       channels;   /* 4 = RGBA8, 1 = R8 */
+    uint32_t       _pad;
+} rtr_texture;
+
 /* What Application::run() uploads once (src/app/application.cppm:226-271,
  * src/app/setup/geometry_builder.cppm:50-212, src/vulkan/raytracing/tlas.cppm:44-149).
  * The library copies everything; the caller keeps ownership of its arrays. */
@@ -79,10 +90,14 @@ typedef struct rtr_scene_desc {
      * NULL -> RTR_IMAGE_ANALYTIC cannot be rendered (RTR_ERR_UNSUPPORTED if asked for). */
     const float*            ltc1;          /* 64*64*4 floats or NULL */
     const float*            ltc2;          /* 64*64*4 floats or NULL */
-    /* miss.rmiss:21-26 samples an equirect HDRI; until the texture row lands the sky is this
-     * constant (sRGB-encoded, ToLinear applied as the miss shader does). */
+    /* miss.rmiss:21-26 samples an equirect HDRI (binding 7); when `hdri` is NULL the sky is this constant
+     * (sRGB-encoded; ToLinear applied as the miss shader does). */
     float                   skyColor[3];
     float                   _pad;
+    /* texSamplers[] (set 1 binding 4): ObjectInfo.colorIndex / specularIndex / metallicIndex / opacityIndex index
+     * this array; the reference keeps the LTC tables at 0 and 1 so material textures start at 2. */
+    const rtr_texture*      textures;      uint32_t numTextures;
+    const rtr_texture*      hdri;          /* equirect sky (RGBA8, as stbi_load of the .hdr gives, file.cppm:279-291) or NULL */
 } rtr_scene_desc;
 
 typedef struct rtr_scene_stats {
@@ -128,7 +143,9 @@ typedef struct rtr_frame_stats {
     uint64_t numHits;          /* N_hit : closest-hit shading fetches (236 B each) */
     uint64_t numLightFetches;  /* N_lightfetch: LightInfo reads (96 B each) */
     uint64_t numLightTriFetches;/* light triangle vertex fetches (3 idx + 3 x 48 B = 156 B each) */
-    uint64_t algorithmicBytes; /* B = 64 N_node + 48 N_tri + 236 N_hit + 96 N_lf + 156 N_ltf + 4 k P (+32 P if HDR RMW) */
+    uint64_t numTexFetches;    /* bilinear texture / HDRI lookups (4 texels, 16 B each) */
+    uint64_t numAlphaTests;    /* opacity.rahit invocations that sampled an opacity map (236 B fetch + 1 lookup each) */
+    uint64_t algorithmicBytes; /* B = 64 N_node + 48 N_tri + 236 (N_hit + N_alpha) + 96 N_lf + 156 N_ltf + 16 N_tex + 4 k P (+16/32 P HDR) */
     /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
     uint64_t numShadowNodeVisits;
     uint64_t numShadowTriTests;

@@ -190,6 +190,35 @@ RTR_HD float rtr_pow(float x, float y) {
     return rtr_exp2(y * rtr_log2(x));
 }
 
+/* ---- atan2 / acos (miss.rmiss:19-22 equirect lookup) ------------------------------------------ */
+/* atan on [0, tan(pi/8)]: odd degree-9 polynomial (the classic single-precision form; |err| < 2e-7) */
+RTR_HD float rtr_atan_small(float x) {
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = rtr_fma(p, z, -1.38776856032e-1f);
+    p = rtr_fma(p, z, 1.99777106478e-1f);
+    p = rtr_fma(p, z, -3.33329491539e-1f);
+    return rtr_fma(p * z, x, x);
+}
+/* atan2(y, x) in (-pi, pi]; atan2(0,0) = 0.  Range reduction: t = min/max in [0,1], pi/8 split,
+ * then octant / quadrant / sign fix-ups. */
+RTR_HD float rtr_atan2(float y, float x) {
+    const float ax = rtr_abs(x), ay = rtr_abs(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    if (!(mx > 0.0f)) return 0.0f;                 /* (0,0) and NaN */
+    const float t = mn / mx;
+    float r;
+    if (t > 0.41421356237f) r = 0.78539816339f + rtr_atan_small((t - 1.0f) / (t + 1.0f));
+    else r = rtr_atan_small(t);
+    if (ay > ax) r = 1.57079632679f - r;
+    if (x < 0.0f) r = 3.14159265359f - r;
+    return y < 0.0f ? -r : r;
+}
+/* acos(x), x in [-1,1]: 2*atan2(sqrt(1-x), sqrt(1+x)) — accurate at both ends */
+RTR_HD float rtr_acos(float x) {
+    return 2.0f * rtr_atan2(rtr_sqrt(1.0f - x), rtr_sqrt(1.0f + x));
+}
+
 /* ---- ray / box / triangle ---------------------------------------------------------------- */
 /* Direction components are kept away from 0 so 1/d is finite and the slab test never
  * forms inf*0 or inf-inf (no NaN reaches rtr_hwmin/rtr_hwmax). */

@@ -7,7 +7,7 @@
  * Deliberate divergences from the reference text (all recorded in DESIGN.md):
  *   D1 (Q3)  zero vertex normals: reference computes normalize(vec3(0)) = NaN
  *            (closesthit.rchit:74-76); here the geometric normal, flipped to face the ray.
- *   D2       miss.rmiss HDRI lookup -> constant sky colour (texture row is "next").
+ *   D2       no HDRI supplied -> constant sky colour (same ToLinear); atan/acos are rtr_math.h's own forms.
  *   D3       pow(): own exp2/log2 forms (rtr_math.h); x < FLT_MIN -> 0.
  *   D4       hit accepted iff tmin < t < tmax; closest = min over (t, customIndex, primitiveID).
  *
@@ -27,15 +27,15 @@ namespace {
 
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
-    uint64_t shadowNodes = 0, shadowTris = 0;
+    uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0;
     void add(const Counters& o) {
-        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris;
+        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
     }
 };
 
-struct WorldTri { rtr_v3 v0, e1, e2; uint32_t custom, prim; };
+struct WorldTri { rtr_v3 v0, e1, e2; uint32_t custom, prim, flags; };
 
 struct Scene {
     const oracle_scene* s;
@@ -46,6 +46,53 @@ struct Scene {
 };
 
 struct Hit { bool hit; float t, u, v; uint32_t custom, prim; };
+
+/* ---- texture(): 8-bit texels, linear filter, repeat addressing, one mip (image_sampler.cppm:26-42) ------------- */
+inline void sample_tex(const rtr_texture& tx, float u, float v, float out[4], Counters& c) {
+    c.texFetch++;
+    if (!(u > -1.0e9f && u < 1.0e9f)) u = 0.0f;        /* NaN / absurd coordinates sample (0,0) */
+    if (!(v > -1.0e9f && v < 1.0e9f)) v = 0.0f;
+    const int W = (int)tx.width, H = (int)tx.height, ch = (int)tx.channels;
+    const float uf = u - __builtin_floorf(u), vf = v - __builtin_floorf(v);      /* repeat */
+    const float x = rtr_fma(uf, (float)W, -0.5f), y = rtr_fma(vf, (float)H, -0.5f);
+    const float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    if (x0 < 0) x0 += W;
+    if (x0 >= W) x0 -= W;
+    if (y0 < 0) y0 += H;
+    if (y0 >= H) y0 -= H;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    if (x1 >= W) x1 -= W;
+    if (y1 >= H) y1 -= H;
+    const uint8_t* p = tx.pixels;
+    for (int k = 0; k < 4; ++k) {
+        if (k >= ch) { out[k] = (k == 3) ? 1.0f : 0.0f; continue; }       /* R8: (r,0,0,1) */
+        const float t00 = (float)p[((size_t)y0 * W + x0) * ch + k] / 255.0f, t10 = (float)p[((size_t)y0 * W + x1) * ch + k] / 255.0f;
+        const float t01 = (float)p[((size_t)y1 * W + x0) * ch + k] / 255.0f, t11 = (float)p[((size_t)y1 * W + x1) * ch + k] / 255.0f;
+        const float a = rtr_fma(t10 - t00, fx, t00), b = rtr_fma(t11 - t01, fx, t01);
+        out[k] = rtr_fma(b - a, fy, a);
+    }
+}
+
+/* opacity.rahit:31-64: invoked for candidates on non-opaque geometry whose object has an opacity map;
+ * false -> ignoreIntersectionEXT */
+inline bool alpha_pass(const rtr_scene_desc& D, uint32_t custom, uint32_t prim, float bu, float bv, Counters& c) {
+    const RtrObjectInfo& oi = D.objects[custom - D.numLights];                           /* :33-34 */
+    if (oi.usesOpacityMap == 0) return true;                                             /* :36-38 */
+    c.alphaTests++;
+    const uint32_t i0 = D.indices[3 * prim + 0 + oi.indexOffset], i1 = D.indices[3 * prim + 1 + oi.indexOffset],
+                   i2 = D.indices[3 * prim + 2 + oi.indexOffset];                        /* :44-46 */
+    const RtrVertex& v0 = D.vertices[i0 + oi.vertexOffset];
+    const RtrVertex& v1 = D.vertices[i1 + oi.vertexOffset];
+    const RtrVertex& v2 = D.vertices[i2 + oi.vertexOffset];
+    const float b0 = 1.0f - bu - bv;                                                      /* :52 */
+    const float uu = rtr_fma(v2.uv[0], bv, rtr_fma(v1.uv[0], bu, v0.uv[0] * b0));        /* :53 */
+    const float vv = rtr_fma(v2.uv[1], bv, rtr_fma(v1.uv[1], bu, v0.uv[1] * b0));
+    float t[4];
+    sample_tex(D.textures[oi.opacityIndex], uu, vv, t, c);                                /* :55 */
+    return !(t[0] < 0.9f);                                                                /* :58-60 */
+}
 
 /* ---- traversal: the algorithm the HIP kernels restate (DESIGN.md "Traversal") ---------------- */
 inline bool id_less(uint32_t c0, uint32_t p0, uint32_t c1, uint32_t p1) {
@@ -69,6 +116,8 @@ Hit trace_brute(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, boo
         float t, u, v;
         c.tris++; if (anyHit) c.shadowTris++;
         if (rtr_mt_intersect(o, d, w.v0, w.e1, w.e2, tmin, &t, &u, &v)) {
+            if (!(t < tmax)) continue;
+            if ((w.flags & 1u) && !alpha_pass(sc.s->desc, w.custom, w.prim, u, v, c)) continue;
             consider(best, t, u, v, w.custom, w.prim, tmax);
             if (anyHit && best.hit) return best;
         }
@@ -109,6 +158,8 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
                 float t, u, v;
                 c.tris++; if (anyHit) c.shadowTris++;
                 if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
+                    if (!(t < tmax)) continue;
+                    if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
                     consider(best, t, u, v, tr.customIndex, tr.primitiveId, tmax);
                     if (anyHit && best.hit) return best;
                 }
@@ -252,10 +303,16 @@ inline Surface closest_hit_shader(const Scene& sc, const Hit& h, rtr_v3 rayDir, 
         if (rtr_dot(n, rayDir) > 0.0f) n = rtr_neg(n);
         sf.normal = n;
     }
-    /* :79-101 materials: constants only (textures are a "next" row; scene creation rejects maps) */
+    /* :77 uv, :79-101 materials from constants or texSamplers[] */
+    const float uu = rtr_fma(v2.uv[0], b2, rtr_fma(v1.uv[0], b1, v0.uv[0] * b0));
+    const float vv = rtr_fma(v2.uv[1], b2, rtr_fma(v1.uv[1], b1, v0.uv[1] * b0));
     rtr_v3 col = rtr_ld3(oi.color);
     float rough = oi.specular;
     sf.metallic = oi.metallic;
+    float tex[4];
+    if (oi.usesColorMap != 0) { sample_tex(D.textures[oi.colorIndex], uu, vv, tex, c); col = rtr_mk(tex[0], tex[1], tex[2]); }
+    if (oi.usesSpecularMap != 0) { sample_tex(D.textures[oi.specularIndex], uu, vv, tex, c); rough = tex[0]; }
+    if (oi.usesMetallicMap != 0) { sample_tex(D.textures[oi.metallicIndex], uu, vv, tex, c); sf.metallic = tex[0]; }
     sf.color = rtr_mk(rtr_to_linear(col.x), rtr_to_linear(col.y), rtr_to_linear(col.z)); /* :104 */
     sf.roughness = 1.0f - rough;                                                         /* :106 */
     return sf;
@@ -281,10 +338,20 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
         rtr_v3 pw = rtr_madd(rtr_madd(TL, dH, offx), dV, offy);                          /* :86-89 */
         rtr_v3 rayDir = rtr_normalize(rtr_sub(pw, camPos));                              /* :91-92 */
         Hit h = trace(sc, camPos, rayDir, 0.001f, 10000.0f, false, c);                   /* :99-107 */
-        if (!h.hit) {                                                                    /* :110-115, miss.rmiss */
-            o.analytic = rtr_add(o.analytic, sc.skyLinear);
-            o.unshadowed = rtr_add(o.unshadowed, sc.skyLinear);
-            o.shadowed = rtr_add(o.shadowed, sc.skyLinear);
+        if (!h.hit) {                                                                    /* :110-115, miss.rmiss:15-27 */
+            rtr_v3 sky = sc.skyLinear;
+            if (D.hdri) {
+                const rtr_v3 dir = rtr_normalize(rayDir);                                /* miss.rmiss:19 */
+                const float hu = rtr_atan2(dir.z, dir.x) / (2.0f * 3.14159265f) + 0.5f;  /* :20 */
+                float hv = rtr_acos(rtr_clamp(dir.y, -1.0f, 1.0f)) / 3.14159265f;        /* :21 */
+                hv = 1.0f - hv;                                                          /* :22 */
+                float tex[4];
+                sample_tex(*D.hdri, hu, hv, tex, c);                                     /* :23 */
+                sky = rtr_mk(rtr_to_linear(tex[0]), rtr_to_linear(tex[1]), rtr_to_linear(tex[2]));   /* :24 */
+            }
+            o.analytic = rtr_add(o.analytic, sky);
+            o.unshadowed = rtr_add(o.unshadowed, sky);
+            o.shadowed = rtr_add(o.shadowed, sky);
             continue;
         }
         if (h.custom < D.numLights) {                                                    /* :116-121, closesthit.rchit:46-50 */
@@ -452,6 +519,7 @@ bool prepare(const oracle_scene* s, Scene& sc) {
                 WorldTri wt;
                 wt.v0 = w[0]; wt.e1 = rtr_sub(w[1], w[0]); wt.e2 = rtr_sub(w[2], w[0]);
                 wt.custom = in.customIndex; wt.prim = t;
+                wt.flags = (in.customIndex >= D.numLights && D.objects[in.customIndex - D.numLights].usesOpacityMap != 0 && m.isOpaque == 0) ? 1u : 0u;
                 sc.brute.push_back(wt);
             }
         }
@@ -556,12 +624,14 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.numNodeVisits = tot.nodes; st.numTriTests = tot.tris; st.numHits = tot.hits;
     st.numLightFetches = tot.lightFetch; st.numLightTriFetches = tot.lightTriFetch;
     st.numShadowNodeVisits = tot.shadowNodes; st.numShadowTriTests = tot.shadowTris;
+    st.numTexFetches = tot.texFetch; st.numAlphaTests = tot.alphaTests;
     st.shadowTraceBytes = 64 * tot.shadowNodes + 48 * tot.shadowTris + 33 * tot.shadow;
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;
     k += out->normal ? 1u : 0u; k += out->position ? 1u : 0u;
-    st.algorithmicBytes = 64 * tot.nodes + 48 * tot.tris + 236 * tot.hits + 96 * tot.lightFetch + 156 * tot.lightTriFetch +
+    st.algorithmicBytes = 64 * tot.nodes + 48 * tot.tris + 236 * (tot.hits + tot.alphaTests) + 96 * tot.lightFetch + 156 * tot.lightTriFetch +
+                          16 * tot.texFetch +
                           4ull * k * st.localPixels + (out->hdr ? (prm.accumulate ? 32ull : 16ull) * st.localPixels : 0ull);
     return 0;
 }

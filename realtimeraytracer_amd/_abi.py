@@ -55,6 +55,10 @@ class RtrBvhTri(C.Structure):
     _fields_ = [("v0", f32 * 3), ("customIndex", u32), ("e1", f32 * 3), ("primitiveId", u32), ("e2", f32 * 3), ("flags", u32)]
 
 
+class rtr_texture(C.Structure):
+    _fields_ = [("pixels", C.POINTER(C.c_uint8)), ("width", u32), ("height", u32), ("channels", u32), ("_pad", u32)]
+
+
 class rtr_scene_desc(C.Structure):
     _fields_ = [("vertices", C.POINTER(RtrVertex)), ("numVertices", u32),
                 ("indices", C.POINTER(u32)), ("numIndices", u32),
@@ -63,7 +67,9 @@ class rtr_scene_desc(C.Structure):
                 ("objects", C.POINTER(RtrObjectInfo)), ("numObjects", u32),
                 ("lights", C.POINTER(RtrAreaLightInfo)), ("numLights", u32),
                 ("ltc1", C.POINTER(f32)), ("ltc2", C.POINTER(f32)),
-                ("skyColor", f32 * 3), ("_pad", f32)]
+                ("skyColor", f32 * 3), ("_pad", f32),
+                ("textures", C.POINTER(rtr_texture)), ("numTextures", u32),
+                ("hdri", C.POINTER(rtr_texture))]
 
 
 class rtr_scene_stats(C.Structure):
@@ -81,7 +87,7 @@ class rtr_render_params(C.Structure):
 class rtr_frame_stats(C.Structure):
     _fields_ = [("numRays", u64), ("numPrimaryRays", u64), ("numShadowRays", u64), ("numNodeVisits", u64),
                 ("numTriTests", u64), ("numHits", u64), ("numLightFetches", u64), ("numLightTriFetches", u64),
-                ("algorithmicBytes", u64), ("numShadowNodeVisits", u64), ("numShadowTriTests", u64), ("shadowTraceBytes", u64),
+                ("numTexFetches", u64), ("numAlphaTests", u64), ("algorithmicBytes", u64), ("numShadowNodeVisits", u64), ("numShadowTriTests", u64), ("shadowTraceBytes", u64),
                 ("totalMs", f32), ("primaryMs", f32), ("shadowGenMs", f32), ("shadowTraceMs", f32), ("resolveMs", f32),
                 ("localRows", u32), ("localPixels", u32), ("pipelineUsed", u32)]
 
@@ -160,6 +166,8 @@ RTRH_SYMBOLS = {
     "rtrh_add_obj_mtl_pair": (C.c_int, [VP, C.c_char_p, C.c_char_p]),
     "rtrh_set_ltc": (C.c_int, [VP, P(f32), P(f32)]),
     "rtrh_set_sky": (C.c_int, [VP, P(f32)]),
+    "rtrh_set_hdri": (C.c_int, [VP, C.c_char_p]),
+    "rtrh_load_image": (C.c_int, [C.c_char_p, C.c_int, P(C.c_int), P(C.c_int), VP, C.c_size_t]),
     "rtrh_build": (C.c_int, [VP]),
     "rtrh_get_desc": (C.c_int, [VP, P(rtr_scene_desc)]),
     "rtrh_object_info": (C.c_int, [VP, C.c_int, P(u32), P(u32), P(u32)]),

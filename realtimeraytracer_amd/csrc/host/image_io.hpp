@@ -1,0 +1,334 @@
+// image_io.hpp — the image decoding the reference gets from stb_image (reference src/core/file.cppm:272-311:
+// stbi_set_flip_vertically_on_load(true); stbi_load(path, &w, &h, &c, isGrayscale ? STBI_grey : STBI_rgb_alpha)).
+// Own decoders, written from the format specifications (PNG/zlib RFC 1950/1951, Radiance RGBE, Netpbm), with
+// stb_image's documented channel conversions:
+//   * to 4 channels: grey -> (g,g,g,255), grey+alpha -> (g,g,g,a), RGB -> (r,g,b,255);
+//   * to 1 channel : luma y = (77 r + 150 g + 29 b) >> 8;
+//   * .hdr -> 8 bit: c = clamp(pow(c, 1/2.2) * 255 + 0.5), alpha 255 (the reference loads its 4k HDRI this way,
+//     src/app/application.cppm:250);
+//   * 16-bit PNG samples keep their high byte.
+// JPEG and the other stb formats are not decoded: load_image throws "unsupported image format" rather than guess.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace rtr::img {
+
+struct Image {
+    int width = 0, height = 0, channels = 0;   // channels of `pixels` (1 or 4 after load_image)
+    std::vector<uint8_t> pixels;
+};
+
+namespace detail {
+
+// ---- RFC 1951 inflate (canonical Huffman, bit-serial decode) --------------------------------------------------
+struct BitReader {
+    const uint8_t* p; size_t n, pos = 0; uint64_t bitbuf = 0; int bitcnt = 0;
+    int bits(int need) {                       // need <= 16
+        uint64_t val = bitbuf;
+        while (bitcnt < need) {
+            if (pos >= n) throw std::runtime_error("PNG: truncated zlib stream");
+            val |= (uint64_t)p[pos++] << bitcnt; bitcnt += 8;
+        }
+        bitbuf = val >> need; bitcnt -= need;
+        return (int)(val & ((1ull << need) - 1ull));
+    }
+};
+struct Huffman { short count[16]; short symbol[288]; };
+inline void build(Huffman& h, const short* length, int n) {
+    for (int i = 0; i < 16; ++i) h.count[i] = 0;
+    for (int i = 0; i < n; ++i) h.count[length[i]]++;
+    short offs[16]; offs[1] = 0;
+    for (int i = 1; i < 15; ++i) offs[i + 1] = offs[i] + h.count[i];
+    for (int i = 0; i < n; ++i) if (length[i]) h.symbol[offs[length[i]]++] = (short)i;
+}
+inline int decode(BitReader& br, const Huffman& h) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= br.bits(1);
+        int count = h.count[len];
+        if (code - count < first) return h.symbol[index + (code - first)];
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    throw std::runtime_error("PNG: bad Huffman code");
+}
+inline void inflate_codes(BitReader& br, std::vector<uint8_t>& out, const Huffman& lencode, const Huffman& distcode) {
+    static const short lens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const short lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const short dists[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const short dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+        int sym = decode(br, lencode);
+        if (sym < 256) out.push_back((uint8_t)sym);
+        else if (sym == 256) return;
+        else {
+            sym -= 257;
+            if (sym >= 29) throw std::runtime_error("PNG: bad length symbol");
+            int len = lens[sym] + br.bits(lext[sym]);
+            int ds = decode(br, distcode);
+            if (ds >= 30) throw std::runtime_error("PNG: bad distance symbol");
+            size_t dist = (size_t)dists[ds] + (size_t)br.bits(dext[ds]);
+            if (dist > out.size()) throw std::runtime_error("PNG: distance too far back");
+            size_t from = out.size() - dist;
+            for (int i = 0; i < len; ++i) out.push_back(out[from + i]);
+        }
+    }
+}
+inline std::vector<uint8_t> zlib_inflate(const uint8_t* data, size_t n, size_t expect) {
+    if (n < 2 || (data[0] & 0x0f) != 8 || ((data[0] << 8 | data[1]) % 31) != 0) throw std::runtime_error("PNG: bad zlib header");
+    if (data[1] & 0x20) throw std::runtime_error("PNG: preset dictionary not allowed");
+    BitReader br{data + 2, n - 2};
+    std::vector<uint8_t> out; out.reserve(expect);
+    int last;
+    do {
+        last = br.bits(1);
+        int type = br.bits(2);
+        if (type == 0) {
+            br.bitbuf = 0; br.bitcnt = 0;
+            if (br.pos + 4 > br.n) throw std::runtime_error("PNG: truncated stored block");
+            unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) throw std::runtime_error("PNG: bad stored block");
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len); br.pos += len;
+        } else if (type == 1) {
+            short l[288]; Huffman lc, dc;
+            for (int i = 0; i < 144; ++i) l[i] = 8;
+            for (int i = 144; i < 256; ++i) l[i] = 9;
+            for (int i = 256; i < 280; ++i) l[i] = 7;
+            for (int i = 280; i < 288; ++i) l[i] = 8;
+            build(lc, l, 288);
+            for (int i = 0; i < 30; ++i) l[i] = 5;
+            build(dc, l, 30);
+            inflate_codes(br, out, lc, dc);
+        } else if (type == 2) {
+            static const short order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int nlen = br.bits(5) + 257, ndist = br.bits(5) + 1, ncode = br.bits(4) + 4;
+            if (nlen > 286 || ndist > 30) throw std::runtime_error("PNG: bad dynamic block counts");
+            short l[320]; Huffman lc, dc;
+            for (int i = 0; i < 19; ++i) l[i] = 0;
+            for (int i = 0; i < ncode; ++i) l[order[i]] = (short)br.bits(3);
+            build(lc, l, 19);
+            int idx = 0;
+            while (idx < nlen + ndist) {
+                int sym = decode(br, lc);
+                if (sym < 16) l[idx++] = (short)sym;
+                else {
+                    int rep, val = 0;
+                    if (sym == 16) { if (idx == 0) throw std::runtime_error("PNG: repeat without previous length"); val = l[idx - 1]; rep = 3 + br.bits(2); }
+                    else if (sym == 17) rep = 3 + br.bits(3);
+                    else rep = 11 + br.bits(7);
+                    if (idx + rep > nlen + ndist) throw std::runtime_error("PNG: too many code lengths");
+                    while (rep--) l[idx++] = (short)val;
+                }
+            }
+            Huffman lenc, distc;
+            build(lenc, l, nlen);
+            build(distc, l + nlen, ndist);
+            inflate_codes(br, out, lenc, distc);
+        } else throw std::runtime_error("PNG: reserved block type");
+    } while (!last);
+    return out;
+}
+
+inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+// decodes to `src_channels` (1,2,3 or 4) 8-bit samples, top row first
+inline void decode_png(const std::vector<uint8_t>& f, int& w, int& h, int& src_channels, std::vector<uint8_t>& px) {
+    size_t pos = 8;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    bool haveHdr = false;
+    while (pos + 12 <= f.size()) {
+        uint32_t len = be32(&f[pos]);
+        std::string type(reinterpret_cast<const char*>(&f[pos + 4]), 4);
+        if (pos + 12 + len > f.size()) throw std::runtime_error("PNG: truncated chunk");
+        const uint8_t* d = &f[pos + 8];
+        if (type == "IHDR") {
+            if (len != 13) throw std::runtime_error("PNG: bad IHDR");
+            w = (int)be32(d); h = (int)be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+            if (d[10] != 0 || d[11] != 0) throw std::runtime_error("PNG: unknown compression/filter method");
+            haveHdr = true;
+        } else if (type == "PLTE") plte.assign(d, d + len);
+        else if (type == "tRNS") trns.assign(d, d + len);
+        else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
+        else if (type == "IEND") break;
+        pos += 12 + len;
+    }
+    if (!haveHdr || w <= 0 || h <= 0 || w > 1 << 16 || h > 1 << 16) throw std::runtime_error("PNG: missing or bad IHDR");
+    if (interlace) throw std::runtime_error("PNG: interlaced images are not supported");
+    int samples;
+    switch (ctype) { case 0: samples = 1; break; case 2: samples = 3; break; case 3: samples = 1; break; case 4: samples = 2; break; case 6: samples = 4; break;
+                     default: throw std::runtime_error("PNG: bad colour type"); }
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) throw std::runtime_error("PNG: unsupported bit depth");
+    if (ctype == 3 && depth == 16) throw std::runtime_error("PNG: bad palette depth");
+    const size_t bitsPerPixel = (size_t)samples * depth, stride = (bitsPerPixel * w + 7) / 8, bpp = std::max<size_t>(1, bitsPerPixel / 8);
+    std::vector<uint8_t> raw = zlib_inflate(idat.data(), idat.size(), (stride + 1) * h);
+    if (raw.size() < (stride + 1) * (size_t)h) throw std::runtime_error("PNG: not enough image data");
+    std::vector<uint8_t> img(stride * h);
+    for (int y = 0; y < h; ++y) {                                   // un-filter
+        const uint8_t* in = &raw[(stride + 1) * y];
+        uint8_t* out = &img[stride * y];
+        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+        int ft = in[0]; ++in;
+        for (size_t i = 0; i < stride; ++i) {
+            int a = i >= bpp ? out[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, v;
+            switch (ft) {
+                case 0: v = in[i]; break;
+                case 1: v = in[i] + a; break;
+                case 2: v = in[i] + b; break;
+                case 3: v = in[i] + ((a + b) >> 1); break;
+                case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                          v = in[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
+                default: throw std::runtime_error("PNG: bad filter type");
+            }
+            out[i] = (uint8_t)v;
+        }
+    }
+    // expand to 8-bit samples
+    auto sample = [&](int y, size_t idx) -> int {                   // idx-th sample of row y
+        const uint8_t* row = &img[stride * y];
+        if (depth == 8) return row[idx];
+        if (depth == 16) return row[idx * 2];                       // high byte
+        size_t bit = idx * depth; int v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+        return v;
+    };
+    if (ctype == 3) {
+        src_channels = trns.empty() ? 3 : 4;
+        px.resize((size_t)w * h * src_channels);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+            int i = sample(y, x);
+            if ((size_t)i * 3 + 2 >= plte.size()) throw std::runtime_error("PNG: palette index out of range");
+            uint8_t* o = &px[((size_t)y * w + x) * src_channels];
+            o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
+            if (src_channels == 4) o[3] = (size_t)i < trns.size() ? trns[i] : 255;
+        }
+    } else {
+        src_channels = samples;
+        px.resize((size_t)w * h * samples);
+        const int scale = (ctype == 0 && depth < 8) ? 255 / ((1 << depth) - 1) : 1;
+        for (int y = 0; y < h; ++y) for (size_t i = 0; i < (size_t)w * samples; ++i) px[(size_t)y * w * samples + i] = (uint8_t)(sample(y, i) * scale);
+    }
+}
+
+inline void decode_pnm(const std::vector<uint8_t>& f, int& w, int& h, int& src_channels, std::vector<uint8_t>& px) {
+    size_t pos = 2;
+    auto next_int = [&]() {
+        for (;;) {
+            while (pos < f.size() && (f[pos] == ' ' || f[pos] == '\t' || f[pos] == '\r' || f[pos] == '\n')) ++pos;
+            if (pos < f.size() && f[pos] == '#') { while (pos < f.size() && f[pos] != '\n') ++pos; continue; }
+            break;
+        }
+        int v = 0; bool any = false;
+        while (pos < f.size() && f[pos] >= '0' && f[pos] <= '9') { v = v * 10 + (f[pos++] - '0'); any = true; }
+        if (!any) throw std::runtime_error("PNM: bad header");
+        return v;
+    };
+    src_channels = f[1] == '5' ? 1 : 3;
+    w = next_int(); h = next_int(); int maxv = next_int();
+    if (maxv != 255) throw std::runtime_error("PNM: only maxval 255 is supported");
+    ++pos;                                                          // single whitespace after maxval
+    size_t n = (size_t)w * h * src_channels;
+    if (w <= 0 || h <= 0 || pos + n > f.size()) throw std::runtime_error("PNM: truncated data");
+    px.assign(f.begin() + pos, f.begin() + pos + n);
+}
+
+// Radiance .hdr (RGBE) -> float RGB, top row first
+inline void decode_hdr(const std::vector<uint8_t>& f, int& w, int& h, std::vector<float>& rgb) {
+    size_t pos = 0;
+    auto line = [&]() { std::string s; while (pos < f.size() && f[pos] != '\n') s += (char)f[pos++]; ++pos; return s; };
+    std::string first = line();
+    if (first != "#?RADIANCE" && first != "#?RGBE") throw std::runtime_error("HDR: bad signature");
+    bool fmt = false;
+    for (;;) { std::string l = line(); if (l.empty()) break; if (l == "FORMAT=32-bit_rle_rgbe") fmt = true; if (pos >= f.size()) break; }
+    if (!fmt) throw std::runtime_error("HDR: unsupported format");
+    std::string res = line();
+    if (std::sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) throw std::runtime_error("HDR: unsupported data layout");
+    rgb.resize((size_t)w * h * 3);
+    std::vector<uint8_t> scan((size_t)w * 4);
+    auto to_float = [](const uint8_t* c, float* o) {
+        if (c[3] == 0) { o[0] = o[1] = o[2] = 0.f; return; }
+        float s = std::ldexp(1.0f, (int)c[3] - (128 + 8));
+        o[0] = c[0] * s; o[1] = c[1] * s; o[2] = c[2] * s;
+    };
+    for (int y = 0; y < h; ++y) {
+        if (pos + 4 > f.size()) throw std::runtime_error("HDR: truncated");
+        if (w >= 8 && w < 32768 && f[pos] == 2 && f[pos + 1] == 2 && !(f[pos + 2] & 0x80)) {      // new-style RLE
+            if (((int)f[pos + 2] << 8 | f[pos + 3]) != w) throw std::runtime_error("HDR: bad scanline width");
+            pos += 4;
+            for (int k = 0; k < 4; ++k) {
+                int x = 0;
+                while (x < w) {
+                    if (pos >= f.size()) throw std::runtime_error("HDR: truncated");
+                    int count = f[pos++];
+                    if (count > 128) { count -= 128; if (x + count > w || pos >= f.size()) throw std::runtime_error("HDR: bad run"); uint8_t v = f[pos++]; while (count--) scan[(size_t)(x++) * 4 + k] = v; }
+                    else { if (count == 0 || x + count > w || pos + count > f.size()) throw std::runtime_error("HDR: bad run"); while (count--) scan[(size_t)(x++) * 4 + k] = f[pos++]; }
+                }
+            }
+        } else {                                                                                  // flat RGBE
+            if (pos + (size_t)w * 4 > f.size()) throw std::runtime_error("HDR: truncated");
+            std::memcpy(scan.data(), &f[pos], (size_t)w * 4); pos += (size_t)w * 4;
+        }
+        for (int x = 0; x < w; ++x) to_float(&scan[(size_t)x * 4], &rgb[((size_t)y * w + x) * 3]);
+    }
+}
+
+inline std::vector<uint8_t> read_file(const std::string& path) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in) throw std::runtime_error("Failed to load image: " + path);
+    size_t n = (size_t)in.tellg();
+    std::vector<uint8_t> b(n);
+    in.seekg(0); in.read(reinterpret_cast<char*>(b.data()), (std::streamsize)n);
+    return b;
+}
+
+}  // namespace detail
+
+// stbi_load(path, ..., desired_channels) + optional vertical flip.  desired_channels: 1 (STBI_grey) or 4 (STBI_rgb_alpha).
+inline Image load_image(const std::string& path, int desired_channels, bool flip_vertically) {
+    if (desired_channels != 1 && desired_channels != 4) throw std::runtime_error("load_image: desired_channels must be 1 or 4");
+    std::vector<uint8_t> f = detail::read_file(path);
+    int w = 0, h = 0, sc = 0;
+    std::vector<uint8_t> px;
+    static const uint8_t pngsig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (f.size() >= 8 && std::memcmp(f.data(), pngsig, 8) == 0) detail::decode_png(f, w, h, sc, px);
+    else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) detail::decode_pnm(f, w, h, sc, px);
+    else if (f.size() >= 10 && (std::memcmp(f.data(), "#?RADIANCE", 10) == 0 || std::memcmp(f.data(), "#?RGBE", 6) == 0)) {
+        std::vector<float> rgb;
+        detail::decode_hdr(f, w, h, rgb);
+        sc = 3; px.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < px.size(); ++i) {                    // stb_image hdr -> ldr: gamma 2.2, scale 1
+            float z = std::pow(rgb[i], 1.0f / 2.2f) * 255.0f + 0.5f;
+            if (z < 0.f) z = 0.f;
+            if (z > 255.f) z = 255.f;
+            px[i] = (uint8_t)(int)z;
+        }
+    } else throw std::runtime_error("Failed to load image: " + path + " (unsupported image format: PNG, binary PGM/PPM and Radiance HDR are decoded)");
+    Image out; out.width = w; out.height = h; out.channels = desired_channels;
+    out.pixels.resize((size_t)w * h * desired_channels);
+    for (int y = 0; y < h; ++y) {
+        const int sy = flip_vertically ? h - 1 - y : y;
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* s = &px[((size_t)sy * w + x) * sc];
+            uint8_t* d = &out.pixels[((size_t)y * w + x) * desired_channels];
+            if (desired_channels == 4) {
+                if (sc == 1) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
+                else if (sc == 2) { d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; }
+                else if (sc == 3) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; }
+                else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; }
+            } else {
+                d[0] = sc <= 2 ? s[0] : (uint8_t)((s[0] * 77 + s[1] * 150 + s[2] * 29) >> 8);
+            }
+        }
+    }
+    return out;
+}
+
+}  // namespace rtr::img

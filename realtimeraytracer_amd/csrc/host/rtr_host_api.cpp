@@ -28,6 +28,7 @@ struct rtrh_scene {
     bool isBuilt = false;
     std::vector<float> ltc1, ltc2;
     rtr::vm::vec3 sky{0.f, 0.f, 0.f};
+    std::string hdriPath;
 };
 
 struct rtrh_camera { std::unique_ptr<scene::Camera> cam; };
@@ -81,12 +82,26 @@ int rtrh_add_obj_mtl_pair(rtrh_scene* s, const char* objPath, const char* mtlDir
 int rtrh_set_ltc(rtrh_scene* s, const float* ltc1, const float* ltc2) {
     return guarded([&] { s->ltc1.assign(ltc1, ltc1 + 64 * 64 * 4); s->ltc2.assign(ltc2, ltc2 + 64 * 64 * 4); });
 }
+int rtrh_set_hdri(rtrh_scene* s, const char* path) { return guarded([&] { s->hdriPath = path ? path : ""; }); }
+// decode an image exactly as core::file::createTextureImage does (flip + channel conversion); out may be NULL to query the extent
+int rtrh_load_image(const char* path, int grayscale, int* w, int* h, uint8_t* out, size_t outBytes) {
+    return guarded([&] {
+        rtr::img::Image im = core::file::createTextureImage(path, grayscale != 0);
+        if (w) *w = im.width;
+        if (h) *h = im.height;
+        if (out) {
+            if (outBytes != im.pixels.size()) throw std::runtime_error("rtrh_load_image: buffer size mismatch");
+            std::memcpy(out, im.pixels.data(), outBytes);
+        }
+    });
+}
 int rtrh_set_sky(rtrh_scene* s, const float* c) { return guarded([&] { s->sky = rtr::vm::vec3(c[0], c[1], c[2]); }); }
 
 // runs CreateScene::createSceneFromObjectsAndLights (reference application.cppm:230)
 int rtrh_build(rtrh_scene* s) {
     return guarded([&] {
         s->built = app::setup::CreateScene::createSceneFromObjectsAndLights(s->objects, s->objMtlPairs, s->lights);
+        if (!s->hdriPath.empty()) s->built.setHDRI(s->hdriPath);
         s->objMtlPairs.clear();   // their shapes are Objects now; a second build must not ingest them again
         s->isBuilt = true;
     });

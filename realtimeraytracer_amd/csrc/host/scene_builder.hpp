@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../../include/rtr.h"
+#include "image_io.hpp"
 #include "obj_loader.hpp"
 #include "scene.hpp"
 
@@ -131,6 +132,18 @@ inline void loadOBJandMTL(const std::string& objPath, const std::string& mtlPath
     }
 }
 
+// file.cppm:272-311: stb_image load with vertical flip, RGBA8 (STBI_rgb_alpha) or R8 (STBI_grey).  The decoded
+// texels are returned to the caller (who hands them to rtr_scene_create) instead of being uploaded to a vk::Image.
+inline rtr::img::Image createTextureImage(const std::string& texturePath, bool isGrayscale) {
+    try {
+        return rtr::img::load_image(texturePath, isGrayscale ? 1 : 4, /*flip_vertically=*/true);
+    } catch (const std::exception& e) {
+        std::cerr << "Failed to load image: " << texturePath << "\n";
+        std::cerr << "Reason: " << e.what() << "\n";
+        throw std::runtime_error("Image load failed");
+    }
+}
+
 }  // namespace core::file
 
 namespace app::setup {
@@ -217,6 +230,19 @@ struct SceneReturnInfo {
     std::vector<scene::Object::GPUObjectInfo> GPUObjects;
     std::vector<scene::AreaLight::GPUAreaLightInfo> GPUAreaLights;
     GeometryReturnInfo geoReturnInfo;
+    std::vector<rtr::img::Image> textures;        // [0], [1] stay empty: the LTC tables live there in the reference (create_scene.cppm:67-69)
+    std::vector<rtr_texture> textureTable;        // C-ABI view of `textures`
+    rtr::img::Image hdriImage;                    // application.cppm:250 (optional)
+    rtr_texture hdriEntry{};
+    void setHDRI(const std::string& path) {
+        hdriImage = core::file::createTextureImage(path, false);
+        hdriEntry = rtr_texture{hdriImage.pixels.data(), (uint32_t)hdriImage.width, (uint32_t)hdriImage.height, 4u, 0u};
+    }
+    void rebuildTextureTable() {
+        textureTable.clear();
+        for (const auto& im : textures)
+            textureTable.push_back(rtr_texture{im.pixels.empty() ? nullptr : im.pixels.data(), (uint32_t)im.width, (uint32_t)im.height, (uint32_t)im.channels, 0u});
+    }
     // fills the C-ABI descriptor; pointers stay valid while this object lives
     rtr_scene_desc desc(const float* ltc1 = nullptr, const float* ltc2 = nullptr, vm::vec3 sky = vm::vec3(0.f)) const {
         rtr_scene_desc d{};
@@ -230,19 +256,38 @@ struct SceneReturnInfo {
         d.lights = GPUAreaLights.data(); d.numLights = (uint32_t)GPUAreaLights.size();
         d.ltc1 = ltc1; d.ltc2 = ltc2;
         d.skyColor[0] = sky.x; d.skyColor[1] = sky.y; d.skyColor[2] = sky.z;
+        d.textures = textureTable.empty() ? nullptr : textureTable.data();
+        d.numTextures = (uint32_t)textureTable.size();
+        d.hdri = hdriImage.pixels.empty() ? nullptr : &hdriEntry;
         return d;
     }
 };
 
 class CreateScene {
 public:
-    // create_scene.cppm:48-160 without the texture half (objects that name texture maps keep their
-    // uses*Map flags; rtr_scene_create then refuses them loudly until the texture row is built).
+    // create_scene.cppm:48-160: geometry, then material textures (path-keyed de-dup, specular -> metallic -> colour ->
+    // opacity per object, specular/metallic as R8, colour/opacity as RGBA8, indices starting at 2), then the info arrays.
     static SceneReturnInfo createSceneFromObjectsAndLights(std::vector<std::shared_ptr<scene::Object>>& objects,
                                                            const std::vector<std::pair<std::string, std::string>>& objMtlPairs,
                                                            std::vector<std::shared_ptr<scene::AreaLight>>& areaLights) {
         SceneReturnInfo r;
         r.geoReturnInfo = GeometryBuilder::createAccelerationStructures(objects, objMtlPairs, areaLights);
+        r.textures.resize(2);                                                           // LTC1, LTC2 slots (:67-69)
+        std::unordered_map<std::string, int> loadedTextures;                            // :71
+        auto useTexture = [&](const std::string& path, bool gray) -> uint32_t {
+            auto it = loadedTextures.find(path);
+            if (it != loadedTextures.end()) return (uint32_t)it->second;
+            r.textures.push_back(core::file::createTextureImage(path, gray));
+            loadedTextures[path] = (int)r.textures.size() - 1;
+            return (uint32_t)r.textures.size() - 1;
+        };
+        for (auto& object : objects) {                                                  // :75-136
+            if (object->usesSpecularMap()) object->setSpecularMapIndex(useTexture(object->getSpecularPath(), true));
+            if (object->usesMetallicMap()) object->setMetallicMapIndex(useTexture(object->getMetallicPath(), true));
+            if (object->usesColorMap()) object->setColorMapIndex(useTexture(object->getColorPath(), false));
+            if (object->usesOpacityMap()) object->setOpacityMapIndex(useTexture(object->getOpacityPath(), false));
+        }
+        r.rebuildTextureTable();
         for (auto& light : areaLights) r.GPUAreaLights.push_back(light->getGPUInfo());   // after TLAS: offsets are set there
         for (auto& object : objects) r.GPUObjects.push_back(object->getGPUInfo());
         return r;

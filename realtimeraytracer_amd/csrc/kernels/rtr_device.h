@@ -22,6 +22,8 @@
 
 namespace rtrdev {
 
+struct DeviceTexture { const uint8_t* pixels; uint32_t width, height, channels, _pad; };
+
 struct DeviceScene {
     const float4* nodes;             /* RtrBvhNode as 4 x float4 */
     const float4* tris;              /* RtrBvhTri  as 3 x float4 */
@@ -35,16 +37,20 @@ struct DeviceScene {
     const float* ltc2;
     float skyLinear[3];
     uint32_t numLights;
+    const DeviceTexture* textures;   /* texSamplers[]: indexed by ObjectInfo.*Index (slots 0,1 unused: LTC) */
+    DeviceTexture hdri;              /* pixels == null -> constant sky */
 };
 
 struct Counters {                    /* device mirror of rtr_frame_stats' counters */
-    unsigned long long rays, primary, shadow, nodes, tris, hits, lightFetch, lightTriFetch, shadowNodes, shadowTris;
+    unsigned long long rays, primary, shadow, nodes, tris, hits, lightFetch, lightTriFetch, shadowNodes, shadowTris, texFetch, alphaTests;
 };
 
 struct LocalStats {
     uint32_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
-    uint32_t shadowNodes = 0, shadowTris = 0;
+    uint32_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0;
     __device__ void flush(Counters* c) const {
+        if (texFetch) atomicAdd(&c->texFetch, (unsigned long long)texFetch);
+        if (alphaTests) atomicAdd(&c->alphaTests, (unsigned long long)alphaTests);
         if (shadowNodes) atomicAdd(&c->shadowNodes, (unsigned long long)shadowNodes);
         if (shadowTris) atomicAdd(&c->shadowTris, (unsigned long long)shadowTris);
         if (rays) atomicAdd(&c->rays, (unsigned long long)rays);
@@ -62,6 +68,67 @@ struct HitRec { float t, u, v; uint32_t custom, prim; };   /* custom == 0xffffff
 #define RTR_MISS 0xffffffffu
 
 __device__ __forceinline__ rtr_v3 f4xyz(const float4& a) { return rtr_mk(a.x, a.y, a.z); }
+
+/* texture(): 8-bit texels, linear filter, repeat addressing, one mip — the reference's sampler
+ * (src/vulkan/memory/image_sampler.cppm:26-42) in software; same arithmetic as oracle sample_tex(). */
+template <bool STATS>
+__device__ __forceinline__ float4 sample_tex(const DeviceTexture& tx, float u, float v, LocalStats& st) {
+    if (STATS) st.texFetch++;
+    if (!(u > -1.0e9f && u < 1.0e9f)) u = 0.0f;
+    if (!(v > -1.0e9f && v < 1.0e9f)) v = 0.0f;
+    const int W = (int)tx.width, H = (int)tx.height, ch = (int)tx.channels;
+    const float uf = u - __builtin_floorf(u), vf = v - __builtin_floorf(v);
+    const float x = rtr_fma(uf, (float)W, -0.5f), y = rtr_fma(vf, (float)H, -0.5f);
+    const float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    if (x0 < 0) x0 += W;
+    if (x0 >= W) x0 -= W;
+    if (y0 < 0) y0 += H;
+    if (y0 >= H) y0 -= H;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    if (x1 >= W) x1 -= W;
+    if (y1 >= H) y1 -= H;
+    const uint8_t* p = tx.pixels;
+    float o[4];
+    if (ch == 4) {
+        const uint32_t q00 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y0 * W + x0) * 4);
+        const uint32_t q10 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y0 * W + x1) * 4);
+        const uint32_t q01 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y1 * W + x0) * 4);
+        const uint32_t q11 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y1 * W + x1) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t00 = (float)((q00 >> (8 * k)) & 0xffu) / 255.0f, t10 = (float)((q10 >> (8 * k)) & 0xffu) / 255.0f;
+            const float t01 = (float)((q01 >> (8 * k)) & 0xffu) / 255.0f, t11 = (float)((q11 >> (8 * k)) & 0xffu) / 255.0f;
+            const float a = rtr_fma(t10 - t00, fx, t00), b = rtr_fma(t11 - t01, fx, t01);
+            o[k] = rtr_fma(b - a, fy, a);
+        }
+    } else {
+        const float t00 = (float)p[(size_t)y0 * W + x0] / 255.0f, t10 = (float)p[(size_t)y0 * W + x1] / 255.0f;
+        const float t01 = (float)p[(size_t)y1 * W + x0] / 255.0f, t11 = (float)p[(size_t)y1 * W + x1] / 255.0f;
+        const float a = rtr_fma(t10 - t00, fx, t00), b = rtr_fma(t11 - t01, fx, t01);
+        o[0] = rtr_fma(b - a, fy, a); o[1] = 0.0f; o[2] = 0.0f; o[3] = 1.0f;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+/* opacity.rahit:31-64 — any-hit for candidates on alpha-tested geometry; false = ignoreIntersectionEXT */
+template <bool STATS>
+__device__ __forceinline__ bool alpha_pass(const DeviceScene& sc, uint32_t custom, uint32_t prim, float bu, float bv, LocalStats& st) {
+    const RtrObjectInfo* oi = sc.objects + (custom - sc.numLights);
+    if (oi->usesOpacityMap == 0u) return true;
+    if (STATS) st.alphaTests++;
+    const uint32_t vOff = oi->vertexOffset, iOff = oi->indexOffset;
+    const uint32_t i0 = sc.indices[3u * prim + 0u + iOff], i1 = sc.indices[3u * prim + 1u + iOff], i2 = sc.indices[3u * prim + 2u + iOff];
+    const float* uv0 = sc.vertices[i0 + vOff].uv;
+    const float* uv1 = sc.vertices[i1 + vOff].uv;
+    const float* uv2 = sc.vertices[i2 + vOff].uv;
+    const float b0 = 1.0f - bu - bv;
+    const float uu = rtr_fma(uv2[0], bv, rtr_fma(uv1[0], bu, uv0[0] * b0));
+    const float vv = rtr_fma(uv2[1], bv, rtr_fma(uv1[1], bu, uv0[1] * b0));
+    const float4 t = sample_tex<STATS>(sc.textures[oi->opacityIndex], uu, vv, st);
+    return !(t.x < 0.9f);
+}
 
 /* ------------------------------------------------------------------------------------------
  * BVH traversal.  Restates, operation for operation, the algorithm of oracle/oracle_render.cpp
@@ -113,6 +180,7 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
                 if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v)) {
                     if (t < tmax) {
                         const uint32_t cu = __float_as_uint(q0.w), pr = __float_as_uint(q1.w);
+                        if ((__float_as_uint(q2.w) & 1u) && !alpha_pass<STATS>(sc, cu, pr, u, v, st)) continue;
                         bool take;
                         if (!found) take = true;
                         else take = t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)));
@@ -264,9 +332,17 @@ template <class Policy, bool STATS>
 __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
                                              const HitRec& h, rtr_v3 rayDir, bool wantAnalytic, Accum& o,
                                              Policy& pol, LocalStats& st) {
-    if (h.custom == RTR_MISS) {                                                           /* :110-115 */
+    if (h.custom == RTR_MISS) {                                                           /* :110-115, miss.rmiss:15-27 */
         if (Policy::kShade) {
-            const rtr_v3 sky = rtr_ld3(sc.skyLinear);
+            rtr_v3 sky = rtr_ld3(sc.skyLinear);
+            if (sc.hdri.pixels) {
+                const rtr_v3 dir = rtr_normalize(rayDir);
+                const float hu = rtr_atan2(dir.z, dir.x) / (2.0f * 3.14159265f) + 0.5f;
+                float hv = rtr_acos(rtr_clamp(dir.y, -1.0f, 1.0f)) / 3.14159265f;
+                hv = 1.0f - hv;
+                const float4 tx = sample_tex<STATS>(sc.hdri, hu, hv, st);
+                sky = rtr_mk(rtr_to_linear(tx.x), rtr_to_linear(tx.y), rtr_to_linear(tx.z));
+            }
             o.analytic = rtr_add(o.analytic, sky); o.unshadowed = rtr_add(o.unshadowed, sky); o.shadowed = rtr_add(o.shadowed, sky);
         }
         return;
@@ -305,10 +381,22 @@ __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const Render
         if (rtr_dot(n, rayDir) > 0.0f) n = rtr_neg(n);
         hitNormal = n;
     }
-    const float metallic = oi->metallic;
-    const float roughness = 1.0f - oi->specular;
+    float metallic = oi->metallic;
+    float rough = oi->specular;
     rtr_v3 color = rtr_mk(0, 0, 0);
-    if (Policy::kShade) color = rtr_mk(rtr_to_linear(oi->color[0]), rtr_to_linear(oi->color[1]), rtr_to_linear(oi->color[2]));
+    if (Policy::kShade) {
+        rtr_v3 col = rtr_ld3(oi->color);
+        if (oi->usesColorMap | oi->usesSpecularMap | oi->usesMetallicMap) {
+            const float4 ta = va[2], tb = vb[2], tc = vc[2];                             /* uv in floats 8,9 of the 48-B vertex */
+            const float uu = rtr_fma(tc.x, b2, rtr_fma(tb.x, b1, ta.x * b0));
+            const float vv = rtr_fma(tc.y, b2, rtr_fma(tb.y, b1, ta.y * b0));
+            if (oi->usesColorMap != 0u) { const float4 t = sample_tex<STATS>(sc.textures[oi->colorIndex], uu, vv, st); col = rtr_mk(t.x, t.y, t.z); }
+            if (oi->usesSpecularMap != 0u) rough = sample_tex<STATS>(sc.textures[oi->specularIndex], uu, vv, st).x;
+            if (oi->usesMetallicMap != 0u) metallic = sample_tex<STATS>(sc.textures[oi->metallicIndex], uu, vv, st).x;
+        }
+        color = rtr_mk(rtr_to_linear(col.x), rtr_to_linear(col.y), rtr_to_linear(col.z));
+    }
+    const float roughness = 1.0f - rough;
 
     const rtr_v3 viewDir = rtr_normalize(rtr_sub(camPos, hitPoint));
     const float om = 1.0f - metallic;

@@ -274,7 +274,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                 if (STATS) { st.tris++; st.shadowTris++; }
                 float t, u, v;
-                if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v)) hit = t < tmax;
+                if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v) && t < tmax) {
+                    hit = true;
+                    if (__float_as_uint(q2.w) & 1u)      /* opacity.rahit on alpha-tested geometry */
+                        hit = alpha_pass<STATS>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
+                }
             }
             if (hit) { vis[slot] = 1; cur = kDone; }
             else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }

@@ -80,6 +80,9 @@ struct rtr_scene {
     DevBuf<RtrObjectInfo> objects;
     DevBuf<RtrAreaLightInfo> lights;
     DevBuf<float> xforms, nmats, ltc1, ltc2;
+    std::vector<DevBuf<uint8_t>> texPixels;
+    DevBuf<uint8_t> hdriPixels;
+    DevBuf<rtrdev::DeviceTexture> texTable;
     std::vector<RtrBvhNode> hostNodes;
     std::vector<RtrBvhTri> hostTris;
     std::vector<RtrAreaLightInfo> hostLights;
@@ -209,10 +212,19 @@ static int validate_desc(const rtr_scene_desc* d) {
                 return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: non-finite transform", i);
     }
     if (d->numLights > d->numInstances) return fail(RTR_ERR_INVALID_ARGUMENT, "numLights %u > numInstances %u (lights are the first instances)", d->numLights, d->numInstances);
+    if (d->numTextures && !d->textures) return fail(RTR_ERR_INVALID_ARGUMENT, "scene desc: null texture array with non-zero count");
+    auto tex_ok = [&](const rtr_texture& t) { return t.pixels && t.width > 0 && t.height > 0 && t.width <= 65536 && t.height <= 65536 && (t.channels == 1 || t.channels == 4); };
+    for (uint32_t t = 0; t < d->numTextures; ++t)
+        if (d->textures[t].pixels && !tex_ok(d->textures[t])) return fail(RTR_ERR_INVALID_ARGUMENT, "texture %u: bad extent %ux%u or channels %u (1 or 4)", t, d->textures[t].width, d->textures[t].height, d->textures[t].channels);
+    if (d->hdri && !tex_ok(*d->hdri)) return fail(RTR_ERR_INVALID_ARGUMENT, "hdri: bad extent or channels");
     for (uint32_t o = 0; o < d->numObjects; ++o) {
         const RtrObjectInfo& oi = d->objects[o];
-        if (oi.usesColorMap || oi.usesSpecularMap || oi.usesMetallicMap || oi.usesOpacityMap)
-            return fail(RTR_ERR_UNSUPPORTED, "object %u uses a texture map; textures are a 'next' row of SURVEY §8f and not built yet", o);
+        const struct { uint32_t uses, index; const char* what; } maps[4] = {{oi.usesColorMap, oi.colorIndex, "color"}, {oi.usesSpecularMap, oi.specularIndex, "specular"},
+                                                                            {oi.usesMetallicMap, oi.metallicIndex, "metallic"}, {oi.usesOpacityMap, oi.opacityIndex, "opacity"}};
+        for (const auto& m : maps)
+            if (m.uses && (m.index >= d->numTextures || !d->textures[m.index].pixels))
+                return fail(RTR_ERR_INVALID_ARGUMENT, "object %u uses a %s map but texture index %u is not in the texture array (%u entries); "
+                            "the library never substitutes a constant for a missing texture", o, m.what, m.index, d->numTextures);
     }
     for (uint32_t l = 0; l < d->numLights; ++l) {
         const RtrAreaLightInfo& li = d->lights[l];
@@ -246,7 +258,9 @@ static int flatten_and_build(const rtr_scene_desc* d, rtr::BvhResult& bvh, std::
                 const rtr_v3 p = rtr_xform_point34(in.transform, rtr_ld3(d->vertices[idx].position));
                 w.v[k][0] = p.x; w.v[k][1] = p.y; w.v[k][2] = p.z;
             }
-            w.customIndex = in.customIndex; w.primitiveId = t; w.flags = 0;
+            w.customIndex = in.customIndex; w.primitiveId = t;
+            /* any-hit (opacity.rahit) runs only on non-opaque geometry (blas.cppm:98-100) of objects with an opacity map */
+            w.flags = (in.customIndex >= d->numLights && d->objects[in.customIndex - d->numLights].usesOpacityMap != 0 && me.isOpaque == 0) ? 1u : 0u;
             soup.push_back(w);
         }
     }
@@ -320,6 +334,21 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
         chk(s->ltc2.upload(d->ltc2, 64 * 64 * 4, st));
         s->hasLtc = true;
     }
+    std::vector<rtrdev::DeviceTexture> table(d->numTextures);
+    s->texPixels.resize(d->numTextures);
+    for (uint32_t t = 0; t < d->numTextures; ++t) {
+        const rtr_texture& tx = d->textures[t];
+        table[t] = rtrdev::DeviceTexture{nullptr, 0, 0, 0, 0};
+        if (!tx.pixels) continue;
+        chk(s->texPixels[t].upload(tx.pixels, (size_t)tx.width * tx.height * tx.channels, st));
+        table[t] = rtrdev::DeviceTexture{s->texPixels[t].p, tx.width, tx.height, tx.channels, 0};
+    }
+    chk(s->texTable.upload(table.data(), table.size(), st));
+    rtrdev::DeviceTexture hdri{nullptr, 0, 0, 0, 0};
+    if (d->hdri) {
+        chk(s->hdriPixels.upload(d->hdri->pixels, (size_t)d->hdri->width * d->hdri->height * d->hdri->channels, st));
+        hdri = rtrdev::DeviceTexture{s->hdriPixels.p, d->hdri->width, d->hdri->height, d->hdri->channels, 0};
+    }
     if (e != hipSuccess) {
         delete s;
         return fail(e == hipErrorOutOfMemory ? RTR_ERR_OUT_OF_MEMORY : RTR_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
@@ -338,6 +367,8 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     dv.ltc1 = s->hasLtc ? s->ltc1.p : nullptr; dv.ltc2 = s->hasLtc ? s->ltc2.p : nullptr;
     for (int k = 0; k < 3; ++k) dv.skyLinear[k] = rtr_to_linear(d->skyColor[k]);
     dv.numLights = d->numLights;
+    dv.textures = s->texTable.p;
+    dv.hdri = hdri;
     *out = s;
     return RTR_OK;
 }
@@ -568,8 +599,10 @@ int rtr_frame_wait(rtr_frame* f) {
         s.numNodeVisits = h.nodes; s.numTriTests = h.tris; s.numHits = h.hits;
         s.numLightFetches = h.lightFetch; s.numLightTriFetches = h.lightTriFetch;
         s.numShadowNodeVisits = h.shadowNodes; s.numShadowTriTests = h.shadowTris;
+        s.numTexFetches = h.texFetch; s.numAlphaTests = h.alphaTests;
         s.shadowTraceBytes = 64ull * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
-        s.algorithmicBytes = 64ull * h.nodes + 48ull * h.tris + 236ull * h.hits + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
+        s.algorithmicBytes = 64ull * h.nodes + 48ull * h.tris + 236ull * (h.hits + h.alphaTests) + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
+                             16ull * h.texFetch +
                              4ull * f->pendingImagesK * s.localPixels + (f->pendingHdr ? (f->pendingAccum ? 32ull : 16ull) * s.localPixels : 0ull);
     }
     return RTR_OK;

@@ -155,6 +155,10 @@ class HostScene:
         assert a.size == 64 * 64 * 4 and b.size == 64 * 64 * 4
         _chk(self.lib.rtrh_set_ltc(self.h, a.ctypes.data_as(C.POINTER(A.f32)), b.ctypes.data_as(C.POINTER(A.f32))), "setLTC")
 
+    def setHDRI(self, path):
+        """equirect sky image (reference application.cppm:250: createTextureImage(sky4k.hdr, false))"""
+        _chk(self.lib.rtrh_set_hdri(self.h, path.encode() if path else None), "setHDRI")
+
     def setSky(self, c):
         _chk(self.lib.rtrh_set_sky(self.h, _v3(c)), "setSky")
 
@@ -207,6 +211,17 @@ class HostScene:
                 self.h = None
         except Exception:
             pass
+
+
+def load_image(path, grayscale=False):
+    """core::file::createTextureImage's decode (reference file.cppm:272-291): flipped, RGBA8 or R8 numpy array."""
+    lib = A.host_lib()
+    w, h = C.c_int(), C.c_int()
+    _chk(lib.rtrh_load_image(path.encode(), int(grayscale), C.byref(w), C.byref(h), None, 0), "load_image")
+    ch = 1 if grayscale else 4
+    out = np.empty((h.value, w.value, ch), np.uint8)
+    _chk(lib.rtrh_load_image(path.encode(), int(grayscale), None, None, out.ctypes.data_as(A.VP), out.nbytes), "load_image")
+    return out
 
 
 def scene_info(frame, num_lights, cam_position):

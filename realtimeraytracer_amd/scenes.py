@@ -424,3 +424,166 @@ def file_sha256(path):
         for chunk in iter(lambda: f.read(1 << 20), b""):
             h.update(chunk)
     return h.hexdigest()
+
+
+# ---------------------------------------------------------------------------------------------
+# Image writers for the synthetic textures (PNG via zlib, binary PGM/PPM, Radiance HDR) and a textured scene
+# ---------------------------------------------------------------------------------------------
+def write_png(path, arr, level=6):
+    """arr: uint8 (H,W) grey, (H,W,2) grey+alpha, (H,W,3) RGB or (H,W,4) RGBA.  Filter type 0..4 cycles per row so the
+    decoder's un-filter paths are all exercised."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(arr, np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    raw = bytearray()
+    prev = np.zeros((w * c,), np.int32)
+    for y in range(h):
+        row = a[y].reshape(-1).astype(np.int32)
+        ft = y % 5
+        left = np.concatenate([np.zeros(c, np.int32), row[:-c]])
+        upleft = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+        if ft == 0:
+            enc = row
+        elif ft == 1:
+            enc = row - left
+        elif ft == 2:
+            enc = row - prev
+        elif ft == 3:
+            enc = row - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            enc = row - pred
+        raw.append(ft)
+        raw += (enc & 0xff).astype(np.uint8).tobytes()
+        prev = row
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)))
+        comp = zlib.compress(bytes(raw), level)
+        half = len(comp) // 2                       # two IDAT chunks: the decoder must concatenate them
+        f.write(chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b""))
+
+
+def write_pnm(path, arr):
+    a = np.ascontiguousarray(arr, np.uint8)
+    h, w = a.shape[:2]
+    with open(path, "wb") as f:
+        f.write((b"P5" if a.ndim == 2 else b"P6") + b"\n# synthetic\n%d %d\n255\n" % (w, h) + a.tobytes())
+
+
+def write_hdr(path, rgb, rle=True):
+    """rgb: float32 (H,W,3) -> Radiance RGBE (new-style RLE scanlines when rle and 8 <= W < 32768)."""
+    rgb = np.asarray(rgb, np.float32)
+    h, w, _ = rgb.shape
+    m = rgb.max(axis=2)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(np.int32)
+    scale = np.where(m > 1e-32, np.ldexp(1.0, 8 - e), 0.0).astype(np.float32)
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\n# synthetic sky\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for y in range(h):
+            if rle and 8 <= w < 32768:
+                f.write(bytes([2, 2, w >> 8, w & 255]))
+                for k in range(4):
+                    ch = rgbe[y, :, k]
+                    x = 0
+                    while x < w:
+                        run = 1
+                        while x + run < w and run < 127 and ch[x + run] == ch[x]:
+                            run += 1
+                        if run >= 4:
+                            f.write(bytes([128 + run, int(ch[x])]))
+                            x += run
+                        else:
+                            n = 0
+                            start = x
+                            while x < w and n < 128:
+                                if x + 3 < w and ch[x] == ch[x + 1] == ch[x + 2] == ch[x + 3]:
+                                    break
+                                x += 1
+                                n += 1
+                            if n == 0:
+                                n, x = 1, x + 1
+                            f.write(bytes([n]) + ch[start:start + n].tobytes())
+            else:
+                f.write(rgbe[y].tobytes())
+    return rgbe
+
+
+def write_textured_room(directory=None):
+    """A small room whose materials exercise every texture path of the reference: map_Kd (RGB PNG), map_Ks (PGM, read
+    as R8), map_Pm (grey PNG), map_d (RGBA PNG alpha cut-out, any-hit), tiled uvs (repeat addressing), plus an .hdr sky."""
+    d = directory or _cache_dir()
+    obj = os.path.join(d, "textured_room.obj")
+    tdir = os.path.join(d, "room_tex")
+    os.makedirs(tdir, exist_ok=True)
+    yy, xx = np.mgrid[0:64, 0:64]
+    checker = (((xx // 8) + (yy // 8)) % 2).astype(np.uint8)
+    albedo = np.stack([60 + 180 * checker, 200 - 120 * checker + (xx * 0.5).astype(np.uint8), 80 + (yy * 2).astype(np.uint8)], -1).astype(np.uint8)
+    write_png(os.path.join(tdir, "albedo.png"), albedo)
+    write_pnm(os.path.join(tdir, "spec.pgm"), (40 + 3 * ((xx + yy) % 64)).astype(np.uint8))
+    write_png(os.path.join(tdir, "metal.png"), (255 * ((xx // 16 + yy // 16) % 2)).astype(np.uint8))
+    leaf = np.zeros((96, 96, 4), np.uint8)
+    ly, lx = np.mgrid[0:96, 0:96]
+    holes = (((lx - 48) ** 2 + (ly - 48) ** 2) < 30 ** 2) & ((((lx // 6) + (ly // 6)) % 3) != 0)
+    leaf[..., 0] = np.where(holes, 255, 40)            # opacity.rahit reads .r: >= 0.9 keeps the hit
+    leaf[..., 1] = 180
+    leaf[..., 2] = 60
+    leaf[..., 3] = np.where(holes, 255, 0)
+    write_png(os.path.join(tdir, "leaf_alpha.png"), leaf)
+    brick = np.stack([150 + 60 * ((yy // 8) % 2), 70 + 20 * ((xx // 16) % 2), 50 + 0 * xx], -1).astype(np.uint8)
+    write_png(os.path.join(tdir, "brick.png"), brick)
+    hy, hx = np.mgrid[0:64, 0:128]
+    sky = np.stack([0.3 + 0.5 * hx / 128.0 + 0 * hy, 0.5 + 0.3 * np.sin(hy / 10.0), 0.9 - 0.4 * hy / 64.0], -1).astype(np.float32)
+    sky[10:14, 30:40] = 12.0                           # a bright "sun" patch: exercises the > 1 clamp of hdr -> ldr
+    write_hdr(os.path.join(d, "room_sky.hdr"), sky)
+    with open(os.path.join(d, "textured_room.mtl"), "w") as f:
+        f.write("newmtl floor\nKd 1 1 1\nKs 0.2 0.2 0.2\nmap_Kd room_tex/albedo.png\nmap_Ks room_tex/spec.pgm\n\n")
+        f.write("newmtl wall\nKd 1 1 1\nKs 0.1 0.1 0.1\nmap_Kd room_tex/brick.png\n\n")
+        f.write("newmtl panel\nKd 0.9 0.9 0.9\nKs 0.7 0.7 0.7\nmap_Pm room_tex/metal.png\n\n")
+        f.write("newmtl leaf\nKd 0.2 0.8 0.3\nKs 0.1 0.1 0.1\nmap_Kd room_tex/leaf_alpha.png\nmap_d room_tex/leaf_alpha.png\n\n")
+        f.write("newmtl plain\nKd 0.7 0.7 0.75\nKs 0.3 0.3 0.3\nmetallic 0.5\n\n")
+
+    def quad(name, mtl, p, uv):
+        s = "o %s\nusemtl %s\n" % (name, mtl)
+        s += "".join("v %r %r %r\n" % tuple(float(c) for c in q) for q in p)
+        s += "".join("vt %r %r\n" % tuple(float(c) for c in t) for t in uv)
+        s += "vn 0 1 0\nf -4/-4/-1 -3/-3/-1 -2/-2/-1\nf -4/-4/-1 -2/-2/-1 -1/-1/-1\n"
+        return s
+    o = ["mtllib textured_room.mtl\n"]
+    o.append(quad("floor", "floor", [(-300, 0, -300), (-300, 0, 300), (300, 0, 300), (300, 0, -300)], [(0, 0), (0, 3), (3, 3), (3, 0)]))          # tiled 3x
+    o.append(quad("back", "wall", [(-300, 0, 300), (-300, 300, 300), (300, 300, 300), (300, 0, 300)], [(-1, 0), (-1, 2.5), (1.5, 2.5), (1.5, 0)]))  # negative uvs
+    o.append(quad("panel", "panel", [(-250, 20, 100), (-250, 220, 100), (-60, 220, 180), (-60, 20, 180)], [(0, 0), (0, 1), (1, 1), (1, 0)]))
+    o.append(quad("leaf_near", "leaf", [(40, 10, -60), (40, 210, -60), (240, 210, -60), (240, 10, -60)], [(0, 0), (0, 1), (1, 1), (1, 0)]))
+    o.append(quad("leaf_far", "leaf", [(90, 10, 40), (90, 230, 40), (290, 230, 40), (290, 10, 40)], [(0, 0), (0, 2), (2, 2), (2, 0)]))
+    o.append(quad("block", "plain", [(-80, 0.5, -120), (-80, 0.5, -20), (20, 0.5, -20), (20, 0.5, -120)], [(0, 0), (0, 1), (1, 1), (1, 0)]))
+    with open(obj, "w") as f:
+        f.write("".join(o))
+    return obj, d + "/", os.path.join(d, "room_sky.hdr")
+
+
+def textured_room(width=320, height=200, directory=None, ltc=None, hdri=True):
+    obj, mtldir, sky = write_textured_room(directory)
+    hs = host.HostScene()
+    light = hs.addAreaLight(4.0, (1.0, 0.95, 0.85), True)
+    light.move((0.0, 280.0, -50.0)).scale((250.0, 200.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    hs.addObjMtlPair(obj, mtldir)
+    hs.setSky((0.4, 0.5, 0.8))
+    if hdri:
+        hs.setHDRI(sky)
+    if ltc is not None:
+        hs.setLTC(*ltc)
+    hs.build()
+    pos = (0.0, 160.0, -420.0)
+    cam = host.Camera(55.0, pos, (0.0, 110.0, 0.0), (0.0, 1.0, 0.0), width, height)
+    return SceneSetup("textured_room", hs, cam, pos, width, height)

@@ -93,16 +93,22 @@ def test_model_dedup_across_instances(scene_cache):
     assert hs.desc.numIndices == 108
 
 
-def test_texture_named_objects_are_refused_loudly(scene_cache):
-    """Textures are a 'next' row: the product must say so, not render something else."""
+def test_missing_textures_are_refused_loudly(scene_cache):
+    """A texture the host cannot load, or an ObjectInfo that names a texture the caller did not supply, is an error —
+    the library never substitutes a constant."""
+    import ctypes as C
     obj, _ = scenes.write_cornell(scene_cache)
     hs = host.HostScene()
     o = hs.addObject(obj)
-    o.setColor("some/texture.png")
-    hs.build()
-    assert hs.objectInfos()[0].usesColorMap == 1
+    o.setColor("some/missing_texture.png")
+    with pytest.raises(host.HostError):                  # createTextureImage: "Image load failed" (file.cppm:282-286)
+        hs.build()
+    s = scenes.cornell_box(32, 32)
+    d = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc))
+    objs = (A.RtrObjectInfo * d.numObjects)(*[s.desc.objects[i] for i in range(d.numObjects)])
+    objs[2].usesColorMap, objs[2].colorIndex = 1, 7
+    d.objects = C.cast(objs, C.POINTER(A.RtrObjectInfo))
     lib = A.hip_lib()
     st = A.rtr_scene_stats()
-    import ctypes as C
-    rc = lib.rtr_host_build_bvh(C.byref(hs.desc), C.byref(st), None, 0, None, 0)
-    assert rc == -4 and b"texture" in lib.rtr_last_error()
+    rc = lib.rtr_host_build_bvh(C.byref(d), C.byref(st), None, 0, None, 0)
+    assert rc == -1 and b"texture index 7" in lib.rtr_last_error()

@@ -1,0 +1,119 @@
+"""Image decoding of the host layer (csrc/host/image_io.hpp): what the reference gets from stb_image in
+core::file::createTextureImage (src/core/file.cppm:272-311) — vertical flip + STBI_grey / STBI_rgb_alpha conversion."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from realtimeraytracer_amd import host, scenes
+
+
+def _rng_img(h, w, c, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    a[: h // 2, : w // 2] = a[0, 0]            # some flat areas so LZ77 matches + long Huffman runs occur
+    return a
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("level", [0, 1, 9])      # stored blocks, fixed/dynamic Huffman
+def test_png_roundtrip_all_colour_types(tmp_path, c, level):
+    a = _rng_img(37, 53, c, 10 * c + level)
+    p = str(tmp_path / f"t{c}_{level}.png")
+    scenes.write_png(p, a if c > 1 else a[:, :, 0], level=level)
+    rgba = host.load_image(p, grayscale=False)
+    grey = host.load_image(p, grayscale=True)
+    src = a[::-1]                                   # stbi_set_flip_vertically_on_load(true)
+    if c == 1:
+        exp = np.concatenate([src.repeat(3, 2), np.full((37, 53, 1), 255, np.uint8)], 2)
+        expg = src[:, :, :1]
+    elif c == 2:
+        exp = np.concatenate([src[:, :, :1].repeat(3, 2), src[:, :, 1:2]], 2)
+        expg = src[:, :, :1]
+    else:
+        exp = np.concatenate([src[:, :, :3], src[:, :, 3:4] if c == 4 else np.full((37, 53, 1), 255, np.uint8)], 2)
+        s = src.astype(np.uint32)
+        expg = ((s[:, :, 0] * 77 + s[:, :, 1] * 150 + s[:, :, 2] * 29) >> 8).astype(np.uint8)[:, :, None]
+    assert np.array_equal(rgba, exp)
+    assert np.array_equal(grey, expg)
+
+
+def test_png_palette_and_low_bit_depths(tmp_path):
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    w, h = 10, 3
+    pal = bytes([255, 0, 0, 0, 255, 0, 0, 0, 255, 10, 20, 30])
+    idx = np.array([[0, 1, 2, 3, 0, 1, 2, 3, 0, 1], [3, 3, 2, 2, 1, 1, 0, 0, 3, 2], [1] * 10], np.uint8)
+    rows = b""
+    for y in range(h):                               # 2 bits per pixel, filter 0
+        bits = 0
+        packed = bytearray()
+        for x in range(w):
+            bits = (bits << 2) | int(idx[y, x])
+            if x % 4 == 3:
+                packed.append(bits); bits = 0
+        packed.append((bits << 4) & 0xff)            # 10 pixels -> 2.5 bytes: pad the last one
+        rows += b"\x00" + bytes(packed)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 2, 3, 0, 0, 0)) + chunk(b"PLTE", pal) + \
+        chunk(b"tRNS", bytes([255, 128, 0])) + chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b"")
+    p = str(tmp_path / "pal.png")
+    open(p, "wb").write(png)
+    rgba = host.load_image(p)
+    palarr = np.frombuffer(pal, np.uint8).reshape(4, 3)
+    alpha = np.array([255, 128, 0, 255], np.uint8)
+    exp = np.concatenate([palarr[idx], alpha[idx][:, :, None]], 2)[::-1]
+    assert np.array_equal(rgba, exp)
+
+
+def test_pnm_and_hdr(tmp_path):
+    a = _rng_img(9, 11, 3, 3)
+    scenes.write_pnm(str(tmp_path / "a.ppm"), a)
+    scenes.write_pnm(str(tmp_path / "g.pgm"), a[:, :, 0])
+    assert np.array_equal(host.load_image(str(tmp_path / "a.ppm"))[:, :, :3], a[::-1])
+    assert np.array_equal(host.load_image(str(tmp_path / "g.pgm"), grayscale=True)[:, :, 0], a[::-1, :, 0])
+    rng = np.random.default_rng(5)
+    f = (rng.random((7, 40, 3)) * np.array([0.2, 1.0, 6.0])).astype(np.float32)
+    f[2, 5:30] = f[2, 5]                             # a run for the RLE encoder
+    for rle in (True, False):
+        p = str(tmp_path / f"s{int(rle)}.hdr")
+        rgbe = scenes.write_hdr(p, f, rle=rle)
+        got = host.load_image(p)
+        # what stb_image's hdr->ldr does to the decoded RGBE: pow(x, 1/2.2) * 255 + 0.5, clamped
+        dec = rgbe[..., :3].astype(np.float32) * np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 136)[..., None]
+        dec[rgbe[..., 3] == 0] = 0
+        exp = np.clip(np.power(dec, np.float32(1 / 2.2)) * 255.0 + 0.5, 0, 255).astype(np.uint8)[::-1]
+        assert np.abs(got[:, :, :3].astype(int) - exp.astype(int)).max() <= 1     # libm powf vs numpy: at most one code value
+        assert np.all(got[:, :, 3] == 255)
+
+
+def test_bad_images_raise(tmp_path):
+    p = str(tmp_path / "x.jpg")
+    open(p, "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    with pytest.raises(host.HostError):
+        host.load_image(p)
+    with pytest.raises(host.HostError):
+        host.load_image(str(tmp_path / "missing.png"))
+    q = str(tmp_path / "trunc.png")
+    scenes.write_png(q, _rng_img(16, 16, 3, 1))
+    data = open(q, "rb").read()
+    open(q, "wb").write(data[: len(data) // 2])
+    with pytest.raises(host.HostError):
+        host.load_image(q)
+
+
+def test_texture_table_of_created_scene(scene_cache):
+    """create_scene.cppm:71-141: indices start at 2, path-keyed de-dup, specular/metallic R8, colour/opacity RGBA8."""
+    s = scenes.textured_room(64, 40)
+    d = s.desc
+    assert d.numTextures == 2 + 5 and not d.textures[0].pixels and not d.textures[1].pixels
+    infos = s.host.objectInfos()
+    floor, back, panel, leaf_near, leaf_far, block = infos
+    assert floor.usesColorMap and floor.usesSpecularMap and not floor.usesMetallicMap
+    assert d.textures[floor.specularIndex].channels == 1 and d.textures[floor.colorIndex].channels == 4
+    assert floor.specularIndex == 2 and floor.colorIndex == 3            # specular is visited before colour (:76-106)
+    assert panel.usesMetallicMap and d.textures[panel.metallicIndex].channels == 1
+    assert leaf_near.usesOpacityMap and leaf_near.opacityIndex == leaf_near.colorIndex == leaf_far.colorIndex   # same path -> one texture
+    assert not block.usesColorMap and abs(block.metallic - 0.5) < 1e-7   # unknown_parameter["metallic"]
+    assert d.hdri and d.hdri.contents.width == 128 and d.hdri.contents.height == 64 and d.hdri.contents.channels == 4

@@ -165,3 +165,23 @@ def test_oracle_denoise_combine_properties(oracle):
     o2 = oracle.denoise_combine(an, sh2, un, no, po, iterations=1)
     d = o2[A.IMAGE_DENOISED_SHADOWED].view(np.uint8).reshape(H, W, 4)[H // 2, :, 0].astype(int)
     assert d[W // 2 - 3] < 80 and d[W // 2 + 2] > 230
+
+
+def test_textured_room_bvh_vs_brute_force(oracle, scene_cache):
+    """Texture maps, alpha-tested any-hit (opacity.rahit) and the HDRI miss shader through both oracle traversals."""
+    s = scenes.textured_room(120, 76, ltc=scenes.synthetic_ltc())
+    st, nodes, tris = api.host_build_bvh(s.desc)
+    flags = np.frombuffer(tris, dtype=np.uint32).reshape(-1, 12)[:, 11]
+    assert flags.sum() == 4                                  # the two leaf quads (2 triangles each) are alpha-tested
+    p = _params(120, 76, spp=2, images=ALL5)
+    a = oracle.render(s.desc, s.camera, s.scene_info(1), p, bvh=(nodes, tris), images=ALL5, threads=8)
+    b = oracle.render(s.desc, s.camera, s.scene_info(1), p, bvh=None, images=ALL5, threads=8)
+    for which in (0, 1, 2, 6, 7):
+        assert np.array_equal(a.images[which], b.images[which])
+    assert a.stats.numAlphaTests > 1000 and a.stats.numTexFetches > a.stats.numHits
+    # the sky is not flat any more (HDRI), and the cut-out lets rays through
+    top = a.images[1][:8].reshape(-1)
+    assert len(np.unique(top)) > 20
+    s2 = scenes.textured_room(120, 76, hdri=False)          # keep the owner of the arrays alive while the oracle reads them
+    c = oracle.render(s2.desc, s.camera, s.scene_info(1), _params(120, 76, spp=2), bvh=None, threads=8)
+    assert len(np.unique(c.images[1][:8].reshape(-1))) < len(np.unique(top))
