@@ -17,6 +17,14 @@ import numpy as np
 from . import host
 
 
+def _atomic_write(path, data, mode="w"):
+    """Several ranks may generate the same scene file concurrently: write aside, then rename (atomic on POSIX)."""
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, mode) as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
 def _cache_dir():
     d = os.environ.get("RTR_SCENE_CACHE") or os.path.join(tempfile.gettempdir(), "rtr_scene_cache")
     os.makedirs(d, exist_ok=True)
@@ -92,10 +100,9 @@ def cornell_obj_text():
 def write_cornell(directory=None):
     d = directory or _cache_dir()
     obj, mtl = os.path.join(d, "cornell_box.obj"), os.path.join(d, "cornell_box.mtl")
-    with open(obj, "w") as f:
-        f.write(cornell_obj_text())
-    with open(mtl, "w") as f:
-        f.write(_CORNELL_MTL)
+    if not (os.path.exists(obj) and os.path.exists(mtl)):
+        _atomic_write(mtl, _CORNELL_MTL)
+        _atomic_write(obj, cornell_obj_text())
     return obj, d + "/"
 
 
@@ -128,14 +135,14 @@ class ObjWriter:
             tt = t + 1 + base
             lines.append("".join("f %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c) for a, b, c in tt))
             base += len(v)
-        with open(obj_path, "w") as f:
-            f.write("".join(lines))
-        with open(os.path.join(os.path.dirname(obj_path), mtl_name), "w") as f:
-            for name, (kd, ks, metallic) in self.materials.items():
-                f.write("newmtl %s\nKa 0 0 0\nKd %.4f %.4f %.4f\nKs %.4f %.4f %.4f\n" % (name, kd[0], kd[1], kd[2], ks, ks, ks))
-                if metallic is not None:
-                    f.write("metallic %.4f\n" % metallic)
-                f.write("\n")
+        mtl = []
+        for name, (kd, ks, metallic) in self.materials.items():
+            mtl.append("newmtl %s\nKa 0 0 0\nKd %.4f %.4f %.4f\nKs %.4f %.4f %.4f\n" % (name, kd[0], kd[1], kd[2], ks, ks, ks))
+            if metallic is not None:
+                mtl.append("metallic %.4f\n" % metallic)
+            mtl.append("\n")
+        _atomic_write(os.path.join(os.path.dirname(obj_path), mtl_name), "".join(mtl))   # MTL first: the OBJ's existence is the "done" mark
+        _atomic_write(obj_path, "".join(lines))
 
 
 def _normalize(v):
