@@ -98,7 +98,15 @@ typedef struct rtr_scene_desc {
      * this array; the reference keeps the LTC tables at 0 and 1 so material textures start at 2. */
     const rtr_texture*      textures;      uint32_t numTextures;
     const rtr_texture*      hdri;          /* equirect sky (RGBA8, as stbi_load of the .hdr gives, file.cppm:279-291) or NULL */
+    /* Acceleration-structure build preference (reference: vk::BuildAccelerationStructureFlagBitsKHR, blas.cppm:115
+     * ePreferFastTrace; tlas.cppm eAllowUpdate): RTR_BUILD_HOST_SAH (default, best trace speed) or
+     * RTR_BUILD_DEVICE_LBVH (Morton/radix-tree build on the GPU, fastest build).  Rendered images are identical. */
+    uint32_t                buildFlags;
+    uint32_t                _pad2;
 } rtr_scene_desc;
+
+#define RTR_BUILD_HOST_SAH    0u
+#define RTR_BUILD_DEVICE_LBVH 1u
 
 typedef struct rtr_scene_stats {
     uint32_t numTriangles;
@@ -183,6 +191,12 @@ int  rtr_scene_export_bvh(const rtr_scene* scene, RtrBvhNode* nodes, size_t node
  * in `stats`.  Used by the CPU-side tests (BVH invariants, oracle BVH-vs-brute-force). */
 int  rtr_host_build_bvh(const rtr_scene_desc* desc, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes,
                         RtrBvhTri* tris, size_t triBytes);
+/* Dynamic scenes: new instance transforms (same instances, meshes and customIndex as at creation) and, optionally,
+ * new light infos (NULL keeps them).  World-space triangle records are recomputed and every BVH box is re-fitted ON
+ * THE DEVICE; the topology is kept.  Replaces TLAS::updateTransform + TLAS::refit
+ * (src/vulkan/raytracing/tlas.cppm:151-207; present in the reference, never called by its app). */
+int  rtr_scene_update_instances(rtr_scene* scene, const RtrInstance* instances, uint32_t numInstances,
+                                const RtrAreaLightInfo* lights, uint32_t numLights);
 /* replaces the host-visible LightInfo buffer rewrite (src/app/application.cppm:264-271). */
 int  rtr_scene_update_lights(rtr_scene* scene, const RtrAreaLightInfo* lights, uint32_t numLights);
 

@@ -69,7 +69,7 @@ class rtr_scene_desc(C.Structure):
                 ("ltc1", C.POINTER(f32)), ("ltc2", C.POINTER(f32)),
                 ("skyColor", f32 * 3), ("_pad", f32),
                 ("textures", C.POINTER(rtr_texture)), ("numTextures", u32),
-                ("hdri", C.POINTER(rtr_texture))]
+                ("hdri", C.POINTER(rtr_texture)), ("buildFlags", u32), ("_pad2", u32)]
 
 
 class rtr_scene_stats(C.Structure):
@@ -109,6 +109,7 @@ def IMG_BIT(which):
 IMAGES_FRAMEBUFFER = IMG_BIT(IMAGE_SHADOWED)
 IMAGES_RAYGEN5 = IMG_BIT(0) | IMG_BIT(1) | IMG_BIT(2) | IMG_BIT(6) | IMG_BIT(7)
 IMAGES_DENOISE = IMG_BIT(3) | IMG_BIT(4) | IMG_BIT(5)
+BUILD_HOST_SAH, BUILD_DEVICE_LBVH = 0, 1
 
 P = C.POINTER
 VP = C.c_void_p
@@ -125,6 +126,7 @@ RTR_SYMBOLS = {
     "rtr_scene_export_bvh": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_host_build_bvh": (C.c_int, [P(rtr_scene_desc), P(rtr_scene_stats), VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_scene_update_lights": (C.c_int, [VP, P(RtrAreaLightInfo), u32]),
+    "rtr_scene_update_instances": (C.c_int, [VP, P(RtrInstance), u32, P(RtrAreaLightInfo), u32]),
     "rtr_frame_create": (C.c_int, [VP, u32, u32, u32, P(VP)]),
     "rtr_frame_destroy": (None, [VP]),
     "rtr_frame_bind_external": (C.c_int, [VP, C.c_int, VP, C.c_size_t]),

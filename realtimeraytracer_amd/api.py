@@ -67,6 +67,15 @@ class Scene:
         _check(self.lib.rtr_scene_export_bvh(self.h, nodes, C.sizeof(nodes), tris, C.sizeof(tris)), "rtr_scene_export_bvh")
         return nodes, tris
 
+    def update_instances(self, instances, lights=None):
+        """rtr_scene_update_instances: new transforms (+ optional light infos) -> device-side re-flatten + BVH refit."""
+        arr = (A.RtrInstance * len(instances))(*instances)
+        if lights is None:
+            _check(self.lib.rtr_scene_update_instances(self.h, arr, len(instances), None, 0), "rtr_scene_update_instances")
+        else:
+            larr = (A.RtrAreaLightInfo * len(lights))(*lights)
+            _check(self.lib.rtr_scene_update_instances(self.h, arr, len(instances), larr, len(lights)), "rtr_scene_update_instances")
+
     def update_lights(self, lights):
         arr = (A.RtrAreaLightInfo * len(lights))(*lights)
         _check(self.lib.rtr_scene_update_lights(self.h, arr, len(lights)), "rtr_scene_update_lights")

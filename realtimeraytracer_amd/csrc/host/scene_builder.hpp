@@ -259,6 +259,7 @@ struct SceneReturnInfo {
         d.textures = textureTable.empty() ? nullptr : textureTable.data();
         d.numTextures = (uint32_t)textureTable.size();
         d.hdri = hdriImage.pixels.empty() ? nullptr : &hdriEntry;
+        d.buildFlags = RTR_BUILD_HOST_SAH;
         return d;
     }
 };

@@ -1,0 +1,290 @@
+/* rtr_bvh.hip — BVH build and refit ON the device.
+ *
+ * Replaces what the reference leaves to the driver: vkCmdBuildAccelerationStructuresKHR for BLAS/TLAS
+ * (src/vulkan/raytracing/blas.cppm:113-160, tlas.cppm:112-149) and TLAS::updateTransform / refit
+ * (tlas.cppm:151-207 — present in the reference, never called by its app).
+ *
+ *   build  : LBVH (Karras 2012).  k_world_prims flattens instances to world space (same arithmetic as the host
+ *            packer) and reduces centroid bounds; 30-bit Morton code | primitive index as a unique 64-bit key;
+ *            rocPRIM/hipCUB radix sort (a plain library sort, the one step that is not hand-written);
+ *            k_karras builds the radix tree, one lane per internal node; subtrees of <= 4 primitives collapse into
+ *            leaves (Morton-sorted primitives of a subtree are contiguous, so a leaf is (first,count) as in the
+ *            host builder); k_fit fits the child boxes bottom-up.
+ *   refit  : k_world_prims again with new transforms into the existing leaf order, then k_fit on the unchanged
+ *            topology (works for host-SAH-built and device-LBVH-built trees alike).
+ *
+ * k_fit: one lane per inner node fills the slots of its leaf children, then climbs: an agent-scope
+ * fence + atomic counter per node lets exactly the second arriver continue with both child boxes visible
+ * (cdna guide G16: visibility comes from the release/acquire pair, not from placement).  Every climb ends at the
+ * root or at a node whose sibling has not arrived, so all waves exit.
+ * Output layout = RTR_BVH_LAYOUT_VERSION 2 (64-B children-in-parent nodes, 48-B {v0,e1,e2} records), boxes padded
+ * outwards by 2^-18 of the largest coordinate like the host builder, so traversal results are identical whichever
+ * builder made the tree.
+ */
+#include "rtr_bvh.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include "../../../include/rtr_math.h"
+
+namespace rtrdev {
+
+constexpr int kB = 256;
+constexpr uint32_t kLeafMax = 4;
+
+__device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ inline float ord2f(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+/* scene reduction words: [0..2] centroid min (ordered uint), [3..5] centroid max, [6] max |coordinate| (float bits, >= 0) */
+__global__ __launch_bounds__(kB) void k_world_prims(BvhInputs in, uint32_t n, const uint32_t* __restrict__ slotOfPrim,
+                                                    float4* __restrict__ triOut, float4* __restrict__ boxMin, float4* __restrict__ boxMax,
+                                                    uint32_t* __restrict__ red) {
+    const uint32_t p = blockIdx.x * kB + threadIdx.x;
+    float cmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, mabs = 0.f;
+    if (p < n) {
+        const PrimRef pr = in.prims[p];
+        const InstanceRef ir = in.instances[pr.customIndex];
+        rtr_v3 w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t idx = in.indices[ir.indexOffset + 3u * pr.primitiveId + k] + ir.vertexOffset;
+            w[k] = rtr_xform_point34(ir.transform, rtr_ld3(in.vertices[idx].position));
+        }
+        const rtr_v3 e1 = rtr_sub(w[1], w[0]), e2 = rtr_sub(w[2], w[0]);
+        const uint32_t s = slotOfPrim ? slotOfPrim[p] : p;          /* refit writes straight into leaf order */
+        triOut[(size_t)s * 3 + 0] = make_float4(w[0].x, w[0].y, w[0].z, __uint_as_float(pr.customIndex));
+        triOut[(size_t)s * 3 + 1] = make_float4(e1.x, e1.y, e1.z, __uint_as_float(pr.primitiveId));
+        triOut[(size_t)s * 3 + 2] = make_float4(e2.x, e2.y, e2.z, __uint_as_float(pr.flags));
+        const float mn[3] = {fminf(fminf(w[0].x, w[1].x), w[2].x), fminf(fminf(w[0].y, w[1].y), w[2].y), fminf(fminf(w[0].z, w[1].z), w[2].z)};
+        const float mx[3] = {fmaxf(fmaxf(w[0].x, w[1].x), w[2].x), fmaxf(fmaxf(w[0].y, w[1].y), w[2].y), fmaxf(fmaxf(w[0].z, w[1].z), w[2].z)};
+        boxMin[s] = make_float4(mn[0], mn[1], mn[2], 0.f);
+        boxMax[s] = make_float4(mx[0], mx[1], mx[2], 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float c = 0.5f * (mn[k] + mx[k]);
+            cmin[k] = c; cmax[k] = c;
+            mabs = fmaxf(mabs, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
+        }
+    }
+    /* wave reduction, then one atomic per wave and word */
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { cmin[k] = fminf(cmin[k], __shfl_xor(cmin[k], o)); cmax[k] = fmaxf(cmax[k], __shfl_xor(cmax[k], o)); }
+        mabs = fmaxf(mabs, __shfl_xor(mabs, o));
+    }
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { atomicMin(&red[k], f2ord(cmin[k])); atomicMax(&red[3 + k], f2ord(cmax[k])); }
+        atomicMax(&red[6], __float_as_uint(mabs));
+    }
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(kB) void k_morton(uint32_t n, const float4* __restrict__ boxMin, const float4* __restrict__ boxMax,
+                                               const uint32_t* __restrict__ red, unsigned long long* __restrict__ keys) {
+    const uint32_t p = blockIdx.x * kB + threadIdx.x;
+    if (p >= n) return;
+    const float4 a = boxMin[p], b = boxMax[p];
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lo = ord2f(red[k]), hi = ord2f(red[3 + k]);
+        const float ext = hi - lo;
+        float t = ext > 0.f ? (c[k] - lo) / ext : 0.f;
+        t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+        q[k] = (uint32_t)t;
+    }
+    const uint32_t m = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    keys[p] = ((unsigned long long)m << 32) | p;
+}
+
+/* gather the canonical-order records into Morton order and remember where every canonical primitive went */
+__global__ __launch_bounds__(kB) void k_gather(uint32_t n, const unsigned long long* __restrict__ keys,
+                                               const float4* __restrict__ triIn, const float4* __restrict__ minIn, const float4* __restrict__ maxIn,
+                                               float4* __restrict__ triOut, float4* __restrict__ minOut, float4* __restrict__ maxOut,
+                                               uint32_t* __restrict__ slotOfPrim) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = (uint32_t)(keys[i] & 0xffffffffull);
+    triOut[(size_t)i * 3 + 0] = triIn[(size_t)p * 3 + 0];
+    triOut[(size_t)i * 3 + 1] = triIn[(size_t)p * 3 + 1];
+    triOut[(size_t)i * 3 + 2] = triIn[(size_t)p * 3 + 2];
+    minOut[i] = minIn[p]; maxOut[i] = maxIn[p];
+    slotOfPrim[p] = i;
+}
+
+/* Karras 2012: longest common prefix of the (unique) keys i and j, -1 outside [0,n) */
+__device__ __forceinline__ int lcp(const unsigned long long* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+__device__ __forceinline__ int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t)~((first << 3) | (count - 1u)); }
+
+/* one lane per internal node: range, split, children; child codes with <=4-primitive subtrees collapsed to leaves */
+__global__ __launch_bounds__(kB) void k_karras(int n, const unsigned long long* __restrict__ keys, int2* __restrict__ range,
+                                               int2* __restrict__ rawChild /* index, with bit 31 = primitive leaf */) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (lcp(keys, n, i, i + 1) - lcp(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lcp(keys, n, i, i - d);
+    int lmax = 2;
+    while (lcp(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (lcp(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lcp(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (lcp(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    range[i] = make_int2(lo, hi);
+    rawChild[i] = make_int2(lo == gamma ? (gamma | (int)0x80000000) : gamma, hi == gamma + 1 ? ((gamma + 1) | (int)0x80000000) : gamma + 1);
+}
+
+__global__ __launch_bounds__(kB) void k_mark_unused(uint32_t numNodes, int32_t* __restrict__ parent) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i < numNodes) parent[i] = -2;
+}
+
+/* child codes in the final node array + parent links for the climb */
+__global__ __launch_bounds__(kB) void k_emit(int n, const int2* __restrict__ range, const int2* __restrict__ rawChild,
+                                             float4* __restrict__ nodes, int32_t* __restrict__ parent) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int2 r = range[i];
+    if ((uint32_t)(r.y - r.x + 1) <= kLeafMax && i != 0) return;        /* inside / root of a collapsed subtree: never referenced */
+    const int2 rc = rawChild[i];
+    int32_t code[2];
+    const int raw[2] = {rc.x, rc.y};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (raw[s] < 0) code[s] = leaf_code((uint32_t)(raw[s] & 0x7fffffff), 1u);
+        else {
+            const int2 cr = range[raw[s]];
+            const uint32_t cnt = (uint32_t)(cr.y - cr.x + 1);
+            if (cnt <= kLeafMax) code[s] = leaf_code((uint32_t)cr.x, cnt);
+            else { code[s] = raw[s]; parent[raw[s]] = (i << 1) | s; }
+        }
+    }
+    int4 w = make_int4(code[0], code[1], 0, 0);
+    nodes[(size_t)i * 4 + 3] = *reinterpret_cast<float4*>(&w);
+    if (i == 0) parent[0] = -1;
+}
+
+/* bottom-up fit (build and refit).  counters must be zero on entry; depth[] gets the inner-node height. */
+__global__ __launch_bounds__(kB) void k_fit(uint32_t numNodes, float4* nodes, const float4* __restrict__ boxMin, const float4* __restrict__ boxMax,
+                                            const int32_t* __restrict__ parent, uint32_t* counters, uint32_t* depth, const uint32_t* __restrict__ red,
+                                            uint32_t* maxDepthOut) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= numNodes) return;
+    const int32_t par0 = parent[i];
+    if (par0 == -2) return;                                   /* slot of the node array that is not part of the tree */
+    const float pad = fmaxf(__uint_as_float(red[6]), 1e-6f) * 3.814697265625e-06f;
+    float* nf = reinterpret_cast<float*>(nodes + (size_t)i * 4);
+    const int2 ch = *reinterpret_cast<const int2*>(nodes + (size_t)i * 4 + 3);
+    uint32_t filled = 0;
+    const int32_t code[2] = {ch.x, ch.y};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (code[s] >= 0) continue;
+        const uint32_t c = (uint32_t)~code[s];
+        const uint32_t first = c >> 3, cnt = (c & 7u) + 1u;
+        float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4 a = boxMin[first + k], b = boxMax[first + k];
+            mn[0] = fminf(mn[0], a.x); mn[1] = fminf(mn[1], a.y); mn[2] = fminf(mn[2], a.z);
+            mx[0] = fmaxf(mx[0], b.x); mx[1] = fmaxf(mx[1], b.y); mx[2] = fmaxf(mx[2], b.z);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nf[6 * s + k] = mn[k] - pad; nf[6 * s + 3 + k] = mx[k] + pad; }
+        ++filled;
+    }
+    if (filled == 0) return;                                  /* two inner children: their climbs complete this node */
+    uint32_t cur = i;
+    uint32_t add = filled;
+    for (;;) {
+        __threadfence();                                      /* release my slot writes (agent scope) */
+        const uint32_t before = atomicAdd(&counters[cur], add);
+        if (before + add < 2u) return;                        /* sibling subtree not finished: its lane will continue */
+        __threadfence();                                      /* acquire the sibling's writes */
+        float* cf = reinterpret_cast<float*>(nodes + (size_t)cur * 4);
+        const int2 cc = *reinterpret_cast<const int2*>(nodes + (size_t)cur * 4 + 3);
+        const uint32_t dl = cc.x >= 0 ? __hip_atomic_load(&depth[cc.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t dr = cc.y >= 0 ? __hip_atomic_load(&depth[cc.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t dcur = 1u + (dl > dr ? dl : dr);
+        __hip_atomic_store(&depth[cur], dcur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t p = parent[cur];
+        if (p < 0) { *maxDepthOut = dcur; return; }           /* root done */
+        const uint32_t pi = (uint32_t)p >> 1, ps = (uint32_t)p & 1u;
+        float* pf = reinterpret_cast<float*>(nodes + (size_t)pi * 4);
+        /* my box = union of my two child boxes (volatile-style loads through the agent-scope path) */
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = __hip_atomic_load(&cf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float b = __hip_atomic_load(&cf[6 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float c = __hip_atomic_load(&cf[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float d = __hip_atomic_load(&cf[9 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pf[6 * ps + k], fminf(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pf[6 * ps + 3 + k], fmaxf(c, d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cur = pi; add = 1u;
+    }
+}
+
+/* ---- host-side drivers ------------------------------------------------------------------------------ */
+#define BV_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t bvh_refit(const BvhInputs& in, uint32_t numPrims, uint32_t numNodes, const BvhDeviceArrays& a, hipStream_t s) {
+    BV_TRY(hipMemsetAsync(a.counters, 0, (size_t)numNodes * sizeof(uint32_t), s));
+    BV_TRY(hipMemsetAsync(a.depth, 0, (size_t)numNodes * sizeof(uint32_t), s));
+    uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    BV_TRY(hipMemcpyAsync(a.red, init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_world_prims, dim3((numPrims + kB - 1) / kB), dim3(kB), 0, s, in, numPrims, a.slotOfPrim, a.tris, a.boxMin, a.boxMax, a.red);
+    hipLaunchKernelGGL(k_fit, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, a.nodes, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
+    return hipGetLastError();
+}
+
+hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDeviceArrays& a, const BvhScratch& t, hipStream_t s) {
+    const uint32_t n = numPrims, numNodes = n - 1;
+    uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    BV_TRY(hipMemcpyAsync(a.red, init, sizeof init, hipMemcpyHostToDevice, s));
+    BV_TRY(hipMemsetAsync(a.counters, 0, (size_t)numNodes * sizeof(uint32_t), s));
+    BV_TRY(hipMemsetAsync(a.depth, 0, (size_t)numNodes * sizeof(uint32_t), s));
+    const dim3 gp((n + kB - 1) / kB), gn((numNodes + kB - 1) / kB);
+    hipLaunchKernelGGL(k_world_prims, gp, dim3(kB), 0, s, in, n, (const uint32_t*)nullptr, t.trisCanon, t.minCanon, t.maxCanon, a.red);
+    hipLaunchKernelGGL(k_morton, gp, dim3(kB), 0, s, n, t.minCanon, t.maxCanon, a.red, t.keysIn);
+    size_t tempBytes = t.sortTempBytes;
+    BV_TRY(hipcub::DeviceRadixSort::SortKeys(t.sortTemp, tempBytes, t.keysIn, t.keysOut, (int)n, 0, 64, s));
+    hipLaunchKernelGGL(k_gather, gp, dim3(kB), 0, s, n, t.keysOut, t.trisCanon, t.minCanon, t.maxCanon, a.tris, a.boxMin, a.boxMax, a.slotOfPrim);
+    hipLaunchKernelGGL(k_karras, gn, dim3(kB), 0, s, (int)n, t.keysOut, t.range, t.rawChild);
+    hipLaunchKernelGGL(k_mark_unused, gn, dim3(kB), 0, s, numNodes, a.parent);
+    hipLaunchKernelGGL(k_emit, gn, dim3(kB), 0, s, (int)n, t.range, t.rawChild, a.nodes, a.parent);
+    hipLaunchKernelGGL(k_fit, gn, dim3(kB), 0, s, numNodes, a.nodes, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
+    return hipGetLastError();
+}
+
+size_t bvh_sort_temp_bytes(uint32_t numPrims) {
+    size_t bytes = 0;
+    unsigned long long* nul = nullptr;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, nul, nul, (int)numPrims, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace rtrdev

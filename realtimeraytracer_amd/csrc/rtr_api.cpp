@@ -7,9 +7,11 @@
 #include "bvh_build.h"
 #include "kernels/rtr_kernels.h"
 #include "kernels/rtr_post.h"
+#include "kernels/rtr_bvh.h"
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -86,6 +88,17 @@ struct rtr_scene {
     std::vector<RtrBvhNode> hostNodes;
     std::vector<RtrBvhTri> hostTris;
     std::vector<RtrAreaLightInfo> hostLights;
+    /* device build / refit state (kernels/rtr_bvh.hip) */
+    std::vector<RtrInstance> hostInstances;
+    std::vector<RtrMesh> hostMeshes;
+    std::vector<RtrObjectInfo> hostObjects;
+    DevBuf<rtrdev::PrimRef> prims;
+    DevBuf<rtrdev::InstanceRef> instRefs;
+    DevBuf<float4> boxMin, boxMax;
+    DevBuf<int32_t> parent;
+    DevBuf<uint32_t> counters, depth, slotOfPrim, red;
+    uint32_t numPrims = 0, numNodeSlots = 0;
+    bool refitReady = false;
     rtr_scene_stats stats{};
     DeviceScene dev{};
     uint32_t numLights = 0, numObjects = 0, numVertices = 0, numIndices = 0;
@@ -305,15 +318,104 @@ int rtr_host_build_bvh(const rtr_scene_desc* d, rtr_scene_stats* stats, RtrBvhNo
     return RTR_OK;
 }
 
+/* canonical (instance-major) primitive table + per-customIndex instance table for the device flatten kernel */
+static void make_prim_tables(const rtr_scene_desc* d, const RtrInstance* instances, std::vector<rtrdev::PrimRef>& prims,
+                             std::vector<rtrdev::InstanceRef>& refs) {
+    prims.clear();
+    refs.assign(d->numInstances, rtrdev::InstanceRef{});
+    for (uint32_t i = 0; i < d->numInstances; ++i) {
+        const RtrInstance& in = instances[i];
+        const RtrMesh& me = d->meshes[in.meshIndex];
+        rtrdev::InstanceRef& r = refs[in.customIndex];
+        memcpy(r.transform, in.transform, sizeof r.transform);
+        r.vertexOffset = me.vertexOffset; r.indexOffset = me.indexOffset;
+        const uint32_t flags = (in.customIndex >= d->numLights && d->objects[in.customIndex - d->numLights].usesOpacityMap != 0 && me.isOpaque == 0) ? 1u : 0u;
+        for (uint32_t t = 0; t < me.indexCount / 3u; ++t) prims.push_back(rtrdev::PrimRef{in.customIndex, t, flags, 0u});
+    }
+}
+
+static rtrdev::BvhDeviceArrays device_arrays(rtr_scene* s) {
+    rtrdev::BvhDeviceArrays a{};
+    a.nodes = s->nodes.p; a.tris = s->tris.p; a.boxMin = s->boxMin.p; a.boxMax = s->boxMax.p; a.parent = s->parent.p;
+    a.counters = s->counters.p; a.depth = s->depth.p; a.slotOfPrim = s->slotOfPrim.p; a.red = s->red.p;
+    return a;
+}
+
+/* Device LBVH build into s->nodes / s->tris (+ refit arrays); fills hostNodes/hostTris and the stats. */
+static int build_on_device(rtr_scene* s, const rtr_scene_desc* d, size_t numPrims) {
+    hipStream_t st = s->ctx->stream;
+    std::vector<rtrdev::PrimRef> prims; std::vector<rtrdev::InstanceRef> refs;
+    make_prim_tables(d, d->instances, prims, refs);
+    const uint32_t n = (uint32_t)numPrims, numNodes = n - 1;
+    for (uint32_t v = 0; v < d->numVertices; ++v)
+        for (int k = 0; k < 3; ++k)
+            if (!(d->vertices[v].position[k] > -3.0e38f && d->vertices[v].position[k] < 3.0e38f))
+                return fail(RTR_ERR_INVALID_ARGUMENT, "BVH build: non-finite vertex position in vertex %u", v);
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(s->prims.upload(prims.data(), prims.size(), st));
+    HIP_TRY(s->instRefs.upload(refs.data(), refs.size(), st));
+    HIP_TRY(s->nodes.alloc((size_t)numNodes * 4)); HIP_TRY(s->tris.alloc((size_t)n * 3));
+    HIP_TRY(s->boxMin.alloc(n)); HIP_TRY(s->boxMax.alloc(n)); HIP_TRY(s->parent.alloc(numNodes));
+    HIP_TRY(s->counters.alloc(numNodes)); HIP_TRY(s->depth.alloc(numNodes)); HIP_TRY(s->slotOfPrim.alloc(n)); HIP_TRY(s->red.alloc(8));
+    DevBuf<float4> trisCanon, minCanon, maxCanon; DevBuf<unsigned long long> keysIn, keysOut; DevBuf<int2> range, rawChild; DevBuf<uint8_t> sortTemp;
+    HIP_TRY(trisCanon.alloc((size_t)n * 3)); HIP_TRY(minCanon.alloc(n)); HIP_TRY(maxCanon.alloc(n));
+    HIP_TRY(keysIn.alloc(n)); HIP_TRY(keysOut.alloc(n)); HIP_TRY(range.alloc(numNodes)); HIP_TRY(rawChild.alloc(numNodes));
+    rtrdev::BvhScratch sc{};
+    sc.sortTempBytes = rtrdev::bvh_sort_temp_bytes(n);
+    HIP_TRY(sortTemp.alloc(sc.sortTempBytes));
+    sc.trisCanon = trisCanon.p; sc.minCanon = minCanon.p; sc.maxCanon = maxCanon.p; sc.keysIn = keysIn.p; sc.keysOut = keysOut.p;
+    sc.range = range.p; sc.rawChild = rawChild.p; sc.sortTemp = sortTemp.p;
+    HIP_TRY(hipMemsetAsync(s->nodes.p, 0, (size_t)numNodes * 64, st));
+    rtrdev::BvhInputs in{s->prims.p, s->instRefs.p, s->vertices.p, s->indices.p};
+    hipError_t e = rtrdev::bvh_build_lbvh(in, n, device_arrays(s), sc, st);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "device BVH build: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(st));
+    s->hostNodes.resize(numNodes); s->hostTris.resize(n);
+    uint32_t red[8];
+    HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, (size_t)numNodes * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s->hostTris.data(), s->tris.p, (size_t)n * 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(red, s->red.p, sizeof red, hipMemcpyDeviceToHost));
+    const float buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (red[7] > 64) return fail(RTR_ERR_BVH_TOO_DEEP, "device-built BVH depth %u exceeds the 64-entry LDS traversal stack", red[7]);
+    memset(&s->stats, 0, sizeof s->stats);
+    s->stats.numTriangles = n; s->stats.numNodes = numNodes; s->stats.maxDepth = red[7]; s->stats.maxLeafSize = 4;
+    s->stats.bvhLayoutVersion = RTR_BVH_LAYOUT_VERSION;
+    s->stats.stackEntries = red[7] <= 16 ? 16 : (red[7] <= 32 ? 32 : 64);
+    s->stats.buildMs = buildMs;
+    float mabs; memcpy(&mabs, &red[6], 4);
+    s->stats.boxPad = (mabs > 1e-6f ? mabs : 1e-6f) * 3.814697265625e-06f;
+    s->numPrims = n; s->numNodeSlots = numNodes; s->refitReady = true;
+    return RTR_OK;
+}
+
+static void instance_tables(uint32_t numInstances, const RtrInstance* instances, std::vector<float>& xforms, std::vector<float>& nmats) {
+    xforms.assign(12 * (size_t)numInstances, 0.f);
+    nmats.assign(12 * (size_t)numInstances, 0.f);
+    for (uint32_t i = 0; i < numInstances; ++i) {
+        memcpy(&xforms[12 * (size_t)instances[i].customIndex], instances[i].transform, 12 * sizeof(float));
+        rtr_normal_matrix(instances[i].transform, &nmats[12 * (size_t)instances[i].customIndex]);
+    }
+}
+
 int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: null ctx/out");
     *out = nullptr;
     int rc = validate_desc(d);
     if (rc != RTR_OK) return rc;
+    if (d->buildFlags > RTR_BUILD_DEVICE_LBVH) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: unknown buildFlags %u", d->buildFlags);
     HIP_TRY(hipSetDevice(ctx->device));
+    size_t totalPrims = 0;
+    for (uint32_t i = 0; i < d->numInstances; ++i) totalPrims += d->meshes[d->instances[i].meshIndex].indexCount / 3u;
+    if (totalPrims >= (1u << 28)) return fail(RTR_ERR_INVALID_ARGUMENT, "too many triangles for the leaf encoding (2^28)");
+    /* tiny scenes always take the host builder (the radix tree needs a root with more than one leaf's worth of primitives) */
+    const bool deviceBuild = d->buildFlags == RTR_BUILD_DEVICE_LBVH && totalPrims >= 16;
     rtr::BvhResult bvh; std::vector<float> xforms, nmats; uint32_t stackEntries = 0; size_t numTris = 0;
-    rc = flatten_and_build(d, bvh, xforms, nmats, &stackEntries, &numTris);
-    if (rc != RTR_OK) return rc;
+    if (!deviceBuild) {
+        rc = flatten_and_build(d, bvh, xforms, nmats, &stackEntries, &numTris);
+        if (rc != RTR_OK) return rc;
+    } else {
+        instance_tables(d->numInstances, d->instances, xforms, nmats);
+    }
 
     rtr_scene* s = new rtr_scene();
     s->ctx = ctx;
@@ -321,8 +423,10 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     static_assert(sizeof(RtrBvhNode) == 4 * sizeof(float4) && sizeof(RtrBvhTri) == 3 * sizeof(float4), "layout");
-    chk(s->nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() * 4, st));
-    chk(s->tris.upload(reinterpret_cast<const float4*>(bvh.tris.data()), bvh.tris.size() * 3, st));
+    if (!deviceBuild) {
+        chk(s->nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() * 4, st));
+        chk(s->tris.upload(reinterpret_cast<const float4*>(bvh.tris.data()), bvh.tris.size() * 3, st));
+    }
     chk(s->vertices.upload(d->vertices, d->numVertices, st));
     chk(s->indices.upload(d->indices, d->numIndices, st));
     chk(s->objects.upload(d->objects, d->numObjects, st));
@@ -355,9 +459,18 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     }
     s->numLights = d->numLights; s->numObjects = d->numObjects; s->numVertices = d->numVertices; s->numIndices = d->numIndices;
     if (d->numLights) s->hostLights.assign(d->lights, d->lights + d->numLights);
-    fill_stats(s->stats, bvh, stackEntries, numTris);
-    s->hostNodes.swap(bvh.nodes);
-    s->hostTris.swap(bvh.tris);
+    if (d->numInstances) s->hostInstances.assign(d->instances, d->instances + d->numInstances);
+    if (d->numMeshes) s->hostMeshes.assign(d->meshes, d->meshes + d->numMeshes);
+    if (d->numObjects) s->hostObjects.assign(d->objects, d->objects + d->numObjects);
+    if (deviceBuild) {
+        rc = build_on_device(s, d, totalPrims);
+        if (rc != RTR_OK) { delete s; return rc; }
+    } else {
+        fill_stats(s->stats, bvh, stackEntries, numTris);
+        s->hostNodes.swap(bvh.nodes);
+        s->hostTris.swap(bvh.tris);
+        s->numPrims = (uint32_t)s->hostTris.size(); s->numNodeSlots = (uint32_t)s->hostNodes.size();
+    }
 
     DeviceScene& dv = s->dev;
     dv.nodes = s->nodes.p; dv.tris = s->tris.p;
@@ -370,6 +483,88 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     dv.textures = s->texTable.p;
     dv.hdri = hdri;
     *out = s;
+    return RTR_OK;
+}
+
+/* A host-built tree gets its refit arrays on the first update: parent links from the node array, the
+ * canonical-primitive -> leaf-slot map from the ids stored in the triangle records. */
+static int ensure_refit_ready(rtr_scene* s) {
+    if (s->refitReady) return RTR_OK;
+    if (s->hostInstances.empty()) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: the scene has no instances");
+    hipStream_t st = s->ctx->stream;
+    const uint32_t numNodes = (uint32_t)s->hostNodes.size(), n = (uint32_t)s->hostTris.size();
+    std::vector<int32_t> parent(numNodes, -2);
+    parent[0] = -1;
+    std::vector<uint32_t> stack{0};
+    while (!stack.empty()) {
+        const uint32_t i = stack.back(); stack.pop_back();
+        for (int sl = 0; sl < 2; ++sl) {
+            const int32_t c = s->hostNodes[i].child[sl];
+            if (c >= 0 && parent[(size_t)c] == -2) { parent[(size_t)c] = (int32_t)((i << 1) | (uint32_t)sl); stack.push_back((uint32_t)c); }
+        }
+    }
+    /* canonical order = instances in creation order, primitives in mesh order */
+    std::vector<uint32_t> base(s->hostInstances.size(), 0);       /* by customIndex */
+    uint32_t acc = 0;
+    for (const RtrInstance& in : s->hostInstances) { base[in.customIndex] = acc; acc += s->hostMeshes[in.meshIndex].indexCount / 3u; }
+    if (acc != n) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: scene has no geometry to refit");
+    std::vector<uint32_t> slotOfPrim(n, 0);
+    for (uint32_t slot = 0; slot < n; ++slot) slotOfPrim[base[s->hostTris[slot].customIndex] + s->hostTris[slot].primitiveId] = slot;
+    HIP_TRY(s->parent.upload(parent.data(), parent.size(), st));
+    HIP_TRY(s->slotOfPrim.upload(slotOfPrim.data(), slotOfPrim.size(), st));
+    HIP_TRY(s->boxMin.alloc(n)); HIP_TRY(s->boxMax.alloc(n));
+    HIP_TRY(s->counters.alloc(numNodes)); HIP_TRY(s->depth.alloc(numNodes)); HIP_TRY(s->red.alloc(8));
+    s->numPrims = n; s->numNodeSlots = numNodes; s->refitReady = true;
+    return RTR_OK;
+}
+
+int rtr_scene_update_instances(rtr_scene* s, const RtrInstance* instances, uint32_t numInstances, const RtrAreaLightInfo* lights, uint32_t numLights) {
+    if (!s || (!instances && numInstances)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: null argument");
+    if (numInstances != s->hostInstances.size()) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: %u instances given, scene has %zu", numInstances, s->hostInstances.size());
+    if (lights && numLights != s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: %u lights given, scene has %u", numLights, s->numLights);
+    for (uint32_t i = 0; i < numInstances; ++i) {
+        if (instances[i].meshIndex != s->hostInstances[i].meshIndex || instances[i].customIndex != s->hostInstances[i].customIndex)
+            return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: instance %u changed mesh or customIndex; only transforms may change (a refit keeps the topology)", i);
+        for (int k = 0; k < 12; ++k)
+            if (!(instances[i].transform[k] > -3.0e38f && instances[i].transform[k] < 3.0e38f))
+                return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: instance %u has a non-finite transform", i);
+    }
+    if (lights)
+        for (uint32_t l = 0; l < numLights; ++l)
+            if (lights[l].vertexOffset != s->hostLights[l].vertexOffset || lights[l].indexOffset != s->hostLights[l].indexOffset ||
+                lights[l].numTriangles != s->hostLights[l].numTriangles)
+                return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: light %u changed its mesh", l);
+    if (s->hostTris.empty() || s->hostTris[0].customIndex == 0xffffffffu) return RTR_OK;     /* empty scene: nothing to refit */
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    int rc = ensure_refit_ready(s);
+    if (rc != RTR_OK) return rc;
+    hipStream_t st = s->ctx->stream;
+    rtr_scene_desc view{};
+    view.meshes = s->hostMeshes.data(); view.numMeshes = (uint32_t)s->hostMeshes.size();
+    view.numInstances = numInstances; view.objects = s->hostObjects.data(); view.numObjects = (uint32_t)s->hostObjects.size();
+    view.numLights = s->numLights;
+    std::vector<rtrdev::PrimRef> prims; std::vector<rtrdev::InstanceRef> refs;
+    make_prim_tables(&view, instances, prims, refs);
+    HIP_TRY(s->prims.upload(prims.data(), prims.size(), st));
+    HIP_TRY(s->instRefs.upload(refs.data(), refs.size(), st));
+    std::vector<float> xforms, nmats;
+    instance_tables(numInstances, instances, xforms, nmats);
+    HIP_TRY(hipMemcpyAsync(s->xforms.p, xforms.data(), xforms.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->nmats.p, nmats.data(), nmats.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    if (lights && numLights) HIP_TRY(hipMemcpyAsync(s->lights.p, lights, numLights * sizeof(RtrAreaLightInfo), hipMemcpyHostToDevice, st));
+    rtrdev::BvhInputs in{s->prims.p, s->instRefs.p, s->vertices.p, s->indices.p};
+    hipError_t e = rtrdev::bvh_refit(in, s->numPrims, s->numNodeSlots, device_arrays(s), st);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "device BVH refit: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(st));
+    /* keep the host mirror (rtr_scene_export_bvh) and the stats in step */
+    uint32_t red[8];
+    HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, s->hostNodes.size() * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s->hostTris.data(), s->tris.p, s->hostTris.size() * 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(red, s->red.p, sizeof red, hipMemcpyDeviceToHost));
+    float mabs; memcpy(&mabs, &red[6], 4);
+    s->stats.boxPad = (mabs > 1e-6f ? mabs : 1e-6f) * 3.814697265625e-06f;
+    s->hostInstances.assign(instances, instances + numInstances);
+    if (lights && numLights) s->hostLights.assign(lights, lights + numLights);
     return RTR_OK;
 }
 

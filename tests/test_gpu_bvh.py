@@ -1,0 +1,138 @@
+"""BVH build and refit on the device (kernels/rtr_bvh.hip) — invariants of the LBVH, image equality
+with the host-SAH tree (results do not depend on the tree), oracle parity with the device-built tree, and refit after
+instance transforms change (TLAS::updateTransform/refit counterpart)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from realtimeraytracer_amd import _abi as A
+from realtimeraytracer_amd import api, scenes
+from test_oracle_bvh import _check_bvh
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_flags(desc, flags):
+    d = A.rtr_scene_desc.from_buffer_copy(bytes(desc))
+    d.buildFlags = flags
+    return d
+
+
+def _render(ctx, scene, setup, p, frame_no=0):
+    rows = api.shard_rows(p.height, p.bandRows or 8, p.shardCount or 1)
+    frame = api.Frame(ctx, p.width, rows, p.images or A.IMAGES_FRAMEBUFFER)
+    api.render(scene, setup.camera, setup.scene_info(frame_no), p, frame)
+    return frame
+
+
+@pytest.mark.parametrize("which", ["cornell", "bunny", "sponza", "room"])
+def test_device_lbvh_build(gpu_ctx, oracle, scene_cache, which):
+    W, H = 320, 184
+    s = {"cornell": lambda: scenes.cornell_box(W, H), "bunny": lambda: scenes.bunny_class(W, H, subdiv=5),
+         "sponza": lambda: scenes.sponza_class(W, H), "room": lambda: scenes.textured_room(W, H)}[which]()
+    sah = api.Scene(gpu_ctx, s.desc)
+    lbvh = api.Scene(gpu_ctx, _with_flags(s.desc, A.BUILD_DEVICE_LBVH))
+    st = lbvh.stats()
+    assert st.numTriangles == sah.stats().numTriangles
+    if st.numTriangles >= 16:                        # tiny scenes (the 14-triangle room) fall back to the host builder
+        assert st.numNodes == st.numTriangles - 1
+    assert st.maxLeafSize <= 4 and st.maxDepth <= 64 and st.stackEntries >= st.maxDepth
+    nodes, tris = lbvh.export_bvh()
+    _check_bvh(s.desc, st, nodes, tris)
+    p = api.make_params(W, H, spp=2, collect_stats=1)
+    f_sah, f_lbvh = _render(gpu_ctx, sah, s, p), _render(gpu_ctx, lbvh, s, p)
+    assert np.array_equal(f_sah.download(), f_lbvh.download()), "image must not depend on which builder made the tree"
+    ref = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=(nodes, tris), threads=16)
+    assert np.array_equal(f_lbvh.download(), ref.images[A.IMAGE_SHADOWED])
+    g = f_lbvh.stats()
+    assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits)
+    # deterministic: a second device build gives the same bytes
+    n2, t2 = api.Scene(gpu_ctx, _with_flags(s.desc, A.BUILD_DEVICE_LBVH)).export_bvh()
+    assert bytes(n2) == bytes(nodes) and bytes(t2) == bytes(tris)
+
+
+def _moved(setup, which, delta, scale=1.0):
+    """copies of the instance list / light list with instance `which` translated by delta (and uniformly scaled)"""
+    inst = [A.RtrInstance.from_buffer_copy(bytes(i)) for i in setup.host.instances()]
+    m = np.array(inst[which].transform[:], np.float32).reshape(3, 4)
+    m[:, :3] *= np.float32(scale)
+    m[:, 3] += np.array(delta, np.float32)
+    for k, v in enumerate(m.reshape(-1)):
+        inst[which].transform[k] = float(v)
+    lights = [A.RtrAreaLightInfo.from_buffer_copy(bytes(l)) for l in setup.host.lightInfos()]
+    if which < len(lights):                      # a light instance: its LightInfo.transform is the same matrix, column-major
+        cm = np.zeros((4, 4), np.float32); cm[:3, :] = m; cm[3, 3] = 1
+        for k, v in enumerate(cm.T.reshape(-1)):
+            lights[which].transform[k] = float(v)
+    return inst, lights
+
+
+@pytest.mark.parametrize("flags", [A.BUILD_HOST_SAH, A.BUILD_DEVICE_LBVH])
+def test_refit_matches_fresh_build(gpu_ctx, oracle, scene_cache, flags):
+    W, H = 256, 160
+    s = scenes.cornell_box(W, H)
+    scene = api.Scene(gpu_ctx, _with_flags(s.desc, flags))
+    p = api.make_params(W, H, spp=1, collect_stats=1)
+    before = _render(gpu_ctx, scene, s, p).download()
+    # move the tall block (last instance) and the area light (instance 0), shrink the short block
+    inst, lights = _moved(s, len(s.host.instances()) - 1, (-120.0, 0.0, -60.0))
+    tmp = type("T", (), {})()
+    tmp.host = type("H", (), {"instances": lambda self=None: inst, "lightInfos": lambda self=None: lights})()
+    inst, lights = _moved(tmp, 0, (40.0, -30.0, 20.0))
+    tmp.host = type("H", (), {"instances": lambda self=None: inst, "lightInfos": lambda self=None: lights})()
+    inst, lights = _moved(tmp, len(inst) - 2, (15.0, 0.0, -25.0), scale=0.8)
+    scene.update_instances(inst, lights)
+    after = _render(gpu_ctx, scene, s, p)
+    img = after.download()
+    assert not np.array_equal(img, before)
+    # the same scene built from scratch with the new transforms
+    d2 = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc))
+    iarr = (A.RtrInstance * len(inst))(*inst)
+    larr = (A.RtrAreaLightInfo * len(lights))(*lights)
+    d2.instances = C.cast(iarr, C.POINTER(A.RtrInstance))
+    d2.lights = C.cast(larr, C.POINTER(A.RtrAreaLightInfo))
+    fresh = api.Scene(gpu_ctx, d2)
+    assert np.array_equal(_render(gpu_ctx, fresh, s, p).download(), img), "refit image != image of a fresh build"
+    # oracle on the refitted tree (exported from the device) and by brute force
+    nodes, tris = scene.export_bvh()
+    _check_bvh(d2, scene.stats(), nodes, tris)
+    ref = oracle.render(d2, s.camera, s.scene_info(0), p, bvh=(nodes, tris), threads=8)
+    assert np.array_equal(img, ref.images[A.IMAGE_SHADOWED])
+    assert after.stats().numNodeVisits == ref.stats.numNodeVisits
+    brute = oracle.render(d2, s.camera, s.scene_info(0), p, bvh=None, threads=8)
+    assert np.array_equal(img, brute.images[A.IMAGE_SHADOWED])
+    # refit back to the original transforms restores the original image bit for bit
+    scene.update_instances(s.host.instances(), s.host.lightInfos())
+    assert np.array_equal(_render(gpu_ctx, scene, s, p).download(), before)
+
+
+def test_update_instances_rejects_topology_changes(gpu_ctx, scene_cache):
+    s = scenes.cornell_box(64, 64)
+    scene = api.Scene(gpu_ctx, s.desc)
+    inst = [A.RtrInstance.from_buffer_copy(bytes(i)) for i in s.host.instances()]
+    with pytest.raises(api.RtrError):
+        scene.update_instances(inst[:-1])
+    inst[3].meshIndex = 1
+    with pytest.raises(api.RtrError):
+        scene.update_instances(inst)
+    inst = [A.RtrInstance.from_buffer_copy(bytes(i)) for i in s.host.instances()]
+    inst[2].transform[3] = float("nan")
+    with pytest.raises(api.RtrError):
+        scene.update_instances(inst)
+
+
+def test_lbvh_sponza_1080p_counts(gpu_ctx, scene_cache):
+    """Quality of the device-built tree on the headline workload: same image, more node visits than SAH (reported)."""
+    W, H = 1920, 1080
+    s = scenes.sponza_class(W, H)
+    p = api.make_params(W, H, collect_stats=1)
+    sah = api.Scene(gpu_ctx, s.desc)
+    lbvh = api.Scene(gpu_ctx, _with_flags(s.desc, A.BUILD_DEVICE_LBVH))
+    a, b = _render(gpu_ctx, sah, s, p), _render(gpu_ctx, lbvh, s, p)
+    assert np.array_equal(a.download(), b.download())
+    ra, rb = a.stats(), b.stats()
+    assert ra.numRays == rb.numRays
+    print(f"\nSAH: build {sah.stats().buildMs:.1f} ms, {ra.numNodeVisits / ra.numRays:.1f} nodes/ray, {ra.totalMs:.2f} ms/frame; "
+          f"LBVH: build {lbvh.stats().buildMs:.1f} ms (incl. upload + read-back), {rb.numNodeVisits / rb.numRays:.1f} nodes/ray, {rb.totalMs:.2f} ms/frame")
+    assert rb.numNodeVisits < 4 * ra.numNodeVisits
