@@ -188,14 +188,31 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
  * oracle's trace_bvh() — so visibility bits AND work counters are unchanged. */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
 constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
-constexpr uint32_t kRefillDefault = 16;    /* idle lanes that trigger a refill */
+constexpr uint32_t kRefillDefault = 28;    /* idle lanes that trigger a refill */
+
+/* Hybrid stack: the first STACK entries of a lane live in LDS (lane-interleaved, conflict-free); deeper entries
+ * spill to a lane-interleaved global array.  Ordered traversal rarely holds more than ~10 entries, so STACK = 16
+ * (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum) almost never spills, where the
+ * depth-bound 32-entry stack limited the CU to 20 waves (measured: 3.82 -> 3.64 ms on the bench frame). */
+template <int STACK>
+struct HybridStack {
+    int32_t* lds; int32_t* spill; size_t stride;
+    __device__ __forceinline__ void push(int sp, int32_t v) const {
+        if (sp < STACK) lds[sp * kBlock] = v;
+        else spill[(size_t)(sp - STACK) * stride] = v;
+    }
+    __device__ __forceinline__ int32_t pop(int sp) const {
+        return sp < STACK ? lds[sp * kBlock] : spill[(size_t)(sp - STACK) * stride];
+    }
+};
 
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
                                                          const uint32_t* __restrict__ count, uint32_t* nextBatch,
-                                                         uint8_t* __restrict__ vis, Counters* stats, uint32_t kBatch, uint32_t kRefill) {
+                                                         uint8_t* __restrict__ vis, Counters* stats, uint32_t kBatch, uint32_t kRefill,
+                                                         int32_t* spill, uint32_t kInnerMin) {
     __shared__ int32_t s_stack[STACK * kBlock];
-    int32_t* stack = s_stack + threadIdx.x;
+    const HybridStack<STACK> stack{s_stack + threadIdx.x, spill + (size_t)blockIdx.x * kBlock + threadIdx.x, (size_t)gridDim.x * kBlock};
     const uint32_t n = *count;
     LocalStats st;
     uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
@@ -242,8 +259,16 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
             if (exhausted) break;
             continue;
         }
-        /* ---- inner nodes: until every live lane is on a leaf ---- */
-        while (__ballot(cur >= 0) != 0ull) {
+        /* ---- inner nodes ("while-while" with an early exit) ----
+         * Keep descending while more than kInnerMin lanes are on inner nodes, or while nobody has a leaf to test; then
+         * test the leaves that are waiting.  Waiting for EVERY lane to reach a leaf (kInnerMin = 0) left the early
+         * lanes idle for the stragglers: 3.64 ms -> 3.0 ms at kInnerMin = 20 (profiles/r01/sweep_inner.log).  Testing one
+         * triangle per step instead of a whole leaf was tried and was 3-5 % slower.  Every pass of the outer loop visits
+         * a node or tests a leaf for at least one lane (or exits), so all waves drain. */
+        for (;;) {
+            const unsigned long long innerMask = __ballot(cur >= 0);
+            if (innerMask == 0ull) break;
+            if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
             if (cur >= 0) {
                 const float4* nd = sc.nodes + (size_t)cur * 4;
                 const float4 a = nd[0], b = nd[1], c = nd[2];
@@ -257,15 +282,15 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;
                 const int32_t farC = swap ? ch.x : ch.y;
-                if (hl && hr) { stack[sp * kBlock] = farC; ++sp; cur = nearC; }
+                if (hl && hr) { stack.push(sp, farC); ++sp; cur = nearC; }
                 else if (hl) cur = ch.x;
                 else if (hr) cur = ch.y;
-                else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+                else if (sp > 0) { --sp; cur = stack.pop(sp); }
                 else { vis[slot] = 0; cur = kDone; }
             }
         }
         /* ---- leaves ---- */
-        if (cur != kDone) {
+        if (cur < 0 && cur != kDone) {
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             bool hit = false;
@@ -281,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 }
             }
             if (hit) { vis[slot] = 1; cur = kDone; }
-            else if (sp > 0) { --sp; cur = stack[sp * kBlock]; }
+            else if (sp > 0) { --sp; cur = stack.pop(sp); }
             else { vis[slot] = 0; cur = kDone; }
         }
     }
@@ -366,20 +391,19 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (ev) hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(k_shadow_gen, dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount);
     if (ev) hipEventRecord(ev[2], s);
-    /* persistent waves: as many workgroups as stay resident (LDS stack: STACK*1 KiB per workgroup of the
-     * 160 KiB per CU, at most 8 x 256 threads per CU), each pulling batches until the queue is empty */
-    uint32_t perCU = 160u / (uint32_t)STACK;
-    if (perCU > 8u) perCU = 8u;
-    if (perCU == 0u) perCU = 1u;
+    /* persistent waves: as many workgroups as stay resident (16 KiB of LDS stack per workgroup -> 8 per CU, the
+     * 32-wave hardware maximum), each pulling batches until the queue is empty */
     const size_t maxRays = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
-    uint32_t tblocks = 256u * perCU;
+    uint32_t tblocks = 256u * 8u;
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
-    if (stats) hipLaunchKernelGGL((k_shadow_trace<STACK, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill);
-    else hipLaunchKernelGGL((k_shadow_trace<STACK, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill);
+    static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 20u, 0u, 63u);
+    (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
+    if (stats) hipLaunchKernelGGL((k_shadow_trace<16, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
+    else hipLaunchKernelGGL((k_shadow_trace<16, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
     if (ev) hipEventRecord(ev[3], s);
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
