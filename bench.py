@@ -242,23 +242,25 @@ def main():
         from oracle import oracle_py as O
         threads = min(os.cpu_count() or 1, 16)
         bvh = scene.export_bvh()
-        sample_shards = 2
+        # bounded sample: the whole frame, twice (best of two) — about 20-30 core-seconds of oracle work on the 16 host cores
+        sample_shards = 1
         pc = api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=0,
                              shard_count=sample_shards, collect_stats=1)
-        t1 = time.perf_counter()
-        r = O.render(setup.desc, setup.camera, setup.scene_info(0), pc, bvh=bvh, threads=threads)
-        dt = time.perf_counter() - t1
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            r = O.render(setup.desc, setup.camera, setup.scene_info(0), pc, bvh=bvh, threads=threads)
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        dt = best
         out["cpu_baseline"] = {"value": round(r.stats.numRays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                               "sample": f"every {sample_shards}nd 8-row band of the same frame ({r.stats.numRays} rays, {dt:.1f} s), scalar C++ oracle, "
+                               "sample": f"the same frame, all {r.stats.numRays} rays, best of 2 runs ({dt:.2f} s each), scalar C++ oracle (oracle/), "
                                          f"{threads} std::threads over rows, -O2 -ffp-contract=off"}
         if args.verify:
-            ys = mgpu.global_rows_of_shard(H, args.band_rows, sample_shards, 0)
-            # the verify render used frame index = last step; re-render that frame on the GPU for the comparison
-            api.render(scene, setup.camera, setup.scene_info(0), params(0), frame)
+            api.render(scene, setup.camera, setup.scene_info(0), params(0), frame)     # frame 0 again, the one the oracle rendered
             gpu = local.cpu().numpy().view(np.uint32)
-            ok = ys >= 0
-            bad = int((gpu[ys[ok]] != r.images[A.IMAGE_SHADOWED][ok]).sum())
-            out["verify"] = {"rows_checked": int(ok.sum()), "pixels_differing": bad}
+            bad = int((gpu != r.images[A.IMAGE_SHADOWED]).sum())
+            out["verify"] = {"pixels_checked": int(gpu.size), "pixels_differing_vs_oracle": bad}
     elif rank == 0:
         out["cpu_baseline"] = None
         # N > 1: the assembled frame of the last step must equal the same frame rendered unsharded on this GPU

@@ -12,6 +12,7 @@ struct Workspace {
     float4*   rayQueue = nullptr;    /* 2 x float4 per queued shadow ray: (o.xyz,tmax) (d.xyz,bits(slot)) */
     uint8_t*  vis = nullptr;         /* per slot: 1 = occluded */
     uint32_t* queueCount = nullptr;  /* device counter of queued rays */
+    uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail (capacity: one per slot) */
     int32_t*  spill = nullptr;       /* traversal-stack overflow of k_shadow_trace: 48 entries x (2048 workgroups x 256 lanes) */
     size_t    capPixelSamples = 0;
     size_t    capRays = 0;

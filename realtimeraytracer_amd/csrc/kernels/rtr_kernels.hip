@@ -190,10 +190,15 @@ constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first
 constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
 constexpr uint32_t kRefillDefault = 28;    /* idle lanes that trigger a refill */
 
-/* Hybrid stack: the first STACK entries of a lane live in LDS (lane-interleaved, conflict-free); deeper entries
- * spill to a lane-interleaved global array.  Ordered traversal rarely holds more than ~10 entries, so STACK = 16
- * (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum) almost never spills, where the
- * depth-bound 32-entry stack limited the CU to 20 waves (measured: 3.82 -> 3.64 ms on the bench frame). */
+/* Stack policy of the persistent kernel.  Ordered traversal rarely holds more than ~10 entries, so every lane gets 16
+ * LDS entries (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum; the depth-bound 32-entry
+ * stack limited the CU to 20 waves).  What happens to the rare ray that needs a 17th entry:
+ *   production kernel (EXACT = false): the ray is abandoned — its queue index goes to an overflow list and
+ *                    k_shadow_tail finishes it from scratch with a full-depth stack — so the hot loop is pure LDS with
+ *                    no spill branch (an LDS/global select made the compiler emit flat_load for EVERY pop);
+ *   counting kernel  (EXACT = true): deeper entries spill to a lane-interleaved global array, so every ray is traced in
+ *                    one go and the work counters stay exactly those of the oracle.
+ * Both produce the same visibility bits. */
 template <int STACK>
 struct HybridStack {
     int32_t* lds; int32_t* spill; size_t stride;
@@ -210,9 +215,11 @@ template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
                                                          const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                          uint8_t* __restrict__ vis, Counters* stats, uint32_t kBatch, uint32_t kRefill,
-                                                         int32_t* spill, uint32_t kInnerMin) {
+                                                         int32_t* spill, uint32_t kInnerMin, uint32_t* overflow) {
+    constexpr bool EXACT = STATS;
     __shared__ int32_t s_stack[STACK * kBlock];
-    const HybridStack<STACK> stack{s_stack + threadIdx.x, spill + (size_t)blockIdx.x * kBlock + threadIdx.x, (size_t)gridDim.x * kBlock};
+    int32_t* lds = s_stack + threadIdx.x;
+    const HybridStack<STACK> hstack{lds, spill + (size_t)blockIdx.x * kBlock + threadIdx.x, (size_t)gridDim.x * kBlock};
     const uint32_t n = *count;
     LocalStats st;
     uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     int sp = 0;
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), idir = rtr_mk(0, 0, 0), ood = rtr_mk(0, 0, 0);
     float tmax = 0.f;
-    uint32_t slot = 0;
+    uint32_t slot = 0, rayIndex = 0;
     const float tmin = 0.001f;
 
     for (;;) {
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const uint32_t avail = batchEnd - batchPos;
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (cur == kDone && prefix < avail) {
-                    const size_t i = (size_t)(batchPos + prefix) * 2;
+                    rayIndex = batchPos + prefix;
+                    const size_t i = (size_t)rayIndex * 2;
                     const float4 a = queue[i], b = queue[i + 1];
                     o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
                     if (STATS) { st.rays++; st.shadow++; }
@@ -273,6 +281,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const float4* nd = sc.nodes + (size_t)cur * 4;
                 const float4 a = nd[0], b = nd[1], c = nd[2];
                 const int2 ch = *reinterpret_cast<const int2*>(nd + 3);
+                /* speculative read of the stack top next to the node loads: its LDS latency is hidden and the pop below
+                 * needs no load of its own (index clamped so the address is always valid) */
+                int32_t top = 0;
+                if (!EXACT) top = lds[(sp > 0 ? sp - 1 : 0) * kBlock];
                 if (STATS) { st.nodes++; st.shadowNodes++; }
                 const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {a.w, b.x, b.y};
                 const float rmn[3] = {b.z, b.w, c.x}, rmx[3] = {c.y, c.z, c.w};
@@ -282,11 +294,25 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;
                 const int32_t farC = swap ? ch.x : ch.y;
-                if (hl && hr) { stack.push(sp, farC); ++sp; cur = nearC; }
-                else if (hl) cur = ch.x;
-                else if (hr) cur = ch.y;
-                else if (sp > 0) { --sp; cur = stack.pop(sp); }
-                else { vis[slot] = 0; cur = kDone; }
+                if (EXACT) {
+                    if (hl && hr) { hstack.push(sp, farC); ++sp; cur = nearC; }
+                    else if (hl) cur = ch.x;
+                    else if (hr) cur = ch.y;
+                    else if (sp > 0) { --sp; cur = hstack.pop(sp); }
+                    else { vis[slot] = 0; cur = kDone; }
+                } else {
+                    const bool both = hl && hr, none = !(hl || hr);
+                    int32_t next = both ? nearC : (hl ? ch.x : ch.y);
+                    if (both) {
+                        if (sp < STACK) { lds[sp * kBlock] = farC; ++sp; }
+                        else { overflow[1u + atomicAdd(overflow, 1u)] = rayIndex; next = kDone; }   /* finished by k_shadow_tail */
+                    }
+                    if (none) {
+                        if (sp > 0) { --sp; next = top; }
+                        else { vis[slot] = 0; next = kDone; }
+                    }
+                    cur = next;
+                }
             }
         }
         /* ---- leaves ---- */
@@ -306,11 +332,28 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 }
             }
             if (hit) { vis[slot] = 1; cur = kDone; }
-            else if (sp > 0) { --sp; cur = stack.pop(sp); }
+            else if (sp > 0) { --sp; cur = EXACT ? hstack.pop(sp) : lds[sp * kBlock]; }
             else { vis[slot] = 0; cur = kDone; }
         }
     }
     if (STATS) st.flush(stats);
+}
+
+/* Finishes the rays the production k_shadow_trace abandoned (stack deeper than its 16 LDS entries): one ray per lane,
+ * full-depth 64-entry LDS stack, plain trace<true>().  Usually zero rays; the grid is small and exits at once. */
+__global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const float4* __restrict__ queue, const uint32_t* __restrict__ overflow,
+                                                        uint8_t* __restrict__ vis) {
+    __shared__ int32_t s_stack[64 * kBlock];
+    int32_t* stack = s_stack + threadIdx.x;
+    const uint32_t n = overflow[0];
+    LocalStats st;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t r = overflow[1u + i];
+        const float4 a = queue[(size_t)r * 2], b = queue[(size_t)r * 2 + 1];
+        HitRec h;
+        const bool occ = trace<true, false, kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
+        vis[__float_as_uint(b.w)] = occ ? 1 : 0;
+    }
 }
 
 /* ---- wavefront stage 4: resolve (shade with looked-up visibility, tonemap, store) ------------- */
@@ -385,6 +428,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const uint32_t blocks = (padded_pixels(ra) + kBlock - 1) / kBlock;
     hipError_t e;
     if ((e = hipMemsetAsync(ws.queueCount, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] batch cursor */
+    if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
     if (ev) hipEventRecord(ev[0], s);
     if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
     else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
@@ -402,8 +446,11 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 20u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
-    if (stats) hipLaunchKernelGGL((k_shadow_trace<16, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
-    else hipLaunchKernelGGL((k_shadow_trace<16, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
+    if (stats) hipLaunchKernelGGL((k_shadow_trace<16, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin, ws.overflow);
+    else {
+        hipLaunchKernelGGL((k_shadow_trace<16, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin, ws.overflow);
+        hipLaunchKernelGGL(k_shadow_tail, dim3(64), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis);
+    }
     if (ev) hipEventRecord(ev[3], s);
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);

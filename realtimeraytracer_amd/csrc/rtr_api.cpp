@@ -116,6 +116,7 @@ struct rtr_frame {
     DevBuf<uint32_t> hitCustom, queueCount;
     DevBuf<uint8_t> vis;
     DevBuf<int32_t> spill;
+    DevBuf<uint32_t> overflow;
     DevBuf<Counters> counters;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evMega[2] = {nullptr, nullptr};
@@ -751,12 +752,12 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     hipError_t e;
     if (wave) {
         if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); }
-        if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); }
+        if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); HIP_TRY(f->overflow.alloc(nSlots + 1)); }
         if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(2));
         if (!f->spill.p) HIP_TRY(f->spill.alloc((size_t)48 * 2048 * 256));      /* (64 - 16) entries x the largest persistent grid */
         Workspace ws;
         ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
-        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p;
+        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p; ws.overflow = f->overflow.p;
         e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev);
     } else {
         (void)hipEventRecord(f->evMega[0], st);
