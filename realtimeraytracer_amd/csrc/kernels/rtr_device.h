@@ -89,13 +89,17 @@ __device__ __forceinline__ float4 sample_tex(const DeviceTexture& tx, float u, f
     int x1 = x0 + 1, y1 = y0 + 1;
     if (x1 >= W) x1 -= W;
     if (y1 >= H) y1 -= H;
-    const uint8_t* p = tx.pixels;
+    /* the pointer comes out of a table in memory, so the compiler cannot know its address space and would emit
+     * flat_load (slower, and counted on both vmcnt and lgkmcnt); texels always live in global memory */
+    typedef const __attribute__((address_space(1))) uint8_t* gptr8;
+    typedef const __attribute__((address_space(1))) uint32_t* gptr32;
+    const gptr8 p = (gptr8)(uintptr_t)tx.pixels;
     float o[4];
     if (ch == 4) {
-        const uint32_t q00 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y0 * W + x0) * 4);
-        const uint32_t q10 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y0 * W + x1) * 4);
-        const uint32_t q01 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y1 * W + x0) * 4);
-        const uint32_t q11 = *reinterpret_cast<const uint32_t*>(p + ((size_t)y1 * W + x1) * 4);
+        const uint32_t q00 = *(gptr32)(p + ((size_t)y0 * W + x0) * 4);
+        const uint32_t q10 = *(gptr32)(p + ((size_t)y0 * W + x1) * 4);
+        const uint32_t q01 = *(gptr32)(p + ((size_t)y1 * W + x0) * 4);
+        const uint32_t q11 = *(gptr32)(p + ((size_t)y1 * W + x1) * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float t00 = (float)((q00 >> (8 * k)) & 0xffu) / 255.0f, t10 = (float)((q10 >> (8 * k)) & 0xffu) / 255.0f;

@@ -55,7 +55,8 @@ struct CountPolicy {
 
 struct EmitPolicy {
     static constexpr bool kShade = false;
-    float4* queue; volatile uint32_t* waveOffset; uint32_t base; uint32_t slot;
+    typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;     /* keeps the access a ds_read/ds_write, not a flat_load */
+    float4* queue; lds_word waveOffset; uint32_t base; uint32_t slot;
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
-        EmitPolicy pol{queue, &s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
+        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
         shade_sample<EmitPolicy, false>(sc, ra, px, py, h, primary_dir(ra, px, py, i), false, acc, pol, st);
     }
 }
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
          * Keep descending while more than kInnerMin lanes are on inner nodes, or while nobody has a leaf to test; then
          * test the leaves that are waiting.  Waiting for EVERY lane to reach a leaf (kInnerMin = 0) left the early
          * lanes idle for the stragglers: 3.64 ms -> 3.0 ms at kInnerMin = 20 (profiles/r01/sweep_inner.log).  Testing one
-         * triangle per step instead of a whole leaf was tried and was 3-5 % slower.  Every pass of the outer loop visits
+         * triangle per step instead of a whole leaf was tried and was 3-5 % slower; two or three node visits per exit check
+         * changed nothing (the scalar loop control overlaps other waves' vector work).  Every pass of the outer loop visits
          * a node or tests a leaf for at least one lane (or exits), so all waves drain. */
         for (;;) {
             const unsigned long long innerMask = __ballot(cur >= 0);
