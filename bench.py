@@ -46,6 +46,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + RTR_BENCH_SAME_DEVICE=1 rehearses the N>1 control flow with several ranks on ONE GPU (shards staged through host memory)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N",
+                    help="single-GPU rehearsal of what ONE rank does in an N-GPU run: renders shard 0 of N with the same two-stream "
+                         "frame pipelining, without the gather (the printed value is this rank's rays/s, not a job total)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames pipelined on separate streams (0 = default: 3 at N=1, 4 when the frame is sharded over N>1 GPUs; 1 = one frame at a time)")
+    ap.add_argument("--isolated-frames", type=int, default=10,
+                    help="after the timed region, render this many frames ONE AT A TIME to report per-kernel durations free of "
+                         "cross-frame overlap (0 = skip; profiles/run_rocprof.sh skips it so rocprof's averages cover the timed launches only)")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
     args = ap.parse_args()
 
@@ -78,23 +85,33 @@ def main():
 
     W, H, S = args.width, args.height, args.spp
     setup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
-    ctx = api.Context(local_rank)
-    stream = torch.cuda.Stream(device=device)
-    ctx.set_stream(stream.cuda_stream)
+    emu = args.emulate_rank_of if (world == 1 and args.emulate_rank_of > 1) else 0
+    nshards = emu if emu else world
+    # Several frames are kept in flight on separate streams (one context each, ONE shared scene): the tails of one
+    # frame's latency-bound kernels, its small kernels and its RCCL gather overlap the next frames' kernels.  At N=1 that
+    # is worth ~12 % (the 1.1 ms of primary / queue-build / resolve work hides under the traversal kernel's tail); for a
+    # 1/8-frame shard no single kernel can fill the GPU (259 k primary rays for 524 k lane slots), so it is where the
+    # strong scaling comes from (one rank of 8: 0.93 -> 0.53 ms per frame).  Frames are independent, so results are
+    # unchanged; the per-launch HIP-event durations stay valid for the dominant kernel at <= 3 frames in flight.
+    nbuf = args.frames_in_flight or (4 if nshards > 1 else 3)
+    ctxs = [api.Context(local_rank) for _ in range(nbuf)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(nbuf)]
+    for c, st_ in zip(ctxs, streams):
+        c.set_stream(st_.cuda_stream)
+    ctx, stream = ctxs[0], streams[0]
     scene = api.Scene(ctx, setup.desc)
     sstats = scene.stats()
-    rows = api.shard_rows(H, args.band_rows, world)
-    # N > 1 double-buffers the shard framebuffer so the RCCL gather of frame i overlaps the render of frame i+1
-    nbuf = 2 if world > 1 else 1
-    frames = [api.Frame(ctx, W, rows, A.IMAGES_FRAMEBUFFER) for _ in range(nbuf)]
+    rows = api.shard_rows(H, args.band_rows, nshards)
+    frames = [api.Frame(ctxs[b], W, rows, A.IMAGES_FRAMEBUFFER) for b in range(nbuf)]
     locals_ = [torch.zeros((rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)]   # RGBA8 framebuffer of this shard
     for fr, lo in zip(frames, locals_):
         fr.bind_external(A.IMAGE_SHADOWED, lo.data_ptr(), lo.numel() * 4)
     frame, local = frames[0], locals_[0]
     gathered = [torch.zeros((world, rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if (rank == 0 and world > 1) else None
-    full = torch.zeros((H, W), dtype=torch.int32, device=device) if rank == 0 else None
+    fulls = [torch.zeros((H, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if rank == 0 else None
+    full = fulls[0] if fulls else None
 
-    def params(collect=0, shard_index=rank, shard_count=world):
+    def params(collect=0, shard_index=rank, shard_count=nshards):
         return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=shard_index,
                                shard_count=shard_count, collect_stats=collect, pipeline=args.pipeline)
 
@@ -120,7 +137,7 @@ def main():
     def gather_async(buf):
         """the one exchange step (RCCL over xGMI): every rank's shard -> rank 0, asynchronous w.r.t. the render stream"""
         if args.backend == "gloo":            # rehearsal only: stage through host memory
-            stream.synchronize()
+            streams[buf].synchronize()
             host = locals_[buf].cpu()
             if rank == 0:
                 hosts = [torch.empty_like(host) for _ in range(world)]
@@ -134,33 +151,45 @@ def main():
         return dist.gather(locals_[buf], gather_list=None, dst=0, async_op=True)
 
     def finish(buf):
-        """stream-level wait for gather `buf`, then (rank 0) de-interleave it into the full frame"""
+        """stream-level wait for gather `buf`, then (rank 0) de-interleave it into that buffer's full frame"""
         if works[buf] is None:
             return
         works[buf].wait()
         works[buf] = None
-        if rank == 0:
-            api.deinterleave_bands(ctx, gathered[buf].data_ptr(), full.data_ptr(), W, H, args.band_rows, world)
+        if rank == 0 and world > 1:
+            api.deinterleave_bands(ctxs[buf], gathered[buf].data_ptr(), fulls[buf].data_ptr(), W, H, args.band_rows, world)
+
+    last_buf = [0]
+
+    inflight = [False] * nbuf
+
+    def collect(buf):
+        """host-side join of the frame that used `buf` (the other frames stay in flight) + its per-launch HIP-event times"""
+        if not inflight[buf]:
+            return
+        frames[buf].wait()
+        inflight[buf] = False
+        st = frames[buf].stats()
+        kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
+        kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
 
     def step(i):
         info = setup.scene_info(i)
-        with torch.cuda.stream(stream):
-            if world == 1:
-                api.render(scene, setup.camera, info, p_run, frame)             # synchronous: per-launch event times
-                st = frame.stats()
-                kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
-                kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
-            else:
-                b = i & 1
-                finish(b)                                   # frame i-2 (same buffers) fully consumed
-                api.render(scene, setup.camera, info, p_run, frames[b], asynchronous=True)
-                works[b] = gather_async(b)                  # overlaps the next frame's kernels
-                finish(1 - b)                               # frame i-1: its gather ran under this frame's render
+        b = i % nbuf
+        last_buf[0] = b
+        with torch.cuda.stream(streams[b]):
+            collect(b)                                  # frame i-nbuf: done long ago unless the host runs ahead
+            finish(b)                                   # its gather (stream-level wait) + de-interleave on rank 0
+            api.render(scene, setup.camera, info, p_run, frames[b], asynchronous=True)
+            inflight[b] = True
+            if world > 1:
+                works[b] = gather_async(b)              # RCCL gather to rank 0; runs under the other streams' kernels
 
     def drain():
-        if world > 1:
-            with torch.cuda.stream(stream):
-                finish(0); finish(1)
+        for b in range(nbuf):
+            with torch.cuda.stream(streams[b]):
+                collect(b)
+                finish(b)
 
     def sync_all():
         if world > 1:
@@ -180,14 +209,25 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        last = frames[(args.warmup + args.steps - 1) & 1]
-        last.wait()
-        st = last.stats()    # last step's launches (async mode keeps only those)
-        kern.update({"primary": st.primaryMs, "shadow_gen": st.shadowGenMs, "shadow_trace": st.shadowTraceMs,
-                     "resolve": st.resolveMs, "n": 1})
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # After the timed region: the same frames ONE AT A TIME, so every kernel has the GPU to itself.  With several frames in
+    # flight a launch's HIP-event bracket also contains the time it queued behind / shared CUs with the neighbouring frames'
+    # kernels (k_shadow_trace: ~6 ms bracket, 3.5 ms dispatch begin->end in rocprof, 2.93 ms alone), so the per-kernel cost
+    # and the roofline are taken from this pass; rocprofv3 of `--frames-in-flight 1` reproduces it (profiles/).
+    kern_iso, iso_ms_per_frame = None, None
+    if nbuf > 1 and args.isolated_frames > 0:
+        kern_iso = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0}
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for j in range(args.isolated_frames):
+            api.render(scene, setup.camera, setup.scene_info(args.warmup + j), p_run, frames[0])
+            st = frames[0].stats()
+            kern_iso["primary"] += st.primaryMs / args.isolated_frames; kern_iso["shadow_gen"] += st.shadowGenMs / args.isolated_frames
+            kern_iso["shadow_trace"] += st.shadowTraceMs / args.isolated_frames; kern_iso["resolve"] += st.resolveMs / args.isolated_frames
+        iso_ms_per_frame = (time.perf_counter() - t1) * 1e3 / args.isolated_frames
 
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     mrays = rays_per_frame * args.steps / elapsed / 1e6
@@ -195,7 +235,8 @@ def main():
     out = None
     if rank == 0:
         n = max(kern["n"], 1)
-        trace_ms = kern["shadow_trace"] / n
+        bracket_ms = kern["shadow_trace"] / n                      # in-region HIP-event bracket
+        trace_ms = kern_iso["shadow_trace"] if kern_iso else bracket_ms
         trace_bytes = fs.shadowTraceBytes                         # rank 0's launch
         roofline = None
         if pipeline_used == 2 and trace_ms > 0:
@@ -212,6 +253,9 @@ def main():
             roofline = {"bound": "hbm", "kernel": "k_shadow_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(trace_bytes), "avg_launch_ms": round(trace_ms, 4),
+                        "avg_launch_ms_source": (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
+                                                 if kern_iso else "HIP events on the launch stream over the timed region"),
+                        "in_flight_event_bracket_ms": round(bracket_ms, 4) if kern_iso else None,
                         "bvh_layout_version": int(sstats.bvhLayoutVersion)}
         elif trace_ms == 0 and kern["primary"] > 0:
             mk_ms = kern["primary"] / n
@@ -232,13 +276,20 @@ def main():
                        "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries),
                                "build_ms": round(float(sstats.buildMs), 1)}},
             "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
-            "kernels_ms": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
+            "frames_in_flight": nbuf,
+            "kernels_ms": {k: round(v, 4) for k, v in kern_iso.items()} if kern_iso else {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
+            "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"} if kern_iso else None,
+            "one_frame_at_a_time": {"ms_per_frame": round(iso_ms_per_frame, 4), "mrays_per_s": round(fs.numRays / iso_ms_per_frame / 1e3, 2),
+                                    "frames": args.isolated_frames, "scope": "rank 0's shard, no gather"} if iso_ms_per_frame else None,
             "algorithmic_gbps_all_kernels": round(counts[3].item() / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": roofline,
         }
 
     # ---- reported CPU baseline (rank 0, N=1 only): the oracle on a bounded sample --------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and emu:
+        out["emulated_rank_of"] = emu
+        out["config"]["workload"] += f" [single-GPU rehearsal of ONE rank of {emu}: shard 0 only, no gather; value = this rank's rays/s]"
+    if rank == 0 and world == 1 and not emu and not args.no_cpu_baseline:
         from oracle import oracle_py as O
         threads = min(os.cpu_count() or 1, 16)
         bvh = scene.export_bvh()
@@ -257,10 +308,12 @@ def main():
                                "sample": f"the same frame, all {r.stats.numRays} rays, best of 2 runs ({dt:.2f} s each), scalar C++ oracle (oracle/), "
                                          f"{threads} std::threads over rows, -O2 -ffp-contract=off"}
         if args.verify:
-            api.render(scene, setup.camera, setup.scene_info(0), params(0), frame)     # frame 0 again, the one the oracle rendered
-            gpu = local.cpu().numpy().view(np.uint32)
+            api.render(scene, setup.camera, setup.scene_info(0), params(0), frames[0])     # frame 0 again, the one the oracle rendered
+            gpu = locals_[0].cpu().numpy().view(np.uint32)
             bad = int((gpu != r.images[A.IMAGE_SHADOWED]).sum())
             out["verify"] = {"pixels_checked": int(gpu.size), "pixels_differing_vs_oracle": bad}
+    elif rank == 0 and world == 1:
+        out["cpu_baseline"] = None
     elif rank == 0:
         out["cpu_baseline"] = None
         # N > 1: the assembled frame of the last step must equal the same frame rendered unsharded on this GPU
@@ -268,7 +321,7 @@ def main():
         whole = api.Frame(ctx, W, H, A.IMAGES_FRAMEBUFFER)
         api.render(scene, setup.camera, setup.scene_info(last_i), params(0, 0, 1), whole)
         torch.cuda.synchronize()
-        bad = int((full.cpu().numpy().view(np.uint32) != whole.download()).sum())
+        bad = int((fulls[last_i % nbuf].cpu().numpy().view(np.uint32) != whole.download()).sum())
         out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i}
 
     if rank == 0:

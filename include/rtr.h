@@ -223,7 +223,9 @@ uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount)
  * (src/app/application.cppm:362-389, src/vulkan/ray_tracing_pipeline.cppm:212-214). Synchronous. */
 int  rtr_render(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo,
                 const rtr_render_params* params, rtr_frame* frame);
-/* Asynchronous variant: enqueues on the ctx stream and returns; rtr_frame_wait() joins. */
+/* Asynchronous variant: enqueues on the stream of the FRAME's context and returns; rtr_frame_wait() joins.  The scene
+ * may belong to another context of the same device (it is read-only during rendering), so frames created on
+ * different contexts render concurrently on their own streams against one scene. */
 int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo,
                       const rtr_render_params* params, rtr_frame* frame);
 int  rtr_frame_wait(rtr_frame* frame);

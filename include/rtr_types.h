@@ -109,10 +109,10 @@ typedef struct RtrInstance {
  *   f[6..8]  = right min xyz    f[9..11] = right max xyz
  *   child[0], child[1]: >= 0 -> index of an inner node;
  *                       <  0 -> leaf: code = ~child; first = code >> 3; count = (code & 7) + 1
- *   An empty child has an inverted box (min=+big, max=-big) and child = RTR_BVH_EMPTY.
+ *   The root is always an inner node: a scene with a single leaf stores that leaf as BOTH children (testing a
+ *   triangle twice cannot change the (t, id)-minimal hit); an empty scene holds one degenerate triangle.
  */
 #define RTR_BVH_LAYOUT_VERSION 2
-#define RTR_BVH_EMPTY ((int32_t)0x7fffffff)
 #define RTR_BVH_MAX_LEAF 8
 typedef struct RtrBvhNode {
     float   f[12];

@@ -13,12 +13,17 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
-print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
-for f in find("stats/**/*kernel_stats.csv"):
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            name = row.get("Name", "")[:70]
-            print(f"{name:70s} calls={row.get('Calls'):>5s} total_ns={row.get('TotalDurationNs'):>12s} avg_ns={row.get('AverageNs'):>12s} pct={row.get('Percentage')}")
+for sub, what in (("stats", "the default bench command, frames in flight as bench.py defaults"),
+                  ("stats_serial", "same command with --frames-in-flight 1: every kernel has the GPU to itself")):
+    files = find(f"{sub}/**/*kernel_stats.csv")
+    if not files:
+        continue
+    print(f"== kernel stats (rocprofv3 --kernel-trace --stats), {what} ==")
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Name", "")[:70]
+                print(f"{name:70s} calls={row.get('Calls'):>5s} total_ns={row.get('TotalDurationNs'):>12s} avg_ns={row.get('AverageNs'):>12s} pct={row.get('Percentage')}")
 
 for tag in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     files = find(f"{tag}/**/*counter_collection.csv")

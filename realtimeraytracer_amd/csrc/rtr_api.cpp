@@ -692,7 +692,9 @@ int rtr_frame_clear(rtr_frame* f) {
 /* ---- dispatch ------------------------------------------------------------------------------ */
 static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* pin, rtr_frame* f) {
     if (!s || !cam || !info || !pin || !f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: null argument");
-    if (s->ctx != f->ctx) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: scene and frame belong to different contexts");
+    /* work is enqueued on the FRAME's context stream; the (read-only) scene may belong to another context of the same
+     * device, so two frames on two streams can be in flight against one scene */
+    if (s->ctx->device != f->ctx->device) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: scene and frame live on different devices");
     rtr_render_params p = *pin;
     if (p.bandRows == 0) p.bandRows = 8;
     if (p.shardCount == 0) p.shardCount = 1;
@@ -729,8 +731,8 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     for (uint32_t l = 0; l < info->numAreaLights; ++l) maxRays += (uint64_t)s->hostLights[l].numTriangles * p.numShadowRays;
     ra.maxRaysPerSample = (uint32_t)maxRays;
 
-    HIP_TRY(hipSetDevice(s->ctx->device));
-    hipStream_t st = s->ctx->stream;
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
     Counters* dstats = nullptr;
     if (p.collectStats) { HIP_TRY(hipMemsetAsync(f->counters.p, 0, sizeof(Counters), st)); dstats = f->counters.p; }
 

@@ -284,6 +284,32 @@ def test_async_render_into_external_torch_tensor(gpu_ctx, oracle, scene_cache):
         o.close()
 
 
+def test_frames_in_flight_share_one_scene(gpu_ctx, oracle, scene_cache):
+    """bench.py's pipelining: several contexts (one stream each) render different frames of ONE scene concurrently;
+    each frame's work is ordered on its own context's stream and every image still equals the oracle's."""
+    import torch
+    W, H = 320, 200
+    s = scenes.cornell_box(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    p = api.make_params(W, H, spp=2)
+    ctxs, streams, frames = [], [], []
+    for _ in range(3):
+        c = api.Context(0); st = torch.cuda.Stream(); c.set_stream(st.cuda_stream)
+        ctxs.append(c); streams.append(st); frames.append(api.Frame(c, W, H))
+    for rnd in range(2):                                           # buffers reused once, as the bench does
+        for b in range(3):
+            frames[b].wait()
+            api.render(scene, s.camera, s.scene_info(3 * rnd + b), p, frames[b], asynchronous=True)
+    for b in range(3):
+        frames[b].wait()
+        ref = oracle.render(s.desc, s.camera, s.scene_info(3 + b), p, bvh=bvh, threads=8)
+        _assert_same(frames[b].download(), ref.images[A.IMAGE_SHADOWED], f"frame in flight {b}")
+        assert frames[b].stats().shadowTraceMs > 0
+    for o in frames + ctxs + [scene]:
+        o.close()
+
+
 def test_empty_scene_renders_sky(gpu_ctx, oracle):
     from realtimeraytracer_amd import host
     d = A.rtr_scene_desc()
