@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_COPY_GBS = 6290.0   # same guide: measured streaming copy (SURVEY 8d asks for the fraction of this as well)
 
 
 def main():
@@ -50,11 +51,25 @@ def main():
                     help="single-GPU rehearsal of what ONE rank does in an N-GPU run: renders shard 0 of N with the same two-stream "
                          "frame pipelining, without the gather (the printed value is this rank's rays/s, not a job total)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames pipelined on separate streams (0 = default: 3 at N=1, 4 when the frame is sharded over N>1 GPUs; 1 = one frame at a time)")
+    ap.add_argument("--accumulate", type=int, default=1, metavar="K",
+                    help="a step = K frames (frame = 0..K-1) summed in the float HDR buffer and tonemapped once (BASELINE config 5: "
+                         "--width 3840 --height 2160 --accumulate 16)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="shortcut for a BASELINE.json config: 2 cornell 1080p, 3 bunny_class 1080p 4 spp, 4 (default) sponza_class 1080p, "
+                         "5 sponza_class 4K x16 accumulated")
     ap.add_argument("--isolated-frames", type=int, default=10,
                     help="after the timed region, render this many frames ONE AT A TIME to report per-kernel durations free of "
                          "cross-frame overlap (0 = skip; profiles/run_rocprof.sh skips it so rocprof's averages cover the timed launches only)")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
     args = ap.parse_args()
+
+    if args.config == 2:
+        args.workload = "cornell"
+    elif args.config == 3:
+        args.workload, args.spp = "bunny_class", 4
+    elif args.config == 5:
+        args.width, args.height, args.accumulate = 3840, 2160, 16
+    K = max(args.accumulate, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,7 +117,8 @@ def main():
     scene = api.Scene(ctx, setup.desc)
     sstats = scene.stats()
     rows = api.shard_rows(H, args.band_rows, nshards)
-    frames = [api.Frame(ctxs[b], W, rows, A.IMAGES_FRAMEBUFFER) for b in range(nbuf)]
+    images = A.IMAGES_FRAMEBUFFER | (A.IMG_BIT(A.IMAGE_HDR) if K > 1 else 0)
+    frames = [api.Frame(ctxs[b], W, rows, images) for b in range(nbuf)]
     locals_ = [torch.zeros((rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)]   # RGBA8 framebuffer of this shard
     for fr, lo in zip(frames, locals_):
         fr.bind_external(A.IMAGE_SHADOWED, lo.data_ptr(), lo.numel() * 4)
@@ -111,9 +127,15 @@ def main():
     fulls = [torch.zeros((H, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if rank == 0 else None
     full = fulls[0] if fulls else None
 
-    def params(collect=0, shard_index=rank, shard_count=nshards):
-        return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=shard_index,
-                               shard_count=shard_count, collect_stats=collect, pipeline=args.pipeline)
+    def params(collect=0, shard_index=rank, shard_count=nshards, j=0):
+        return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, images=images, band_rows=args.band_rows, shard_index=shard_index,
+                               shard_count=shard_count, accumulate=1 if j > 0 else 0, accumulated_frames=j,
+                               collect_stats=collect, pipeline=args.pipeline)
+
+    def render_step(fr, i, plist, asynchronous):
+        """one step: K frames (frame = 0..K-1 when accumulating, else frame = i) into `fr`, stream-ordered"""
+        for j in range(K):
+            api.render(scene, setup.camera, setup.scene_info(j if K > 1 else i), plist[j], fr, asynchronous=asynchronous)
 
     # ---- untimed stats pass: exact ray / node / triangle counts of one frame -------------------------
     api.render(scene, setup.camera, setup.scene_info(0), params(collect=1), frame)
@@ -122,10 +144,12 @@ def main():
                           dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    rays_per_frame, primary_per_frame = int(counts[0].item()), int(counts[1].item())
+    # a step of K accumulated frames issues K times the rays of one frame: ray counts do not depend on the frame number
+    # (every hit issues numLights x light-triangles x shadow-rays rays; only the sample positions change)
+    rays_per_frame, primary_per_frame = int(counts[0].item()) * K, int(counts[1].item()) * K
     pipeline_used = fs.pipelineUsed
 
-    p_run = params(0)
+    p_run = [params(0, j=j) for j in range(K)]
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0}
 
     works = [None] * nbuf
@@ -174,13 +198,12 @@ def main():
         kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
 
     def step(i):
-        info = setup.scene_info(i)
         b = i % nbuf
         last_buf[0] = b
         with torch.cuda.stream(streams[b]):
             collect(b)                                  # frame i-nbuf: done long ago unless the host runs ahead
             finish(b)                                   # its gather (stream-level wait) + de-interleave on rank 0
-            api.render(scene, setup.camera, info, p_run, frames[b], asynchronous=True)
+            render_step(frames[b], i, p_run, True)
             inflight[b] = True
             if world > 1:
                 works[b] = gather_async(b)              # RCCL gather to rank 0; runs under the other streams' kernels
@@ -223,7 +246,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for j in range(args.isolated_frames):
-            api.render(scene, setup.camera, setup.scene_info(args.warmup + j), p_run, frames[0])
+            render_step(frames[0], args.warmup + j, p_run, False)
             st = frames[0].stats()
             kern_iso["primary"] += st.primaryMs / args.isolated_frames; kern_iso["shadow_gen"] += st.shadowGenMs / args.isolated_frames
             kern_iso["shadow_trace"] += st.shadowTraceMs / args.isolated_frames; kern_iso["resolve"] += st.resolveMs / args.isolated_frames
@@ -252,6 +275,8 @@ def main():
                     traffic = None
             roofline = {"bound": "hbm", "kernel": "k_shadow_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_COPY_GBS, 5),
+                        "hbm_frac": round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                         "algorithmic_bytes_per_launch": int(trace_bytes), "avg_launch_ms": round(trace_ms, 4),
                         "avg_launch_ms_source": (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
                                                  if kern_iso else "HIP events on the launch stream over the timed region"),
@@ -265,11 +290,11 @@ def main():
                         "algorithmic_bytes_per_launch": int(fs.algorithmicBytes), "avg_launch_ms": round(mk_ms, 4),
                         "bvh_layout_version": int(sstats.bvhLayoutVersion)}
         out = {
-            "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S) == (1920, 1080, 1) else f"Mrays/sec at {W}x{H} {S}spp",
+            "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S, K) == (1920, 1080, 1, 1) else f"Mrays/sec at {W}x{H} {S}spp" + (f" x{K} frames accumulated in HDR" if K > 1 else ""),
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {W}x{H} {S}spp, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
+            "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
                                    f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{world}",
                        "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame,
                        "pipeline": "wavefront" if pipeline_used == 2 else "megakernel",
@@ -304,9 +329,17 @@ def main():
             dt = time.perf_counter() - t1
             best = dt if best is None else min(best, dt)
         dt = best
+        # (i) of SURVEY 8d: one thread, on shard 0 of 16 of the same frame (every 16th band: ~1/16 of the rays)
+        p1 = api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, band_rows=args.band_rows, shard_index=0, shard_count=16, collect_stats=1)
+        t1 = time.perf_counter()
+        r1 = O.render(setup.desc, setup.camera, setup.scene_info(0), p1, bvh=bvh, threads=1)
+        dt1 = time.perf_counter() - t1
+        single = {"value": round(r1.stats.numRays / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                  "sample": f"shard 0 of 16 of the same frame ({r1.stats.numRays} rays, {dt1:.2f} s)"}
         out["cpu_baseline"] = {"value": round(r.stats.numRays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                "sample": f"the same frame, all {r.stats.numRays} rays, best of 2 runs ({dt:.2f} s each), scalar C++ oracle (oracle/), "
-                                         f"{threads} std::threads over rows, -O2 -ffp-contract=off"}
+                                         f"{threads} std::threads over rows, -O2 -ffp-contract=off",
+                               "single_thread": single}
         if args.verify:
             api.render(scene, setup.camera, setup.scene_info(0), params(0), frames[0])     # frame 0 again, the one the oracle rendered
             gpu = locals_[0].cpu().numpy().view(np.uint32)
@@ -318,8 +351,8 @@ def main():
         out["cpu_baseline"] = None
         # N > 1: the assembled frame of the last step must equal the same frame rendered unsharded on this GPU
         last_i = args.warmup + args.steps - 1
-        whole = api.Frame(ctx, W, H, A.IMAGES_FRAMEBUFFER)
-        api.render(scene, setup.camera, setup.scene_info(last_i), params(0, 0, 1), whole)
+        whole = api.Frame(ctx, W, H, images)
+        render_step(whole, last_i, [params(0, 0, 1, j=j) for j in range(K)], False)
         torch.cuda.synchronize()
         bad = int((fulls[last_i % nbuf].cpu().numpy().view(np.uint32) != whole.download()).sum())
         out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i}

@@ -121,6 +121,7 @@ typedef struct rtr_scene_stats {
     float    boundsMax[3];
     float    boxPad;
     float    _pad;
+    RtrBvhGrid grid;          /* the 16-bit planes of the exported nodes live on this grid (rewritten by a refit) */
 } rtr_scene_stats;
 
 /* Per-dispatch arguments: what the reference passes as the traceRaysKHR extent + the two
@@ -153,11 +154,11 @@ typedef struct rtr_frame_stats {
     uint64_t numLightTriFetches;/* light triangle vertex fetches (3 idx + 3 x 48 B = 156 B each) */
     uint64_t numTexFetches;    /* bilinear texture / HDRI lookups (4 texels, 16 B each) */
     uint64_t numAlphaTests;    /* opacity.rahit invocations that sampled an opacity map (236 B fetch + 1 lookup each) */
-    uint64_t algorithmicBytes; /* B = 64 N_node + 48 N_tri + 236 (N_hit + N_alpha) + 96 N_lf + 156 N_ltf + 16 N_tex + 4 k P (+16/32 P HDR) */
+    uint64_t algorithmicBytes; /* B = 32 N_node (RTR_BVH_NODE_BYTES) + 48 N_tri + 236 (N_hit + N_alpha) + 96 N_lf + 156 N_ltf + 16 N_tex + 4 k P (+16/32 P HDR) */
     /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
     uint64_t numShadowNodeVisits;
     uint64_t numShadowTriTests;
-    uint64_t shadowTraceBytes; /* 64 N_node_shadow + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
+    uint64_t shadowTraceBytes; /* 32 N_node_shadow + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
     /* timings of the last render (HIP events on the render stream), milliseconds */
     float    totalMs;
     float    primaryMs;        /* k_primary (wavefront) or the whole megakernel */
@@ -183,7 +184,7 @@ int  rtr_ctx_device_name(rtr_ctx* ctx, char* buf, size_t bytes);
 int  rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* desc, rtr_scene** out);
 void rtr_scene_destroy(rtr_scene* scene);
 int  rtr_scene_get_stats(const rtr_scene* scene, rtr_scene_stats* out);
-/* Copy out the device BVH arrays (test / oracle hook; sizes from rtr_scene_get_stats). */
+/* Copy out the device BVH arrays (test / oracle hook; sizes and the plane grid from rtr_scene_get_stats). */
 int  rtr_scene_export_bvh(const rtr_scene* scene, RtrBvhNode* nodes, size_t nodeBytes,
                           RtrBvhTri* tris, size_t triBytes);
 /* Host-only BVH build (no device needed): validates `desc`, flattens and builds exactly as

@@ -248,6 +248,54 @@ RTR_HD int rtr_slab(const float* bmin, const float* bmax, rtr_v3 idir, rtr_v3 oo
     return lo <= hi * RTR_BOX_WIDEN;
 }
 
+/* ---- 16-bit planes on the scene grid (BVH layout version 3, include/rtr_types.h) ----------------------------------
+ * Grid from the (padded) scene bounds: 65532 steps span the extent; the origin sits 1.5 steps below the minimum so the
+ * +-1 guard steps of the quantisers below stay inside [0, 65535]. */
+RTR_HD void rtr_grid_from_bounds(const float* bmin, const float* bmax, float* origin, float* scale) {
+    for (int k = 0; k < 3; ++k) {
+        float ext = bmax[k] - bmin[k];
+        float s = ext / 65532.0f;
+        float floor_s = rtr_max(rtr_abs(bmin[k]), rtr_abs(bmax[k])) * 9.094947e-13f + 1e-30f;   /* 2^-40 of the magnitude: keeps s > 0 for flat scenes */
+        if (!(s > floor_s)) s = floor_s;
+        scale[k] = s;
+        origin[k] = bmin[k] - 1.5f * s;
+    }
+}
+/* Outward quantisation: origin + qlo*scale <= v <= origin + qhi*scale in real arithmetic (x below is accurate to
+ * ~0.01 step, the guard is a whole step).  floor/ceil are exact, the division is IEEE: host and device agree bit for bit. */
+RTR_HD uint32_t rtr_quant_lo(float v, float origin, float scale) {
+    float q = __builtin_floorf((v - origin) / scale) - 1.0f;
+    q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
+    return (uint32_t)q;
+}
+RTR_HD uint32_t rtr_quant_hi(float v, float origin, float scale) {
+    float q = __builtin_ceilf((v - origin) / scale) + 1.0f;
+    q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
+    return (uint32_t)q;
+}
+/* Per-ray constants of the quantised slab test: t(q) = q * ga + gb with ga = scale * idir, gb = (origin - o) * idir.
+ * Same operation count per plane as the fp32 form (one fma) once q is converted.  Rounding: |t(q) - t_exact| corresponds
+ * to moving the plane by at most ~(2 extent + 3 |origin - o| + |o + t d|) * 2^-24, far inside the builder's outward
+ * padding of 2^-18 * max|coordinate| (ray origins up to ~8 scene sizes away), so the test stays conservative with
+ * respect to rtr_mt_intersect's t exactly as rtr_slab was. */
+RTR_HD void rtr_ray_grid(rtr_v3 o, rtr_v3 idir, const float* origin, const float* scale, rtr_v3* ga, rtr_v3* gb) {
+    ga->x = scale[0] * idir.x; ga->y = scale[1] * idir.y; ga->z = scale[2] * idir.z;
+    gb->x = (origin[0] - o.x) * idir.x; gb->y = (origin[1] - o.y) * idir.y; gb->z = (origin[2] - o.z) * idir.z;
+}
+/* Slab test of one child box given its six grid coordinates (already widened to 32 bits). */
+RTR_HD int rtr_slab_q(uint32_t qminx, uint32_t qminy, uint32_t qminz, uint32_t qmaxx, uint32_t qmaxy, uint32_t qmaxz,
+                      rtr_v3 ga, rtr_v3 gb, float tmin, float tmax, float* t_entry) {
+    float tx0 = rtr_fma((float)qminx, ga.x, gb.x), tx1 = rtr_fma((float)qmaxx, ga.x, gb.x);
+    float ty0 = rtr_fma((float)qminy, ga.y, gb.y), ty1 = rtr_fma((float)qmaxy, ga.y, gb.y);
+    float tz0 = rtr_fma((float)qminz, ga.z, gb.z), tz1 = rtr_fma((float)qmaxz, ga.z, gb.z);
+    float lo = rtr_hwmax(rtr_hwmax(rtr_hwmin(tx0, tx1), rtr_hwmin(ty0, ty1)),
+                         rtr_hwmax(rtr_hwmin(tz0, tz1), tmin));
+    float hi = rtr_hwmin(rtr_hwmin(rtr_hwmax(tx0, tx1), rtr_hwmax(ty0, ty1)),
+                         rtr_hwmin(rtr_hwmax(tz0, tz1), tmax));
+    *t_entry = lo;
+    return lo <= hi * RTR_BOX_WIDEN;
+}
+
 /* Moeller-Trumbore, following the only in-repo statement of the ray-triangle arithmetic,
  * reference src/shaders/intersect.rint:18-41 (EPSILON, the u / v / u+v rejections, t > tmin),
  * on a precomputed {v0, e1, e2} record.  Returns 1 and (t,u,v) when tmin < t. */

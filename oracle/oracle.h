@@ -28,6 +28,7 @@ typedef struct oracle_scene {
      * the BVH builder and the traversal. */
     const RtrBvhNode* nodes;  uint32_t numNodes;
     const RtrBvhTri*  tris;   uint32_t numTris;
+    RtrBvhGrid grid;              /* the grid the nodes' 16-bit planes live on (rtr_scene_stats.grid) */
 } oracle_scene;
 
 typedef struct oracle_out {

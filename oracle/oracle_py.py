@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 class oracle_scene(C.Structure):
     _fields_ = [("desc", A.rtr_scene_desc), ("nodes", C.POINTER(A.RtrBvhNode)), ("numNodes", A.u32),
-                ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32)]
+                ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid)]
 
 
 class oracle_out(C.Structure):
@@ -64,11 +64,13 @@ def lib():
 
 
 def make_scene(desc, bvh=None):
-    """bvh = (nodes, tris) ctypes arrays from api.Scene.export_bvh(), or None for brute force."""
+    """bvh = (nodes, tris, grid) from api.Scene.export_bvh() (ctypes arrays + the RtrBvhGrid of rtr_scene_stats), or None
+    for brute force."""
     s = oracle_scene()
     s.desc = desc
     if bvh is not None:
-        nodes, tris = bvh
+        nodes, tris, grid = bvh
+        s.grid = grid
         s.nodes = C.cast(nodes, C.POINTER(A.RtrBvhNode))
         s.numNodes = len(nodes)
         s.tris = C.cast(tris, C.POINTER(A.RtrBvhTri))

@@ -130,7 +130,8 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
     const RtrBvhTri* tris = sc.s->tris;
     Hit best{}; best.hit = false; best.t = tmax;
     rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
-    rtr_v3 ood = rtr_mk(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+    rtr_v3 ga, gb;                                   /* t(q) = q * ga + gb, include/rtr_math.h */
+    rtr_ray_grid(o, idir, sc.s->grid.origin, sc.s->grid.scale, &ga, &gb);
     int32_t stack[128];
     int sp = 0;
     int32_t cur = 0;   /* root is always an inner node */
@@ -140,8 +141,11 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
             c.nodes++; if (anyHit) c.shadowNodes++;
             float tl, tr;
             float limit = best.hit ? best.t : tmax;
-            int hl = rtr_slab(&n.f[0], &n.f[3], idir, ood, tmin, limit, &tl);
-            int hr = rtr_slab(&n.f[6], &n.f[9], idir, ood, tmin, limit, &tr);
+            const uint16_t* q = n.q;
+            int hl = rtr_slab_q(q[RTR_BVH_QSLOT(0, 0, 0)], q[RTR_BVH_QSLOT(0, 0, 1)], q[RTR_BVH_QSLOT(0, 0, 2)],
+                                q[RTR_BVH_QSLOT(0, 1, 0)], q[RTR_BVH_QSLOT(0, 1, 1)], q[RTR_BVH_QSLOT(0, 1, 2)], ga, gb, tmin, limit, &tl);
+            int hr = rtr_slab_q(q[RTR_BVH_QSLOT(1, 0, 0)], q[RTR_BVH_QSLOT(1, 0, 1)], q[RTR_BVH_QSLOT(1, 0, 2)],
+                                q[RTR_BVH_QSLOT(1, 1, 0)], q[RTR_BVH_QSLOT(1, 1, 1)], q[RTR_BVH_QSLOT(1, 1, 2)], ga, gb, tmin, limit, &tr);
             if (hl && hr) {
                 int32_t nearC = n.child[0], farC = n.child[1];
                 if (tr < tl) { nearC = n.child[1]; farC = n.child[0]; }
@@ -625,12 +629,12 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.numLightFetches = tot.lightFetch; st.numLightTriFetches = tot.lightTriFetch;
     st.numShadowNodeVisits = tot.shadowNodes; st.numShadowTriTests = tot.shadowTris;
     st.numTexFetches = tot.texFetch; st.numAlphaTests = tot.alphaTests;
-    st.shadowTraceBytes = 64 * tot.shadowNodes + 48 * tot.shadowTris + 33 * tot.shadow;
+    st.shadowTraceBytes = RTR_BVH_NODE_BYTES * tot.shadowNodes + 48 * tot.shadowTris + 33 * tot.shadow;
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;
     k += out->normal ? 1u : 0u; k += out->position ? 1u : 0u;
-    st.algorithmicBytes = 64 * tot.nodes + 48 * tot.tris + 236 * (tot.hits + tot.alphaTests) + 96 * tot.lightFetch + 156 * tot.lightTriFetch +
+    st.algorithmicBytes = RTR_BVH_NODE_BYTES * tot.nodes + 48 * tot.tris + 236 * (tot.hits + tot.alphaTests) + 96 * tot.lightFetch + 156 * tot.lightTriFetch +
                           16 * tot.texFetch +
                           4ull * k * st.localPixels + (out->hdr ? (prm.accumulate ? 32ull : 16ull) * st.localPixels : 0ull);
     return 0;

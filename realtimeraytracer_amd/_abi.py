@@ -48,7 +48,11 @@ class RtrInstance(C.Structure):
 
 
 class RtrBvhNode(C.Structure):
-    _fields_ = [("f", f32 * 12), ("child", i32 * 2), ("_pad", i32 * 2)]
+    _fields_ = [("q", C.c_uint16 * 12), ("child", i32 * 2)]
+
+
+class RtrBvhGrid(C.Structure):
+    _fields_ = [("origin", f32 * 3), ("_pad0", f32), ("scale", f32 * 3), ("_pad1", f32)]
 
 
 class RtrBvhTri(C.Structure):
@@ -75,7 +79,7 @@ class rtr_scene_desc(C.Structure):
 class rtr_scene_stats(C.Structure):
     _fields_ = [("numTriangles", u32), ("numNodes", u32), ("maxDepth", u32), ("maxLeafSize", u32),
                 ("bvhLayoutVersion", u32), ("stackEntries", u32), ("buildMs", f32), ("sahCost", f32),
-                ("boundsMin", f32 * 3), ("boundsMax", f32 * 3), ("boxPad", f32), ("_pad", f32)]
+                ("boundsMin", f32 * 3), ("boundsMax", f32 * 3), ("boxPad", f32), ("_pad", f32), ("grid", RtrBvhGrid)]
 
 
 class rtr_render_params(C.Structure):
@@ -94,7 +98,7 @@ class rtr_frame_stats(C.Structure):
 
 assert C.sizeof(RtrVertex) == 48 and C.sizeof(RtrCameraData) == 64 and C.sizeof(RtrSceneInfo) == 32
 assert C.sizeof(RtrObjectInfo) == 80 and C.sizeof(RtrAreaLightInfo) == 96
-assert C.sizeof(RtrBvhNode) == 64 and C.sizeof(RtrBvhTri) == 48
+assert C.sizeof(RtrBvhNode) == 32 and C.sizeof(RtrBvhGrid) == 32 and C.sizeof(RtrBvhTri) == 48
 
 # enum rtr_image
 IMAGE_ANALYTIC, IMAGE_SHADOWED, IMAGE_UNSHADOWED = 0, 1, 2

@@ -65,7 +65,7 @@ class Scene:
         ntri = max(s.numTriangles, 1)
         tris = (A.RtrBvhTri * ntri)()
         _check(self.lib.rtr_scene_export_bvh(self.h, nodes, C.sizeof(nodes), tris, C.sizeof(tris)), "rtr_scene_export_bvh")
-        return nodes, tris
+        return nodes, tris, s.grid      # the nodes' 16-bit planes live on s.grid
 
     def update_instances(self, instances, lights=None):
         """rtr_scene_update_instances: new transforms (+ optional light infos) -> device-side re-flatten + BVH refit."""

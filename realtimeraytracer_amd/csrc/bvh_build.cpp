@@ -1,6 +1,7 @@
-/* bvh_build.cpp — deterministic binned-SAH BVH2 builder, children-in-parent 64-B nodes.
- * See bvh_build.h for what it replaces in the reference. */
+/* bvh_build.cpp — deterministic binned-SAH BVH2 builder (children-in-parent nodes with fp32 planes), followed by the
+ * outward quantisation to the 32-B RtrBvhNode.  See bvh_build.h for what it replaces in the reference. */
 #include "bvh_build.h"
+#include "../../include/rtr_math.h"
 
 #include <algorithm>
 #include <chrono>
@@ -41,6 +42,7 @@ struct Builder {
     std::vector<Prim> prims;
     const std::vector<WorldTriangle>* src = nullptr;
     BvhResult* out = nullptr;
+    std::vector<BvhNodeF> nodesF;
     float pad = 0.f;
     double sah = 0.0;
     float rootArea = 1.f;
@@ -149,24 +151,24 @@ struct Builder {
             if (!forceInner) return emit_leaf(lo, hi, box);
             /* root must be an inner node: both children point at the same leaf (testing a triangle
              * twice cannot change the (t,id)-minimal hit) */
-            uint32_t idx = (uint32_t)out->nodes.size();
-            out->nodes.emplace_back();
+            uint32_t idx = (uint32_t)nodesF.size();
+            nodesF.emplace_back();
             int32_t leaf = emit_leaf(lo, hi, box);
-            RtrBvhNode& nd = out->nodes[idx];
+            BvhNodeF& nd = nodesF[idx];
             memset(&nd, 0, sizeof nd);
             write_box(&nd.f[0], box); write_box(&nd.f[6], box);
             nd.child[0] = leaf; nd.child[1] = leaf;
             out->maxDepth = std::max(out->maxDepth, depth + 1);
             return (int32_t)idx;
         }
-        uint32_t idx = (uint32_t)out->nodes.size();
-        out->nodes.emplace_back();
+        uint32_t idx = (uint32_t)nodesF.size();
+        nodesF.emplace_back();
         out->maxDepth = std::max(out->maxDepth, depth + 1);
         sah += (double)(box.half_area() / rootArea) * kCostTraverse;
         Box lb = range_box(lo, mid), rb = range_box(mid, hi);
         int32_t lc = build(lo, mid, lb, depth + 1, false);
         int32_t rc = build(mid, hi, rb, depth + 1, false);
-        RtrBvhNode& nd = out->nodes[idx];
+        BvhNodeF& nd = nodesF[idx];
         memset(&nd, 0, sizeof nd);
         write_box(&nd.f[0], lb); write_box(&nd.f[6], rb);
         nd.child[0] = lc; nd.child[1] = rc;
@@ -208,14 +210,36 @@ bool build_bvh(const std::vector<WorldTriangle>& tris, BvhResult& out, std::stri
     /* outward padding of every stored box: 2^-18 of the largest coordinate magnitude (see rtr_slab) */
     b.pad = std::max(maxAbs, 1e-6f) * 3.814697265625e-06f;
     b.rootArea = std::max(all.half_area(), 1e-30f);
-    out.nodes.reserve(in->size());
+    b.nodesF.reserve(in->size());
     out.tris.reserve(in->size());
     b.build(0, (uint32_t)in->size(), all, 0, true);
+    out.nodes.resize(b.nodesF.size());
+    quantize_nodes(b.nodesF.data(), b.nodesF.size(), out.grid, out.nodes.data());
     for (int k = 0; k < 3; ++k) { out.boundsMin[k] = all.mn[k]; out.boundsMax[k] = all.mx[k]; }
     out.boxPad = b.pad;
     out.sahCost = (float)b.sah;
     out.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
+}
+
+void quantize_nodes(const BvhNodeF* in, size_t count, RtrBvhGrid& grid, RtrBvhNode* out) {
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) {                       /* root box = union of the root's two child boxes (already padded) */
+        mn[k] = std::min(in[0].f[k], in[0].f[6 + k]);
+        mx[k] = std::max(in[0].f[3 + k], in[0].f[9 + k]);
+    }
+    grid = RtrBvhGrid{};
+    rtr_grid_from_bounds(mn, mx, grid.origin, grid.scale);
+    for (size_t i = 0; i < count; ++i) {
+        const BvhNodeF& s = in[i];
+        RtrBvhNode& d = out[i];
+        for (int side = 0; side < 2; ++side)
+            for (int k = 0; k < 3; ++k) {
+                d.q[RTR_BVH_QSLOT(side, 0, k)] = (uint16_t)rtr_quant_lo(s.f[6 * side + k], grid.origin[k], grid.scale[k]);
+                d.q[RTR_BVH_QSLOT(side, 1, k)] = (uint16_t)rtr_quant_hi(s.f[6 * side + 3 + k], grid.origin[k], grid.scale[k]);
+            }
+        d.child[0] = s.child[0]; d.child[1] = s.child[1];
+    }
 }
 
 }  // namespace rtr

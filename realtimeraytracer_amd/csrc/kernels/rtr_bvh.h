@@ -17,7 +17,9 @@ struct BvhInputs {
 };
 
 struct BvhDeviceArrays {          /* persistent: the tree + what a refit needs */
-    float4* nodes;                /* numNodes x 4 */
+    float4* nodesF;               /* numNodes x 4: builder-side nodes with fp32 planes (rtr::BvhNodeF); the fit / refit works here */
+    uint4*  nodes;                /* numNodes x 2: RtrBvhNode (16-bit planes on *grid), what the traversal reads */
+    RtrBvhGrid* grid;             /* 1 record, rewritten by every build / refit */
     float4* tris;                 /* numPrims x 3, leaf order */
     float4* boxMin; float4* boxMax;   /* per leaf-ordered primitive */
     int32_t* parent;              /* per node: (parentIndex << 1) | slot, -1 root, -2 not part of the tree */
@@ -36,7 +38,8 @@ struct BvhScratch {               /* build only */
 size_t bvh_sort_temp_bytes(uint32_t numPrims);
 /* LBVH build: numPrims >= 16.  Node array has numPrims-1 entries (entries inside collapsed subtrees are unused). */
 hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDeviceArrays& a, const BvhScratch& t, hipStream_t s);
-/* Refit after transforms changed: recompute world records in place (leaf order) and re-fit every box. */
+/* Refit after transforms changed: recompute world records in place (leaf order), re-fit every box, re-derive the grid
+ * from the new root bounds and re-quantise. */
 hipError_t bvh_refit(const BvhInputs& in, uint32_t numPrims, uint32_t numNodes, const BvhDeviceArrays& a, hipStream_t s);
 
 }  // namespace rtrdev

@@ -248,6 +248,40 @@ __global__ __launch_bounds__(kB) void k_fit(uint32_t numNodes, float4* nodes, co
     }
 }
 
+/* scene grid from the root's two child boxes (one lane) */
+__global__ void k_grid(const float4* __restrict__ nodesF, RtrBvhGrid* grid) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float* f = reinterpret_cast<const float*>(nodesF);
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) { mn[k] = fminf(f[k], f[6 + k]); mx[k] = fmaxf(f[3 + k], f[9 + k]); }
+    RtrBvhGrid g = {};
+    rtr_grid_from_bounds(mn, mx, g.origin, g.scale);
+    *grid = g;
+}
+
+/* fp32 planes -> 16-bit grid coordinates, rounded outward (same arithmetic as rtr::quantize_nodes on the host) */
+__global__ __launch_bounds__(kB) void k_quantize(uint32_t numNodes, const float4* __restrict__ nodesF, const int32_t* __restrict__ parent,
+                                                 const RtrBvhGrid* __restrict__ grid, uint4* __restrict__ nodes) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= numNodes) return;
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = make_uint4(0, 0, 0, 0);
+    if (parent[i] != -2) {
+        const float4 a = nodesF[(size_t)i * 4], b = nodesF[(size_t)i * 4 + 1], c = nodesF[(size_t)i * 4 + 2];
+        const int4 d = *reinterpret_cast<const int4*>(nodesF + (size_t)i * 4 + 3);
+        const float ox = grid->origin[0], oy = grid->origin[1], oz = grid->origin[2];
+        const float sx = grid->scale[0], sy = grid->scale[1], sz = grid->scale[2];
+        /* a = (lminx,lminy,lminz,lmaxx)  b = (lmaxy,lmaxz,rminx,rminy)  c = (rminz,rmaxx,rmaxy,rmaxz) */
+        w0.x = rtr_quant_lo(a.x, ox, sx) | (rtr_quant_lo(a.y, oy, sy) << 16);
+        w0.y = rtr_quant_hi(a.w, ox, sx) | (rtr_quant_hi(b.x, oy, sy) << 16);
+        w0.z = rtr_quant_lo(b.z, ox, sx) | (rtr_quant_lo(b.w, oy, sy) << 16);
+        w0.w = rtr_quant_hi(c.y, ox, sx) | (rtr_quant_hi(c.z, oy, sy) << 16);
+        w1.x = rtr_quant_lo(a.z, oz, sz) | (rtr_quant_hi(b.y, oz, sz) << 16);
+        w1.y = rtr_quant_lo(c.x, oz, sz) | (rtr_quant_hi(c.w, oz, sz) << 16);
+        w1.z = (uint32_t)d.x; w1.w = (uint32_t)d.y;
+    }
+    nodes[(size_t)i * 2] = w0; nodes[(size_t)i * 2 + 1] = w1;
+}
+
 /* ---- host-side drivers ------------------------------------------------------------------------------ */
 #define BV_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -257,7 +291,9 @@ hipError_t bvh_refit(const BvhInputs& in, uint32_t numPrims, uint32_t numNodes, 
     uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     BV_TRY(hipMemcpyAsync(a.red, init, sizeof init, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_world_prims, dim3((numPrims + kB - 1) / kB), dim3(kB), 0, s, in, numPrims, a.slotOfPrim, a.tris, a.boxMin, a.boxMax, a.red);
-    hipLaunchKernelGGL(k_fit, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, a.nodes, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
+    hipLaunchKernelGGL(k_fit, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, a.nodesF, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(64), 0, s, a.nodesF, a.grid);
+    hipLaunchKernelGGL(k_quantize, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, a.nodesF, a.parent, a.grid, a.nodes);
     return hipGetLastError();
 }
 
@@ -275,8 +311,10 @@ hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDevic
     hipLaunchKernelGGL(k_gather, gp, dim3(kB), 0, s, n, t.keysOut, t.trisCanon, t.minCanon, t.maxCanon, a.tris, a.boxMin, a.boxMax, a.slotOfPrim);
     hipLaunchKernelGGL(k_karras, gn, dim3(kB), 0, s, (int)n, t.keysOut, t.range, t.rawChild);
     hipLaunchKernelGGL(k_mark_unused, gn, dim3(kB), 0, s, numNodes, a.parent);
-    hipLaunchKernelGGL(k_emit, gn, dim3(kB), 0, s, (int)n, t.range, t.rawChild, a.nodes, a.parent);
-    hipLaunchKernelGGL(k_fit, gn, dim3(kB), 0, s, numNodes, a.nodes, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
+    hipLaunchKernelGGL(k_emit, gn, dim3(kB), 0, s, (int)n, t.range, t.rawChild, a.nodesF, a.parent);
+    hipLaunchKernelGGL(k_fit, gn, dim3(kB), 0, s, numNodes, a.nodesF, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(64), 0, s, a.nodesF, a.grid);
+    hipLaunchKernelGGL(k_quantize, gn, dim3(kB), 0, s, numNodes, a.nodesF, a.parent, a.grid, a.nodes);
     return hipGetLastError();
 }
 

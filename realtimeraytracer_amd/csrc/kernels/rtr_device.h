@@ -25,7 +25,8 @@ namespace rtrdev {
 struct DeviceTexture { const uint8_t* pixels; uint32_t width, height, channels, _pad; };
 
 struct DeviceScene {
-    const float4* nodes;             /* RtrBvhNode as 4 x float4 */
+    const uint4* nodes;              /* RtrBvhNode (layout version 3) as 2 x uint4 */
+    const RtrBvhGrid* grid;          /* the grid the 16-bit planes live on; device memory so a refit can rewrite it */
     const float4* tris;              /* RtrBvhTri  as 3 x float4 */
     const RtrVertex* vertices;
     const uint32_t* indices;
@@ -134,6 +135,22 @@ __device__ __forceinline__ bool alpha_pass(const DeviceScene& sc, uint32_t custo
     return !(t.x < 0.9f);
 }
 
+/* Slab test of one child box of an RtrBvhNode: wmin = (qminx | qminy << 16), wmax = (qmaxx | qmaxy << 16),
+ * wz = (qminz | qmaxz << 16).  Same arithmetic as rtr_slab_q (one fma per plane, identical min/max tree); written on
+ * 2-vectors so the six fmas become three v_pk_fma_f32 and the conversions v_cvt_f32_u32 with a 16-bit source select. */
+typedef float rtr_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool slab_pair(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gb,
+                                          float tmin, float tmax, float& t_entry) {
+    const rtr_f2 axy = {ga.x, ga.y}, bxy = {gb.x, gb.y}, az = {ga.z, ga.z}, bz = {gb.z, gb.z};
+    const rtr_f2 t0 = __builtin_elementwise_fma(rtr_f2{(float)(wmin & 0xffffu), (float)(wmin >> 16)}, axy, bxy);
+    const rtr_f2 t1 = __builtin_elementwise_fma(rtr_f2{(float)(wmax & 0xffffu), (float)(wmax >> 16)}, axy, bxy);
+    const rtr_f2 tz = __builtin_elementwise_fma(rtr_f2{(float)(wz & 0xffffu), (float)(wz >> 16)}, az, bz);
+    const float lo = rtr_hwmax(rtr_hwmax(rtr_hwmin(t0.x, t1.x), rtr_hwmin(t0.y, t1.y)), rtr_hwmax(rtr_hwmin(tz.x, tz.y), tmin));
+    const float hi = rtr_hwmin(rtr_hwmin(rtr_hwmax(t0.x, t1.x), rtr_hwmax(t0.y, t1.y)), rtr_hwmin(rtr_hwmax(tz.x, tz.y), tmax));
+    t_entry = lo;
+    return lo <= hi * RTR_BOX_WIDEN;
+}
+
 /* ------------------------------------------------------------------------------------------
  * BVH traversal.  Restates, operation for operation, the algorithm of oracle/oracle_render.cpp
  * trace_bvh(): ordered descent (near child first, ties -> left), far child pushed, box culled iff
@@ -148,22 +165,21 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
     best.custom = RTR_MISS; best.prim = RTR_MISS; best.t = tmax; best.u = 0.f; best.v = 0.f;
     if (!(tmax > tmin)) return false;
     const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
-    const rtr_v3 ood = rtr_mk(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+    rtr_v3 ga, gb;                                        /* t(q) = q * ga + gb (rtr_math.h) */
+    rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
     bool found = false;
     float limit = tmax;
     int sp = 0;
     int32_t cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4* n = sc.nodes + (size_t)cur * 4;
-            const float4 a = n[0], b = n[1], c = n[2];
-            const int2 ch = *reinterpret_cast<const int2*>(n + 3);
+            const uint4* n = sc.nodes + (size_t)cur * 2;
+            const uint4 a = n[0], b = n[1];
+            const int2 ch = make_int2((int)b.z, (int)b.w);
             if (STATS) { st.nodes++; if (ANY) st.shadowNodes++; }
-            const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {a.w, b.x, b.y};
-            const float rmn[3] = {b.z, b.w, c.x}, rmx[3] = {c.y, c.z, c.w};
             float tl, tr;
-            const int hl = rtr_slab(lmn, lmx, idir, ood, tmin, limit, &tl);
-            const int hr = rtr_slab(rmn, rmx, idir, ood, tmin, limit, &tr);
+            const bool hl = slab_pair(a.x, a.y, b.x, ga, gb, tmin, limit, tl);
+            const bool hr = slab_pair(a.z, a.w, b.y, ga, gb, tmin, limit, tr);
             if (hl && hr) {
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     bool exhausted = false;                  /* wave-uniform */
     int32_t cur = kDone;
     int sp = 0;
-    rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), idir = rtr_mk(0, 0, 0), ood = rtr_mk(0, 0, 0);
+    rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
     float tmax = 0.f;
     uint32_t slot = 0, rayIndex = 0;
     const float tmin = 0.001f;
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                     if (!(tmax > tmin)) {
                         vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                     } else {
-                        idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
-                        ood = rtr_mk(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+                        const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+                        rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
                         cur = 0; sp = 0;
                     }
                 }
@@ -280,19 +280,17 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
             if (innerMask == 0ull) break;
             if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
             if (cur >= 0) {
-                const float4* nd = sc.nodes + (size_t)cur * 4;
-                const float4 a = nd[0], b = nd[1], c = nd[2];
-                const int2 ch = *reinterpret_cast<const int2*>(nd + 3);
+                const uint4* nd = sc.nodes + (size_t)cur * 2;      /* one 32-B RtrBvhNode = the whole visit */
+                const uint4 a = nd[0], b = nd[1];
+                const int2 ch = make_int2((int)b.z, (int)b.w);
                 /* speculative read of the stack top next to the node loads: its LDS latency is hidden and the pop below
                  * needs no load of its own (index clamped so the address is always valid) */
                 int32_t top = 0;
                 if (!EXACT) top = lds[(sp > 0 ? sp - 1 : 0) * kBlock];
                 if (STATS) { st.nodes++; st.shadowNodes++; }
-                const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {a.w, b.x, b.y};
-                const float rmn[3] = {b.z, b.w, c.x}, rmx[3] = {c.y, c.z, c.w};
                 float tl, tr;
-                const bool hl = rtr_slab(lmn, lmx, idir, ood, tmin, tmax, &tl) != 0;
-                const bool hr = rtr_slab(rmn, rmx, idir, ood, tmin, tmax, &tr) != 0;
+                const bool hl = slab_pair(a.x, a.y, b.x, ga, gb, tmin, tmax, tl);
+                const bool hr = slab_pair(a.z, a.w, b.y, ga, gb, tmin, tmax, tr);
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;
                 const int32_t farC = swap ? ch.x : ch.y;

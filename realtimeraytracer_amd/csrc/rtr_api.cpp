@@ -76,7 +76,10 @@ struct rtr_ctx {
 
 struct rtr_scene {
     rtr_ctx* ctx = nullptr;
-    DevBuf<float4> nodes, tris;
+    DevBuf<uint4> nodes;                 /* RtrBvhNode, 2 x uint4 each */
+    DevBuf<float4> nodesF;               /* rtr::BvhNodeF, 4 x float4 each: device build / refit only */
+    DevBuf<RtrBvhGrid> grid;
+    DevBuf<float4> tris;
     DevBuf<RtrVertex> vertices;
     DevBuf<uint32_t> indices;
     DevBuf<RtrObjectInfo> objects;
@@ -298,6 +301,7 @@ static void fill_stats(rtr_scene_stats& st, const rtr::BvhResult& bvh, uint32_t 
     st.stackEntries = stackEntries;
     st.buildMs = bvh.buildMs;
     st.sahCost = bvh.sahCost;
+    st.grid = bvh.grid;
     for (int k = 0; k < 3; ++k) { st.boundsMin[k] = bvh.boundsMin[k]; st.boundsMax[k] = bvh.boundsMax[k]; }
     st.boxPad = bvh.boxPad;
 }
@@ -338,7 +342,7 @@ static void make_prim_tables(const rtr_scene_desc* d, const RtrInstance* instanc
 
 static rtrdev::BvhDeviceArrays device_arrays(rtr_scene* s) {
     rtrdev::BvhDeviceArrays a{};
-    a.nodes = s->nodes.p; a.tris = s->tris.p; a.boxMin = s->boxMin.p; a.boxMax = s->boxMax.p; a.parent = s->parent.p;
+    a.nodes = s->nodes.p; a.nodesF = s->nodesF.p; a.grid = s->grid.p; a.tris = s->tris.p; a.boxMin = s->boxMin.p; a.boxMax = s->boxMax.p; a.parent = s->parent.p;
     a.counters = s->counters.p; a.depth = s->depth.p; a.slotOfPrim = s->slotOfPrim.p; a.red = s->red.p;
     return a;
 }
@@ -356,7 +360,8 @@ static int build_on_device(rtr_scene* s, const rtr_scene_desc* d, size_t numPrim
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(s->prims.upload(prims.data(), prims.size(), st));
     HIP_TRY(s->instRefs.upload(refs.data(), refs.size(), st));
-    HIP_TRY(s->nodes.alloc((size_t)numNodes * 4)); HIP_TRY(s->tris.alloc((size_t)n * 3));
+    HIP_TRY(s->nodes.alloc((size_t)numNodes * 2)); HIP_TRY(s->nodesF.alloc((size_t)numNodes * 4)); HIP_TRY(s->grid.alloc(1));
+    HIP_TRY(s->tris.alloc((size_t)n * 3));
     HIP_TRY(s->boxMin.alloc(n)); HIP_TRY(s->boxMax.alloc(n)); HIP_TRY(s->parent.alloc(numNodes));
     HIP_TRY(s->counters.alloc(numNodes)); HIP_TRY(s->depth.alloc(numNodes)); HIP_TRY(s->slotOfPrim.alloc(n)); HIP_TRY(s->red.alloc(8));
     DevBuf<float4> trisCanon, minCanon, maxCanon; DevBuf<unsigned long long> keysIn, keysOut; DevBuf<int2> range, rawChild; DevBuf<uint8_t> sortTemp;
@@ -367,15 +372,17 @@ static int build_on_device(rtr_scene* s, const rtr_scene_desc* d, size_t numPrim
     HIP_TRY(sortTemp.alloc(sc.sortTempBytes));
     sc.trisCanon = trisCanon.p; sc.minCanon = minCanon.p; sc.maxCanon = maxCanon.p; sc.keysIn = keysIn.p; sc.keysOut = keysOut.p;
     sc.range = range.p; sc.rawChild = rawChild.p; sc.sortTemp = sortTemp.p;
-    HIP_TRY(hipMemsetAsync(s->nodes.p, 0, (size_t)numNodes * 64, st));
+    HIP_TRY(hipMemsetAsync(s->nodesF.p, 0, (size_t)numNodes * 64, st));
     rtrdev::BvhInputs in{s->prims.p, s->instRefs.p, s->vertices.p, s->indices.p};
     hipError_t e = rtrdev::bvh_build_lbvh(in, n, device_arrays(s), sc, st);
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "device BVH build: %s", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(st));
     s->hostNodes.resize(numNodes); s->hostTris.resize(n);
     uint32_t red[8];
-    HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, (size_t)numNodes * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, (size_t)numNodes * sizeof(RtrBvhNode), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(s->hostTris.data(), s->tris.p, (size_t)n * 48, hipMemcpyDeviceToHost));
+    RtrBvhGrid grid;
+    HIP_TRY(hipMemcpy(&grid, s->grid.p, sizeof grid, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(red, s->red.p, sizeof red, hipMemcpyDeviceToHost));
     const float buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (red[7] > 64) return fail(RTR_ERR_BVH_TOO_DEEP, "device-built BVH depth %u exceeds the 64-entry LDS traversal stack", red[7]);
@@ -384,6 +391,7 @@ static int build_on_device(rtr_scene* s, const rtr_scene_desc* d, size_t numPrim
     s->stats.bvhLayoutVersion = RTR_BVH_LAYOUT_VERSION;
     s->stats.stackEntries = red[7] <= 16 ? 16 : (red[7] <= 32 ? 32 : 64);
     s->stats.buildMs = buildMs;
+    s->stats.grid = grid;
     float mabs; memcpy(&mabs, &red[6], 4);
     s->stats.boxPad = (mabs > 1e-6f ? mabs : 1e-6f) * 3.814697265625e-06f;
     s->numPrims = n; s->numNodeSlots = numNodes; s->refitReady = true;
@@ -424,9 +432,10 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    static_assert(sizeof(RtrBvhNode) == 4 * sizeof(float4) && sizeof(RtrBvhTri) == 3 * sizeof(float4), "layout");
+    static_assert(sizeof(RtrBvhNode) == 2 * sizeof(uint4) && sizeof(RtrBvhTri) == 3 * sizeof(float4), "layout");
     if (!deviceBuild) {
-        chk(s->nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() * 4, st));
+        chk(s->nodes.upload(reinterpret_cast<const uint4*>(bvh.nodes.data()), bvh.nodes.size() * 2, st));
+        chk(s->grid.upload(&bvh.grid, 1, st));
         chk(s->tris.upload(reinterpret_cast<const float4*>(bvh.tris.data()), bvh.tris.size() * 3, st));
     }
     chk(s->vertices.upload(d->vertices, d->numVertices, st));
@@ -475,7 +484,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     }
 
     DeviceScene& dv = s->dev;
-    dv.nodes = s->nodes.p; dv.tris = s->tris.p;
+    dv.nodes = s->nodes.p; dv.grid = s->grid.p; dv.tris = s->tris.p;
     dv.vertices = s->vertices.p; dv.indices = s->indices.p;
     dv.objects = s->objects.p; dv.lights = s->lights.p;
     dv.xforms = s->xforms.p; dv.nmats = s->nmats.p;
@@ -512,6 +521,13 @@ static int ensure_refit_ready(rtr_scene* s) {
     if (acc != n) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_update_instances: scene has no geometry to refit");
     std::vector<uint32_t> slotOfPrim(n, 0);
     for (uint32_t slot = 0; slot < n; ++slot) slotOfPrim[base[s->hostTris[slot].customIndex] + s->hostTris[slot].primitiveId] = slot;
+    /* the fit works on fp32 planes: child codes from the host tree, boxes recomputed by the refit */
+    std::vector<rtr::BvhNodeF> nf(numNodes);
+    for (uint32_t i = 0; i < numNodes; ++i) {
+        memset(&nf[i], 0, sizeof nf[i]);
+        nf[i].child[0] = s->hostNodes[i].child[0]; nf[i].child[1] = s->hostNodes[i].child[1];
+    }
+    HIP_TRY(s->nodesF.upload(reinterpret_cast<const float4*>(nf.data()), (size_t)numNodes * 4, st));
     HIP_TRY(s->parent.upload(parent.data(), parent.size(), st));
     HIP_TRY(s->slotOfPrim.upload(slotOfPrim.data(), slotOfPrim.size(), st));
     HIP_TRY(s->boxMin.alloc(n)); HIP_TRY(s->boxMax.alloc(n));
@@ -560,8 +576,9 @@ int rtr_scene_update_instances(rtr_scene* s, const RtrInstance* instances, uint3
     HIP_TRY(hipStreamSynchronize(st));
     /* keep the host mirror (rtr_scene_export_bvh) and the stats in step */
     uint32_t red[8];
-    HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, s->hostNodes.size() * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, s->hostNodes.size() * sizeof(RtrBvhNode), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(s->hostTris.data(), s->tris.p, s->hostTris.size() * 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&s->stats.grid, s->grid.p, sizeof(RtrBvhGrid), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(red, s->red.p, sizeof red, hipMemcpyDeviceToHost));
     float mabs; memcpy(&mabs, &red[6], 4);
     s->stats.boxPad = (mabs > 1e-6f ? mabs : 1e-6f) * 3.814697265625e-06f;
@@ -800,8 +817,8 @@ int rtr_frame_wait(rtr_frame* f) {
         s.numLightFetches = h.lightFetch; s.numLightTriFetches = h.lightTriFetch;
         s.numShadowNodeVisits = h.shadowNodes; s.numShadowTriTests = h.shadowTris;
         s.numTexFetches = h.texFetch; s.numAlphaTests = h.alphaTests;
-        s.shadowTraceBytes = 64ull * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
-        s.algorithmicBytes = 64ull * h.nodes + 48ull * h.tris + 236ull * (h.hits + h.alphaTests) + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
+        s.shadowTraceBytes = (uint64_t)RTR_BVH_NODE_BYTES * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
+        s.algorithmicBytes = (uint64_t)RTR_BVH_NODE_BYTES * h.nodes + 48ull * h.tris + 236ull * (h.hits + h.alphaTests) + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
                              16ull * h.texFetch +
                              4ull * f->pendingImagesK * s.localPixels + (f->pendingHdr ? (f->pendingAccum ? 32ull : 16ull) * s.localPixels : 0ull);
     }

@@ -48,7 +48,7 @@ def test_pod_layouts_match_reference():
     assert C.sizeof(A.RtrAreaLightInfo) == 96
     for f, off in (("intensity", 12), ("vertexOffset", 16), ("indexOffset", 20), ("numTriangles", 24), ("isTwoSided", 28), ("transform", 32)):
         assert getattr(A.RtrAreaLightInfo, f).offset == off
-    assert C.sizeof(A.RtrBvhNode) == 64 and C.sizeof(A.RtrBvhTri) == 48
+    assert C.sizeof(A.RtrBvhNode) == 32 and C.sizeof(A.RtrBvhGrid) == 32 and C.sizeof(A.RtrBvhTri) == 48
 
 
 def test_abi_version_and_status_strings():

@@ -59,13 +59,13 @@ def _worker(rank, world, port, cache, out_path):
     s = scenes.cornell_box(W, H)
     st, nodes, tris = api.host_build_bvh(s.desc)
     p = api.make_params(W, H, spp=2, shard_index=rank, shard_count=world)
-    r = O.render(s.desc, s.camera, s.scene_info(1), p, bvh=(nodes, tris), threads=2)
+    r = O.render(s.desc, s.camera, s.scene_info(1), p, bvh=(nodes, tris, st.grid), threads=2)
     local = torch.from_numpy(r.images[A.IMAGE_SHADOWED].view(np.int32).copy())
     gathered = mgpu.gather_to_root(dist, local, world, rank)
     if rank == 0:
         full = mgpu.assemble_numpy(gathered.numpy().view(np.uint32), H, 8)
         p1 = api.make_params(W, H, spp=2)
-        ref = O.render(s.desc, s.camera, s.scene_info(1), p1, bvh=(nodes, tris), threads=2).images[A.IMAGE_SHADOWED]
+        ref = O.render(s.desc, s.camera, s.scene_info(1), p1, bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
         np.save(out_path, np.array([int((full != ref[:H]).sum()), full.shape[0], full.shape[1]]))
     dist.barrier()
     dist.destroy_process_group()

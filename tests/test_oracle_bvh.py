@@ -1,5 +1,6 @@
 """CPU-side checks (no GPU): the oracle against its committed golden image, BVH invariants of the product's
 builder, and BVH traversal against the O(N) brute-force loop."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -22,7 +23,7 @@ def test_oracle_matches_committed_golden(oracle, scene_cache):
     s = scenes.cornell_box(256, 256, ltc=scenes.synthetic_ltc())
     p = _params(256, 256, images=ALL5)
     st, nodes, tris = api.host_build_bvh(s.desc)
-    for bvh in (None, (nodes, tris)):
+    for bvh in (None, (nodes, tris, st.grid)):
         r = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=bvh, images=ALL5, threads=8)
         for which, name in ((0, "analytic"), (1, "shadowed"), (2, "unshadowed"), (6, "normal"), (7, "position")):
             assert np.array_equal(r.images[which], g[name]), f"{name} differs from golden (bvh={'yes' if bvh else 'brute'})"
@@ -34,10 +35,24 @@ def test_oracle_matches_committed_golden(oracle, scene_cache):
     assert np.all(sh[..., 3] == 255) and sh[..., :3].std() > 20
 
 
-def _check_bvh(desc, st, nodes, tris):
+def _decode_boxes(nodes, grid):
+    """RtrBvhNode (layout version 3) -> float64 planes [node, side, min/max, axis] = origin + q * scale"""
+    q = np.frombuffer(nodes, dtype=np.uint16).reshape(-1, 16)[:, :12].astype(np.float64)
+    org, scl = np.array(grid.origin[:], np.float64), np.array(grid.scale[:], np.float64)
+    out = np.zeros((q.shape[0], 2, 2, 3))
+    for side in (0, 1):
+        for is_max in (0, 1):
+            for axis in (0, 1, 2):
+                slot = side * 4 + is_max * 2 + axis if axis < 2 else 8 + side * 2 + is_max     # RTR_BVH_QSLOT
+                out[:, side, is_max, axis] = org[axis] + q[:, slot] * scl[axis]
+    return out
+
+
+def _check_bvh(desc, st, nodes, tris, grid=None):
     n_tri = st.numTriangles
-    nd = np.frombuffer(nodes, dtype=np.float32).reshape(-1, 16)
-    ch = np.frombuffer(nodes, dtype=np.int32).reshape(-1, 16)[:, 12:14]
+    assert st.bvhLayoutVersion == 3 and C.sizeof(A.RtrBvhNode) == 32
+    nd = _decode_boxes(nodes, grid if grid is not None else st.grid)
+    ch = np.frombuffer(nodes, dtype=np.int32).reshape(-1, 8)[:, 6:8]
     tr = np.frombuffer(tris, dtype=np.float32).reshape(-1, 12)
     ids = np.frombuffer(tris, dtype=np.uint32).reshape(-1, 12)
     v0, e1, e2 = tr[:, 0:3], tr[:, 4:7], tr[:, 8:11]
@@ -51,9 +66,9 @@ def _check_bvh(desc, st, nodes, tris):
         i, depth, pmin, pmax = stack.pop()
         max_depth = max(max_depth, depth)
         for side in (0, 1):
-            bmin, bmax = nd[i, 6 * side:6 * side + 3], nd[i, 6 * side + 3:6 * side + 6]
-            if pmin is not None:      # child boxes inside the parent's box for this subtree
-                assert np.all(bmin >= pmin - 1e-3) and np.all(bmax <= pmax + 1e-3)
+            bmin, bmax = nd[i, side, 0], nd[i, side, 1]
+            if pmin is not None:      # child boxes inside the parent's box for this subtree (outward rounding is monotone)
+                assert np.all(bmin >= pmin) and np.all(bmax <= pmax)
             c = int(ch[i, side])
             if c >= 0:
                 stack.append((c, depth + 1, bmin, bmax))
@@ -64,8 +79,11 @@ def _check_bvh(desc, st, nodes, tris):
                 if not (i == 0 and side == 1 and int(ch[0, 0]) == c):   # single-leaf scenes duplicate the leaf in the root
                     seen[first:first + cnt] += 1
                     leaves += 1
-                # every triangle of the leaf inside the (padded) leaf box
-                assert np.all(tmin[first:first + cnt] >= bmin - 1e-6) and np.all(tmax[first:first + cnt] <= bmax + 1e-6)
+                # every triangle of the leaf inside the (padded, outward-quantised) leaf box
+                assert np.all(tmin[first:first + cnt] >= bmin) and np.all(tmax[first:first + cnt] <= bmax)
+                # ... and the box is tight: pad (2^-18 max|coord|) + at most 3 grid steps per side
+                slack = st.boxPad * 1.01 + 3.0 * np.array(grid.scale[:] if grid is not None else st.grid.scale[:])
+                assert np.all(tmin[first:first + cnt].min(axis=0) - bmin <= slack) and np.all(bmax - tmax[first:first + cnt].max(axis=0) <= slack)
     assert np.all(seen == 1), "every triangle must be in exactly one leaf"
     assert max_depth == st.maxDepth
     assert st.stackEntries >= st.maxDepth
@@ -82,7 +100,7 @@ def _check_bvh(desc, st, nodes, tris):
 def test_bvh_invariants_cornell(scene_cache):
     s = scenes.cornell_box(64, 64)
     st, nodes, tris = api.host_build_bvh(s.desc)
-    assert st.numTriangles == 38 and st.bvhLayoutVersion == 2 and st.maxLeafSize <= 8
+    assert st.numTriangles == 38 and st.bvhLayoutVersion == 3 and st.maxLeafSize <= 8
     _check_bvh(s.desc, st, nodes, tris)
     # deterministic
     st2, nodes2, tris2 = api.host_build_bvh(s.desc)
@@ -102,7 +120,7 @@ def test_bvh_vs_brute_force_primary_hits(oracle, scene_cache):
     s = scenes.bunny_class(96, 54, subdiv=3)           # 1,280 + 512 + 2 triangles
     st, nodes, tris = api.host_build_bvh(s.desc)
     p = _params(96, 54, spp=2)
-    a = oracle.primary_hits(s.desc, s.camera, p, bvh=(nodes, tris), threads=8)
+    a = oracle.primary_hits(s.desc, s.camera, p, bvh=(nodes, tris, st.grid), threads=8)
     b = oracle.primary_hits(s.desc, s.camera, p, bvh=None, threads=8)
     for x, y, n in zip(a, b, ("t", "u", "v", "customIndex", "primitiveId")):
         assert np.array_equal(x, y), f"{n} differs between BVH traversal and brute force"
@@ -115,7 +133,7 @@ def test_oracle_frame_bvh_vs_brute_force_sponza_class(oracle, scene_cache):
     st, nodes, tris = api.host_build_bvh(s.desc)
     assert 259_000 < st.numTriangles < 265_000 and st.maxDepth <= 32
     p = _params(48, 27)
-    a = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=(nodes, tris), threads=8)
+    a = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=(nodes, tris, st.grid), threads=8)
     b = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=None, threads=8)
     assert np.array_equal(a.images[1], b.images[1])
     assert a.stats.numRays == b.stats.numRays and a.stats.numTriTests < b.stats.numTriTests / 1000
@@ -131,7 +149,7 @@ def test_empty_and_degenerate_scenes(oracle):
     from realtimeraytracer_amd import host
     cam = host.Camera(60, (0, 0, 5), (0, 0, 0), (0, 1, 0), 16, 16).getGPUData()
     p = _params(16, 16)
-    r = oracle.render(d, cam, host.scene_info(0, 0, (0, 0, 5)), p, bvh=(nodes, tris), threads=1)
+    r = oracle.render(d, cam, host.scene_info(0, 0, (0, 0, 5)), p, bvh=(nodes, tris, st.grid), threads=1)
     sky = oracle.lib().oracle_pack_bgra8(*[oracle.lib().oracle_pow(oracle.lib().oracle_pow(c, 2.2), 1.0) for c in (0.5, 0.7, 1.0)])
     assert r.stats.numRays == 256 and len(np.unique(r.images[1])) == 1
     hs = host.HostScene()
@@ -139,7 +157,7 @@ def test_empty_and_degenerate_scenes(oracle):
     hs.build()
     st, nodes, tris = api.host_build_bvh(hs.desc)
     assert st.numTriangles == 2
-    r = oracle.render(hs.desc, cam, host.scene_info(0, 1, (0, 0, 5)), p, bvh=(nodes, tris), threads=1)
+    r = oracle.render(hs.desc, cam, host.scene_info(0, 1, (0, 0, 5)), p, bvh=(nodes, tris, st.grid), threads=1)
     assert r.stats.numHits == 0      # a == 0 triangles never pass Moeller-Trumbore
 
 
@@ -174,7 +192,7 @@ def test_textured_room_bvh_vs_brute_force(oracle, scene_cache):
     flags = np.frombuffer(tris, dtype=np.uint32).reshape(-1, 12)[:, 11]
     assert flags.sum() == 4                                  # the two leaf quads (2 triangles each) are alpha-tested
     p = _params(120, 76, spp=2, images=ALL5)
-    a = oracle.render(s.desc, s.camera, s.scene_info(1), p, bvh=(nodes, tris), images=ALL5, threads=8)
+    a = oracle.render(s.desc, s.camera, s.scene_info(1), p, bvh=(nodes, tris, st.grid), images=ALL5, threads=8)
     b = oracle.render(s.desc, s.camera, s.scene_info(1), p, bvh=None, images=ALL5, threads=8)
     for which in (0, 1, 2, 6, 7):
         assert np.array_equal(a.images[which], b.images[which])
