@@ -1,0 +1,29 @@
+#!/bin/bash
+# Vector-memory path counters (TA / TCP = L1) for the bench kernels:  bash profiles/pmc_tcp.sh <tag> [extra bench args]
+set -e -o pipefail
+TAG=${1:-tcp}; shift || true
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --frames-in-flight 1 $@"
+timeout -k 10 170 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_tcp1" -- $BENCH > "$OUT/bench_pmc_tcp1.log" 2>&1 || echo "tcp1 failed"
+# (a pass with TA_BUSY_avr / TA_TA_BUSY_sum / TA_*_STALLED_* aborted inside rocprofv3 on this pool and hung the run: not collected)
+timeout -k 10 170 rocprofv3 --kernel-trace --pmc TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_tcp3" -- $BENCH > "$OUT/bench_pmc_tcp3.log" 2>&1 || echo "tcp3 failed"
+timeout -k 10 170 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM_RD --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/bench_pmc_sq.log" 2>&1 || echo "sq failed"
+python3 - "$OUT" <<'PY'
+import csv, glob, os, sys
+from collections import defaultdict
+out = sys.argv[1]
+for tag in ("pmc_tcp1", "pmc_tcp2", "pmc_tcp3", "pmc_sq"):
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            agg[row["Kernel_Name"][:48]][row["Counter_Name"]].append(float(row["Counter_Value"] or 0))
+    for k in agg:
+        if "rtrdev" not in k or "true" in k: continue
+        print(k)
+        for c, v in sorted(agg[k].items()):
+            print(f"   {c:40s} {sum(v)/len(v):16.0f}  (n={len(v)})")
+PY

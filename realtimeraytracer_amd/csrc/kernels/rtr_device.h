@@ -344,16 +344,21 @@ __device__ __forceinline__ rtr_v3 primary_dir(const RenderArgs& ra, uint32_t px,
 
 struct Accum { rtr_v3 analytic, shadowed, unshadowed, avgNormal, avgPosition; };
 
-/* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110,
- * miss.rmiss:15-27 with the constant sky).  Policy::occluded(origin, dir, tmax) answers the
- * shadow query; Policy::kShade == false (generator) skips the BRDF arithmetic but keeps the
- * exact sequence of queries. */
-template <class Policy, bool STATS>
-__device__ __forceinline__ void shade_sample(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
-                                             const HitRec& h, rtr_v3 rayDir, bool wantAnalytic, Accum& o,
-                                             Policy& pol, LocalStats& st) {
+/* What the light loops need to know about a primary hit: closesthit.rchit:53-106 + raygen.rgen:123-163. */
+struct Surface {
+    rtr_v3 hitPoint, hitNormal, viewDir, color, mDiffuse, mSpecular;
+    float roughness, metallic, om;
+    float4 t1, t2;
+};
+
+/* Miss / light-hit handling (raygen.rgen:110-121, miss.rmiss:15-27) and the surface fetch.  Returns false when the
+ * sample is finished (miss or light).  SHADE == false (shadow-ray generator) skips material and colour work but
+ * computes hitPoint / hitNormal with exactly the same operations. */
+template <bool SHADE, bool STATS>
+__device__ __forceinline__ bool fetch_surface(const DeviceScene& sc, const RenderArgs& ra, const HitRec& h, rtr_v3 rayDir,
+                                              bool wantAnalytic, Accum& o, Surface& sf, LocalStats& st) {
     if (h.custom == RTR_MISS) {                                                           /* :110-115, miss.rmiss:15-27 */
-        if (Policy::kShade) {
+        if (SHADE) {
             rtr_v3 sky = rtr_ld3(sc.skyLinear);
             if (sc.hdri.pixels) {
                 const rtr_v3 dir = rtr_normalize(rayDir);
@@ -365,14 +370,14 @@ __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const Render
             }
             o.analytic = rtr_add(o.analytic, sky); o.unshadowed = rtr_add(o.unshadowed, sky); o.shadowed = rtr_add(o.shadowed, sky);
         }
-        return;
+        return false;
     }
     if (h.custom < sc.numLights) {                                                        /* :116-121 */
-        if (Policy::kShade) {
+        if (SHADE) {
             const rtr_v3 lc = rtr_ld3(sc.lights[h.custom].color);
             o.analytic = rtr_add(o.analytic, lc); o.unshadowed = rtr_add(o.unshadowed, lc); o.shadowed = rtr_add(o.shadowed, lc);
         }
-        return;
+        return false;
     }
     const rtr_v3 camPos = rtr_ld3(ra.cam.position);
     /* closesthit.rchit:53-106 */
@@ -404,7 +409,7 @@ __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const Render
     float metallic = oi->metallic;
     float rough = oi->specular;
     rtr_v3 color = rtr_mk(0, 0, 0);
-    if (Policy::kShade) {
+    if (SHADE) {
         rtr_v3 col = rtr_ld3(oi->color);
         if (oi->usesColorMap | oi->usesSpecularMap | oi->usesMetallicMap) {
             const float4 ta = va[2], tb = vb[2], tc = vc[2];                             /* uv in floats 8,9 of the 48-B vertex */
@@ -422,7 +427,7 @@ __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const Render
     const float om = 1.0f - metallic;
     rtr_v3 mDiffuse = rtr_mk(0, 0, 0), mSpecular = rtr_mk(0, 0, 0);
     float4 t1 = make_float4(1, 0, 0, 1), t2 = make_float4(0, 0, 0, 0);
-    if (Policy::kShade) {
+    if (SHADE) {
         o.avgNormal = rtr_add(o.avgNormal, hitNormal);
         o.avgPosition = rtr_add(o.avgPosition, hitPoint);
         mDiffuse = rtr_scale(color, om);
@@ -436,6 +441,22 @@ __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const Render
             t2 = sample_lut(sc.ltc2, lu, lv);
         }
     }
+    sf.hitPoint = hitPoint; sf.hitNormal = hitNormal; sf.viewDir = viewDir; sf.color = color;
+    sf.mDiffuse = mDiffuse; sf.mSpecular = mSpecular; sf.roughness = roughness; sf.metallic = metallic; sf.om = om;
+    sf.t1 = t1; sf.t2 = t2;
+    return true;
+}
+
+/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax) answers the
+ * shadow query; Policy::kShade == false (counting / emitting the queries) skips the BRDF arithmetic but keeps the exact
+ * sequence of queries. */
+template <class Policy, bool STATS>
+__device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
+                                            const Surface& sf, bool wantAnalytic, Accum& o, Policy& pol, LocalStats& st) {
+    const rtr_v3 hitPoint = sf.hitPoint, hitNormal = sf.hitNormal, viewDir = sf.viewDir, color = sf.color;
+    const rtr_v3 mDiffuse = sf.mDiffuse, mSpecular = sf.mSpecular;
+    const float roughness = sf.roughness, om = sf.om;
+    const float4 t1 = sf.t1, t2 = sf.t2;
     const rtr_v3 shadowOrigin = rtr_madd(hitPoint, hitNormal, 0.01f);
 
     for (uint32_t li = 0; li < ra.info.numAreaLights; ++li) {                             /* :165 */
@@ -542,6 +563,16 @@ __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const Render
         o.unshadowed = rtr_add(o.unshadowed, contrib);
         o.analytic = rtr_add(o.analytic, contrib);
     }
+}
+
+/* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110, miss.rmiss:15-27). */
+template <class Policy, bool STATS>
+__device__ __forceinline__ void shade_sample(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
+                                             const HitRec& h, rtr_v3 rayDir, bool wantAnalytic, Accum& o,
+                                             Policy& pol, LocalStats& st) {
+    Surface sf;
+    if (!fetch_surface<Policy::kShade, STATS>(sc, ra, h, rayDir, wantAnalytic, o, sf, st)) return;
+    light_loops<Policy, STATS>(sc, ra, px, py, sf, wantAnalytic, o, pol, st);
 }
 
 __device__ __forceinline__ uint32_t tonemap_pack(rtr_v3 c) {                              /* raygen.rgen:345-357 */

@@ -144,7 +144,12 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
     const bool live = pixel_of(ra, q, px, lrow, py);
     LocalStats st;
     Accum acc = zero_accum();
-    /* phase 1: count */
+    /* The surface fetch (hit -> object -> indices -> vertices, a chain of dependent loads) runs ONCE per sample; the
+     * light loops then run twice over it, first counting the queries, then emitting them.  spp > 1 keeps the fetched
+     * surfaces of the samples in registers only for spp == 1 (the bench case); otherwise the fetch is repeated. */
+    const bool single = ra.spp == 1u;
+    Surface sf0;
+    bool surf0 = false;
     uint32_t n = 0;
     if (live) {
         CountPolicy cp{0};
@@ -152,7 +157,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
             const size_t k = (size_t)i * gridDim.x * kBlock + q;
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
-            shade_sample<CountPolicy, false>(sc, ra, px, py, h, primary_dir(ra, px, py, i), false, acc, cp, st);
+            Surface sf;
+            const bool surf = fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);
+            if (surf) light_loops<CountPolicy, false>(sc, ra, px, py, sf, false, acc, cp, st);
+            if (i == 0) { sf0 = sf; surf0 = surf; }
         }
         n = cp.n;
     }
@@ -168,10 +176,16 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
-        const float4 r = hitTuvp[k];
-        HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
         EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
-        shade_sample<EmitPolicy, false>(sc, ra, px, py, h, primary_dir(ra, px, py, i), false, acc, pol, st);
+        if (single) {
+            if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, false, acc, pol, st);
+        } else {
+            const float4 r = hitTuvp[k];
+            HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
+            Surface sf;
+            if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st))
+                light_loops<EmitPolicy, false>(sc, ra, px, py, sf, false, acc, pol, st);
+        }
     }
 }
 
