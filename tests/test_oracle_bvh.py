@@ -127,6 +127,58 @@ def test_bvh_vs_brute_force_primary_hits(oracle, scene_cache):
     assert (a[3] != 0xffffffff).mean() > 0.3
 
 
+
+def _translated(setup, delta, scale=1.0):
+    """desc + camera of `setup` with every instance (and light) scaled about the origin, then moved by `delta`"""
+    d = np.array(delta, np.float32)
+    inst = [A.RtrInstance.from_buffer_copy(bytes(i)) for i in setup.host.instances()]
+    lights = [A.RtrAreaLightInfo.from_buffer_copy(bytes(l)) for l in setup.host.lightInfos()]
+    for k, it in enumerate(inst):
+        m = np.array(it.transform[:], np.float32).reshape(3, 4) * np.float32(scale)
+        m[:, 3] += d
+        for j, v in enumerate(m.reshape(-1)):
+            it.transform[j] = float(v)
+        if k < len(lights):                                    # LightInfo.transform is the same matrix, column-major 4x4
+            cm = np.zeros((4, 4), np.float32); cm[:3, :] = m; cm[3, 3] = 1
+            for j, v in enumerate(cm.T.reshape(-1)):
+                lights[k].transform[j] = float(v)
+    desc = A.rtr_scene_desc.from_buffer_copy(bytes(setup.desc))
+    iarr = (A.RtrInstance * len(inst))(*inst)
+    larr = (A.RtrAreaLightInfo * len(lights))(*lights)
+    desc.instances = C.cast(iarr, C.POINTER(A.RtrInstance))
+    desc.lights = C.cast(larr, C.POINTER(A.RtrAreaLightInfo))
+    cam = A.RtrCameraData.from_buffer_copy(bytes(setup.camera))
+    for k in range(3):
+        cam.position[k] = float(np.float32(cam.position[k]) * np.float32(scale) + d[k])
+        cam.topLeftViewportCorner[k] = float(np.float32(cam.topLeftViewportCorner[k]) * np.float32(scale) + d[k])
+        cam.horizontalViewportDelta[k] = float(np.float32(cam.horizontalViewportDelta[k]) * np.float32(scale))
+        cam.verticalViewportDelta[k] = float(np.float32(cam.verticalViewportDelta[k]) * np.float32(scale))
+    return desc, cam, (iarr, larr)
+
+
+@pytest.mark.parametrize("delta,scale", [((40000.0, -25000.0, 30000.0), 1.0),      # far from the origin: fp32 ulp 0.004, padding 0.15
+                                         ((0.0, 0.0, 0.0), 1.0e-3),                 # millimetre-sized scene
+                                         ((-3.0e5, 2.0e5, 1.0e5), 4.0)])            # big and very far (primary rays end at t = 10000)
+def test_quantised_boxes_stay_conservative_when_badly_conditioned(oracle, scene_cache, delta, scale):
+    """Layout 3 keeps 16-bit planes on a scene grid; culling must stay conservative (BVH == brute force, hit for hit)
+    when the scene is tiny, huge, or far from the origin, where padding, grid step and fp32 ulp trade places."""
+    s = scenes.bunny_class(96, 54, subdiv=3)
+    desc, cam, keep = _translated(s, delta, scale)
+    st, nodes, tris = api.host_build_bvh(desc)
+    _check_bvh(desc, st, nodes, tris)
+    p = _params(96, 54, spp=1)
+    a = oracle.primary_hits(desc, cam, p, bvh=(nodes, tris, st.grid), threads=8)
+    b = oracle.primary_hits(desc, cam, p, bvh=None, threads=8)
+    for x, y, n in zip(a, b, ("t", "u", "v", "customIndex", "primitiveId")):
+        assert np.array_equal(x, y), f"{n} differs between BVH traversal and brute force"
+    assert (a[3] != 0xffffffff).mean() > 0.2
+    info = s.scene_info(0)
+    for k in range(3):
+        info.camPosition[k] = cam.position[k]
+    fa = oracle.render(desc, cam, info, p, bvh=(nodes, tris, st.grid), threads=8)
+    fb = oracle.render(desc, cam, info, p, bvh=None, threads=8)
+    assert np.array_equal(fa.images[A.IMAGE_SHADOWED], fb.images[A.IMAGE_SHADOWED])
+
 def test_oracle_frame_bvh_vs_brute_force_sponza_class(oracle, scene_cache):
     """Whole shaded frame, Sponza-class (262 k triangles), tiny resolution so brute force stays in seconds."""
     s = scenes.sponza_class(48, 27)
