@@ -264,13 +264,15 @@ def main():
         roofline = None
         if pipeline_used == 2 and trace_ms > 0:
             achieved = trace_bytes / (trace_ms * 1e-3) / 1e9
-            traffic = None
+            traffic = lookups = valu = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
                     traffic = tj.get(key, {}).get("k_shadow_trace_hbm_bytes_per_launch")
+                    lookups = tj.get(key, {}).get("k_shadow_trace_l1_tag_lookups_per_launch")
+                    valu = tj.get(key, {}).get("k_shadow_trace_valu_wave_insts_per_launch")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": "k_shadow_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -281,6 +283,12 @@ def main():
                         "avg_launch_ms_source": (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
                                                  if kern_iso else "HIP events on the launch stream over the timed region"),
                         "in_flight_event_bracket_ms": round(bracket_ms, 4) if kern_iso else None,
+                        # what actually limits the kernel (HBM is not it: the BVH is cache-resident), from committed PMC passes of this
+                        # workload and the launch time measured here; 256 L1s (one tag look-up per clock) and 1024 SIMDs (a wave
+                        # instruction occupies one for 4 clocks) at the 2.4 GHz engine clock
+                        "limits": {"l1_tag_lookup_frac": round(lookups / (256 * 2.4e9 * trace_ms * 1e-3), 4) if lookups else None,
+                                   "valu_busy_frac": round(valu * 4 / (1024 * 2.4e9 * trace_ms * 1e-3), 4) if valu else None,
+                                   "source": "profiles/pmc_traffic.json"},
                         "bvh_layout_version": int(sstats.bvhLayoutVersion)}
         elif trace_ms == 0 and kern["primary"] > 0:
             mk_ms = kern["primary"] / n
