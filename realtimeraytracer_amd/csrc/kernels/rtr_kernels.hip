@@ -208,10 +208,10 @@ constexpr uint32_t kRefillDefault = 28;    /* idle lanes that trigger a refill *
 /* Stack policy of the persistent kernel.  Ordered traversal rarely holds more than ~10 entries, so every lane gets 16
  * LDS entries (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum; the depth-bound 32-entry
  * stack limited the CU to 20 waves).  What happens to the rare ray that needs a 17th entry:
- *   production kernel (EXACT = false): the ray is abandoned — its queue index goes to an overflow list and
+ *   production kernel (k_shadow_trace): the ray is abandoned — its queue index goes to an overflow list and
  *                    k_shadow_tail finishes it from scratch with a full-depth stack — so the hot loop is pure LDS with
  *                    no spill branch (an LDS/global select made the compiler emit flat_load for EVERY pop);
- *   counting kernel  (EXACT = true): deeper entries spill to a lane-interleaved global array, so every ray is traced in
+ *   counting kernel  (k_shadow_trace_count): deeper entries spill to a lane-interleaved global array, so every ray is traced in
  *                    one go and the work counters stay exactly those of the oracle.
  * Both produce the same visibility bits. */
 template <int STACK>
@@ -226,12 +226,15 @@ struct HybridStack {
     }
 };
 
-template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
+/* Counting form (collectStats = 1): the scheduling of the production kernel below, with the work counters and a stack that
+ * spills to global memory instead of abandoning deep rays, so every ray is traced in one go and the counters are exactly
+ * the oracle's. */
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_shadow_trace_count(DeviceScene sc, const float4* __restrict__ queue,
                                                          const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                          uint8_t* __restrict__ vis, Counters* stats, uint32_t kBatch, uint32_t kRefill,
-                                                         int32_t* spill, uint32_t kInnerMin, uint32_t* overflow) {
-    constexpr bool EXACT = STATS;
+                                                         int32_t* spill, uint32_t kInnerMin) {
+    constexpr bool STATS = true;
     __shared__ int32_t s_stack[STACK * kBlock];
     int32_t* lds = s_stack + threadIdx.x;
     const HybridStack<STACK> hstack{lds, spill + (size_t)blockIdx.x * kBlock + threadIdx.x, (size_t)gridDim.x * kBlock};
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     int sp = 0;
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
     float tmax = 0.f;
-    uint32_t slot = 0, rayIndex = 0;
+    uint32_t slot = 0;
     const float tmin = 0.001f;
 
     for (;;) {
@@ -262,8 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const uint32_t avail = batchEnd - batchPos;
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (cur == kDone && prefix < avail) {
-                    rayIndex = batchPos + prefix;
-                    const size_t i = (size_t)rayIndex * 2;
+                    const size_t i = (size_t)(batchPos + prefix) * 2;
                     const float4 a = queue[i], b = queue[i + 1];
                     o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
                     if (STATS) { st.rays++; st.shadow++; }
@@ -297,10 +299,6 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const uint4* nd = sc.nodes + (size_t)cur * 2;      /* one 32-B RtrBvhNode = the whole visit */
                 const uint4 a = nd[0], b = nd[1];
                 const int2 ch = make_int2((int)b.z, (int)b.w);
-                /* speculative read of the stack top next to the node loads: its LDS latency is hidden and the pop below
-                 * needs no load of its own (index clamped so the address is always valid) */
-                int32_t top = 0;
-                if (!EXACT) top = lds[(sp > 0 ? sp - 1 : 0) * kBlock];
                 if (STATS) { st.nodes++; st.shadowNodes++; }
                 float tl, tr;
                 const bool hl = slab_pair(a.x, a.y, b.x, ga, gb, tmin, tmax, tl);
@@ -308,25 +306,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;
                 const int32_t farC = swap ? ch.x : ch.y;
-                if (EXACT) {
-                    if (hl && hr) { hstack.push(sp, farC); ++sp; cur = nearC; }
-                    else if (hl) cur = ch.x;
-                    else if (hr) cur = ch.y;
-                    else if (sp > 0) { --sp; cur = hstack.pop(sp); }
-                    else { vis[slot] = 0; cur = kDone; }
-                } else {
-                    const bool both = hl && hr, none = !(hl || hr);
-                    int32_t next = both ? nearC : (hl ? ch.x : ch.y);
-                    if (both) {
-                        if (sp < STACK) { lds[sp * kBlock] = farC; ++sp; }
-                        else { overflow[1u + atomicAdd(overflow, 1u)] = rayIndex; next = kDone; }   /* finished by k_shadow_tail */
-                    }
-                    if (none) {
-                        if (sp > 0) { --sp; next = top; }
-                        else { vis[slot] = 0; next = kDone; }
-                    }
-                    cur = next;
-                }
+                if (hl && hr) { hstack.push(sp, farC); ++sp; cur = nearC; }
+                else if (hl) cur = ch.x;
+                else if (hr) cur = ch.y;
+                else if (sp > 0) { --sp; cur = hstack.pop(sp); }
+                else { vis[slot] = 0; cur = kDone; }
             }
         }
         /* ---- leaves ---- */
@@ -346,11 +330,130 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 }
             }
             if (hit) { vis[slot] = 1; cur = kDone; }
-            else if (sp > 0) { --sp; cur = EXACT ? hstack.pop(sp) : lds[sp * kBlock]; }
+            else if (sp > 0) { --sp; cur = hstack.pop(sp); }
             else { vis[slot] = 0; cur = kDone; }
         }
     }
     if (STATS) st.flush(stats);
+}
+
+/* Production form (no counters).  Same scheduling — persistent waves, ballot refill, early-exit
+ * while-while, described above — with the hot loop stripped of everything that is not a node visit:
+ *   * a ray's result (0 visible, 1 occluded, 2 "needs a deeper stack") stays in a register and is written when the lane
+ *     is retired in the refill block, so the inner and leaf loops contain no global store and no overflow branch;
+ *   * the stack keeps a dummy slot below entry 0, so the speculative read of the top needs no index clamp;
+ *   * node and triangle addresses are 32-bit offsets from a scalar base (global_load ... saddr), not 64-bit lane math.
+ * Visibility bits are identical to k_shadow_trace_count's (tests/test_gpu_parity.py holds both against the oracle). */
+constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
+
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
+                                                              const uint32_t* __restrict__ count, uint32_t* nextBatch,
+                                                              uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
+                                                              uint32_t kInnerMin, uint32_t* overflow) {
+    __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0 is the dummy below the stack */
+    int32_t* lds = s_stack + threadIdx.x;
+    const uint32_t n = *count;
+    uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
+    bool exhausted = false;                  /* wave-uniform */
+    int32_t cur = kDone;
+    int sp = 0;                              /* entries held; the top is lds[sp * kBlock] */
+    rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
+    float tmax = 0.f;
+    uint32_t slot = 0, rayIndex = 0, res = kResNone;
+    const float tmin = 0.001f;
+    const uint4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ tris = sc.tris;
+
+    for (;;) {
+        /* ---- retire finished rays, refill idle lanes from the wave's batch ---- */
+        const unsigned long long idle = __ballot(cur == kDone);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (nIdle >= kRefill || nIdle == 64u) {
+            if (cur == kDone && res != kResNone) {
+                if (res == 2u) overflow[1u + atomicAdd(overflow, 1u)] = rayIndex;      /* finished by k_shadow_tail */
+                else vis[slot] = (uint8_t)res;
+                res = kResNone;
+            }
+            if (!exhausted) {
+                if (batchPos == batchEnd) {
+                    uint32_t b = 0;
+                    if ((threadIdx.x & 63u) == 0) b = atomicAdd(nextBatch, kBatch);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    if (b >= n) { exhausted = true; }
+                    else { batchPos = b; batchEnd = (b + kBatch < n) ? b + kBatch : n; }
+                }
+                if (!exhausted) {
+                    const uint32_t avail = batchEnd - batchPos;
+                    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (cur == kDone && prefix < avail) {
+                        rayIndex = batchPos + prefix;
+                        const float4 a = queue[rayIndex * 2u], b = queue[rayIndex * 2u + 1u];
+                        o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
+                        if (!(tmax > tmin)) {
+                            vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
+                        } else {
+                            const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+                            rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
+                            cur = 0; sp = 0; res = 0u;
+                        }
+                    }
+                    batchPos += (nIdle < avail) ? nIdle : avail;
+                }
+            }
+        }
+        if (__ballot(cur != kDone) == 0ull) {
+            if (exhausted) break;                /* every lane is idle and was retired above (nIdle == 64) */
+            continue;
+        }
+        /* ---- inner nodes ("while-while" with an early exit, see k_shadow_trace_count) ---- */
+        for (;;) {
+            const unsigned long long innerMask = __ballot(cur >= 0);
+            if (innerMask == 0ull) break;
+            if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
+            if (cur >= 0) {
+                const uint4* nd = nodes + (uint32_t)cur * 2u;      /* one 32-B RtrBvhNode = the whole visit */
+                const uint4 a = nd[0], b = nd[1];
+                const int32_t top = lds[sp * kBlock];              /* speculative: hides the pop's LDS latency under the node loads */
+                float tl, tr;
+                const bool hl = slab_pair(a.x, a.y, b.x, ga, gb, tmin, tmax, tl);
+                const bool hr = slab_pair(a.z, a.w, b.y, ga, gb, tmin, tmax, tr);
+                const bool swap = tr < tl;
+                const int32_t c0 = (int32_t)b.z, c1 = (int32_t)b.w;
+                const bool both = hl && hr, none = !(hl || hr);
+                int32_t next = both ? (swap ? c1 : c0) : (hl ? c0 : c1);
+                const bool push = both && sp < STACK;
+                if (push) { ++sp; lds[sp * kBlock] = swap ? c0 : c1; }
+                if (both && !push) { res = 2u; next = kDone; }       /* needs a 17th entry: the tail kernel redoes this ray */
+                if (none) {
+                    next = sp > 0 ? top : kDone;                    /* stack empty: visible (res is still 0) */
+                    sp = sp > 0 ? sp - 1 : 0;
+                }
+                cur = next;
+            }
+        }
+        /* ---- leaves ---- */
+        if (cur < 0 && cur != kDone) {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            bool hit = false;
+            for (uint32_t i = 0; i < cnt && !hit; ++i) {
+                const float4* tp = tris + (first + i) * 3u;
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                float t, u, v;
+                if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v) && t < tmax) {
+                    hit = true;
+                    if (__float_as_uint(q2.w) & 1u) {      /* opacity.rahit on alpha-tested geometry */
+                        LocalStats st;
+                        hit = alpha_pass<false>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
+                    }
+                }
+            }
+            if (hit) { res = 1u; cur = kDone; }
+            else if (sp > 0) { cur = lds[sp * kBlock]; --sp; }
+            else cur = kDone;                                        /* visible */
+        }
+    }
 }
 
 /* Finishes the rays the production k_shadow_trace abandoned (stack deeper than its 16 LDS entries): one ray per lane,
@@ -460,9 +563,9 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 20u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
-    if (stats) hipLaunchKernelGGL((k_shadow_trace<16, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin, ws.overflow);
+    if (stats) hipLaunchKernelGGL((k_shadow_trace_count<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
     else {
-        hipLaunchKernelGGL((k_shadow_trace<16, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin, ws.overflow);
+        hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
         hipLaunchKernelGGL(k_shadow_tail, dim3(64), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis);
     }
     if (ev) hipEventRecord(ev[3], s);
