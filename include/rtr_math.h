@@ -249,8 +249,8 @@ RTR_HD int rtr_slab(const float* bmin, const float* bmax, rtr_v3 idir, rtr_v3 oo
 }
 
 /* ---- 16-bit planes on the scene grid (BVH layout version 3, include/rtr_types.h) ----------------------------------
- * Grid from the (padded) scene bounds: 65532 steps span the extent; the origin sits 1.5 steps below the minimum so the
- * +-1 guard steps of the quantisers below stay inside [0, 65535]. */
+ * Grid from the (padded) scene bounds: 65532 steps span the extent; the origin sits 1.5 steps below the minimum so every
+ * plane of the tree lands strictly inside [0, 65535]. */
 RTR_HD void rtr_grid_from_bounds(const float* bmin, const float* bmax, float* origin, float* scale) {
     for (int k = 0; k < 3; ++k) {
         float ext = bmax[k] - bmin[k];
@@ -261,16 +261,19 @@ RTR_HD void rtr_grid_from_bounds(const float* bmin, const float* bmax, float* or
         origin[k] = bmin[k] - 1.5f * s;
     }
 }
-/* Outward quantisation: origin + qlo*scale <= v <= origin + qhi*scale in real arithmetic (x below is accurate to
- * ~0.01 step, the guard is a whole step).  floor/ceil are exact, the division is IEEE: host and device agree bit for bit. */
+/* Outward quantisation: origin + qlo*scale <= v <= origin + qhi*scale.  Evaluated in double: x is then within 2e-11 of
+ * the real quotient, so floor/ceil can be off by one only when v sits within ~1e-11 grid steps of a grid plane — a
+ * slip far inside the builder's padding.  (A whole guard step on either side, as a float evaluation needs, made flat
+ * boxes thick enough that every shadow ray started inside its own wall's leaves: +14 % triangle tests.)  floor/ceil
+ * are exact and the division is IEEE: host and device agree bit for bit. */
 RTR_HD uint32_t rtr_quant_lo(float v, float origin, float scale) {
-    float q = __builtin_floorf((v - origin) / scale) - 1.0f;
-    q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
+    double q = __builtin_floor(((double)v - (double)origin) / (double)scale);
+    q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
     return (uint32_t)q;
 }
 RTR_HD uint32_t rtr_quant_hi(float v, float origin, float scale) {
-    float q = __builtin_ceilf((v - origin) / scale) + 1.0f;
-    q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
+    double q = __builtin_ceil(((double)v - (double)origin) / (double)scale);
+    q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
     return (uint32_t)q;
 }
 /* Per-ray constants of the quantised slab test: t(q) = q * ga + gb with ga = scale * idir, gb = (origin - o) * idir.
