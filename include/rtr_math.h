@@ -219,6 +219,15 @@ RTR_HD float rtr_acos(float x) {
     return 2.0f * rtr_atan2(rtr_sqrt(1.0f - x), rtr_sqrt(1.0f + x));
 }
 
+/* b / 255.0f for b = 0..255 without the division sequence: q0 = b * fl(1/255) and one Newton step on the remainder.
+ * Equal to the correctly rounded IEEE quotient for all 256 inputs (tests/test_math.py checks it exhaustively), so the
+ * denoise kernels unpack UNORM8 with 3 vector instructions per channel while the oracle divides. */
+RTR_HD float rtr_unorm8_to_float(uint32_t b) {
+    const float x = (float)b, r = 0.0039215688593685627f;      /* fl(1/255) */
+    const float q0 = x * r;
+    return rtr_fma(rtr_fma(-255.0f, q0, x), r, q0);
+}
+
 /* ---- ray / box / triangle ---------------------------------------------------------------- */
 /* Direction components are kept away from 0 so 1/d is finite and the slab test never
  * forms inf*0 or inf-inf (no NaN reaches rtr_hwmin/rtr_hwmax). */

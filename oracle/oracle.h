@@ -66,6 +66,7 @@ float    oracle_pow(float x, float y);
 float    oracle_log2(float x);
 float    oracle_exp2(float x);
 uint32_t oracle_pack_bgra8(float r, float g, float b);
+float    oracle_unorm8_to_float_fast(uint32_t b);   /* rtr_unorm8_to_float: the product's division-free form */
 int      oracle_mt(const float* o, const float* d, const float* v0, const float* e1, const float* e2,
                    float tmin, float* tuv);
 

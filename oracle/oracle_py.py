@@ -57,6 +57,8 @@ def lib():
             getattr(L, n).argtypes = [A.f32]
         L.oracle_pack_bgra8.restype = A.u32
         L.oracle_pack_bgra8.argtypes = [A.f32, A.f32, A.f32]
+        L.oracle_unorm8_to_float_fast.restype = A.f32
+        L.oracle_unorm8_to_float_fast.argtypes = [A.u32]
         L.oracle_mt.restype = C.c_int
         L.oracle_mt.argtypes = [C.POINTER(A.f32)] * 5 + [A.f32, C.POINTER(A.f32)]
         _lib = L

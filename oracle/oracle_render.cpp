@@ -677,6 +677,7 @@ float oracle_pow(float x, float y) { return rtr_pow(x, y); }
 float oracle_log2(float x) { return rtr_log2(x); }
 float oracle_exp2(float x) { return rtr_exp2(x); }
 uint32_t oracle_pack_bgra8(float r, float g, float b) { return rtr_pack_bgra8(r, g, b); }
+float oracle_unorm8_to_float_fast(uint32_t b) { return rtr_unorm8_to_float(b); }
 int oracle_mt(const float* o, const float* d, const float* v0, const float* e1, const float* e2, float tmin, float* tuv) {
     return rtr_mt_intersect(rtr_ld3(o), rtr_ld3(d), rtr_ld3(v0), rtr_ld3(e1), rtr_ld3(e2), tmin, &tuv[0], &tuv[1], &tuv[2]);
 }

@@ -856,11 +856,9 @@ int rtr_denoise_combine(rtr_frame* f, int iterations) {
         const int step = (i + 1) * 1;                                   /* (i + 1) * DENOISING_STRENGTH */
         hipError_t e;
         if (denoisingOutput == 1) {
-            e = rtrdev::launch_denoise(un, dun, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
-            if (e == hipSuccess) e = rtrdev::launch_denoise(sh, dsh, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
+            e = rtrdev::launch_denoise_pair(un, dun, sh, dsh, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
         } else {
-            e = rtrdev::launch_denoise(dun, un, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
-            if (e == hipSuccess) e = rtrdev::launch_denoise(dsh, sh, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
+            e = rtrdev::launch_denoise_pair(dun, un, dsh, sh, nrm, pos, f->width, f->rows, step, 1.0f, 0.001f, 0.001f, st);
         }
         if (e != hipSuccess) return fail(RTR_ERR_HIP, "denoise launch: %s", hipGetErrorString(e));
         denoisingOutput = 1 - denoisingOutput;

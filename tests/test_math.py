@@ -69,6 +69,15 @@ def test_unorm8_pack(oracle):
     assert L.oracle_pack_bgra8(0.5, 0.5, 0.5) == 0xFF808080          # 127.5 rounds to even = 128
 
 
+def test_unorm8_unpack_without_division_is_exact(oracle):
+    """The denoise kernels unpack UNORM8 as b*fl(1/255) + one Newton step (rtr_unorm8_to_float); the oracle divides.
+    Both must agree for every byte."""
+    import numpy as np
+    L = oracle.lib()
+    for b in range(256):
+        assert np.float32(L.oracle_unorm8_to_float_fast(b)) == np.float32(b) / np.float32(255.0), b
+
+
 def test_moeller_trumbore_edge_cases(oracle):
     """intersect.rint:18-41 semantics: EPSILON rejection, u/v/u+v rejections, t > tmin, no back-face culling."""
     L = oracle.lib()
