@@ -103,14 +103,14 @@ __device__ __forceinline__ float4 sample_tex(const DeviceTexture& tx, float u, f
         const uint32_t q11 = *(gptr32)(p + ((size_t)y1 * W + x1) * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float t00 = (float)((q00 >> (8 * k)) & 0xffu) / 255.0f, t10 = (float)((q10 >> (8 * k)) & 0xffu) / 255.0f;
-            const float t01 = (float)((q01 >> (8 * k)) & 0xffu) / 255.0f, t11 = (float)((q11 >> (8 * k)) & 0xffu) / 255.0f;
+            const float t00 = rtr_unorm8_to_float((q00 >> (8 * k)) & 0xffu), t10 = rtr_unorm8_to_float((q10 >> (8 * k)) & 0xffu);
+            const float t01 = rtr_unorm8_to_float((q01 >> (8 * k)) & 0xffu), t11 = rtr_unorm8_to_float((q11 >> (8 * k)) & 0xffu);
             const float a = rtr_fma(t10 - t00, fx, t00), b = rtr_fma(t11 - t01, fx, t01);
             o[k] = rtr_fma(b - a, fy, a);
         }
     } else {
-        const float t00 = (float)p[(size_t)y0 * W + x0] / 255.0f, t10 = (float)p[(size_t)y0 * W + x1] / 255.0f;
-        const float t01 = (float)p[(size_t)y1 * W + x0] / 255.0f, t11 = (float)p[(size_t)y1 * W + x1] / 255.0f;
+        const float t00 = rtr_unorm8_to_float(p[(size_t)y0 * W + x0]), t10 = rtr_unorm8_to_float(p[(size_t)y0 * W + x1]);
+        const float t01 = rtr_unorm8_to_float(p[(size_t)y1 * W + x0]), t11 = rtr_unorm8_to_float(p[(size_t)y1 * W + x1]);
         const float a = rtr_fma(t10 - t00, fx, t00), b = rtr_fma(t11 - t01, fx, t01);
         o[0] = rtr_fma(b - a, fy, a); o[1] = 0.0f; o[2] = 0.0f; o[3] = 1.0f;
     }
@@ -167,14 +167,19 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
     const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
     rtr_v3 ga, gb;                                        /* t(q) = q * ga + gb (rtr_math.h) */
     rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
+    /* nodes and triangles through buffer resources: a visit's address is one 32-bit shift (see k_shadow_trace) */
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, 0, 0xffffffff, 0x00020000);
     bool found = false;
     float limit = tmax;
     int sp = 0;
     int32_t cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const uint4* n = sc.nodes + (size_t)cur * 2;
-            const uint4 a = n[0], b = n[1];
+            const int32_t nodeOff = cur << 5;
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, 0);
+            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, 0);
             const int2 ch = make_int2((int)b.z, (int)b.w);
             if (STATS) { st.nodes++; if (ANY) st.shadowNodes++; }
             float tl, tr;
@@ -193,8 +198,13 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = code >> 3, count = (code & 7u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
-                const float4* tp = sc.tris + (size_t)(first + i) * 3;
-                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                const int32_t triOff = (int32_t)((first + i) * 48u);
+                const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff, 0, 0);
+                const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 16, 0, 0);
+                const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 32, 0, 0);
+                const float4 q0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+                const float4 q1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+                const float4 q2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
                 if (STATS) { st.tris++; if (ANY) st.shadowTris++; }
                 float t, u, v;
                 if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v)) {
