@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N",
                     help="single-GPU rehearsal of what ONE rank does in an N-GPU run: renders shard 0 of N with the same two-stream "
                          "frame pipelining, without the gather (the printed value is this rank's rays/s, not a job total)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames pipelined on separate streams (0 = default: 3 at N=1, 4 when the frame is sharded over N>1 GPUs; 1 = one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames pipelined on separate streams (0 = default: 4, at every N; 1 = one frame at a time)")
     ap.add_argument("--accumulate", type=int, default=1, metavar="K",
                     help="a step = K frames (frame = 0..K-1) summed in the float HDR buffer and tonemapped once (BASELINE config 5: "
                          "--width 3840 --height 2160 --accumulate 16)")
@@ -104,11 +104,11 @@ def main():
     nshards = emu if emu else world
     # Several frames are kept in flight on separate streams (one context each, ONE shared scene): the tails of one
     # frame's latency-bound kernels, its small kernels and its RCCL gather overlap the next frames' kernels.  At N=1 that
-    # is worth ~12 % (the 1.1 ms of primary / queue-build / resolve work hides under the traversal kernel's tail); for a
+    # is worth ~13 % (part of the 1.1 ms of primary / queue-build / resolve work hides under the traversal kernel); for a
     # 1/8-frame shard no single kernel can fill the GPU (259 k primary rays for 524 k lane slots), so it is where the
-    # strong scaling comes from (one rank of 8: 0.93 -> 0.53 ms per frame).  Frames are independent, so results are
-    # unchanged; the per-launch HIP-event durations stay valid for the dominant kernel at <= 3 frames in flight.
-    nbuf = args.frames_in_flight or (4 if nshards > 1 else 3)
+    # strong scaling comes from (one rank of 8: 0.82 -> 0.44 ms per frame).  Frames are independent, so results are
+    # unchanged.  Per-kernel durations are taken from a one-frame-at-a-time pass after the timed region (see below).
+    nbuf = args.frames_in_flight or 4
     ctxs = [api.Context(local_rank) for _ in range(nbuf)]
     streams = [torch.cuda.Stream(device=device) for _ in range(nbuf)]
     for c, st_ in zip(ctxs, streams):
