@@ -341,7 +341,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace_count(DeviceScene sc, c
  * while-while, described above — with the hot loop stripped of everything that is not a node visit:
  *   * a ray's result (0 visible, 1 occluded, 2 "needs a deeper stack") stays in a register and is written when the lane
  *     is retired in the refill block, so the inner and leaf loops contain no global store and no overflow branch;
- *   * the stack keeps a dummy slot below entry 0, so the speculative read of the top needs no index clamp;
+ *   * the slot below stack entry 0 holds the "ray finished" code, so a pop needs no empty-stack test and the speculative
+ *     read of the top needs no index clamp;
  *   * node and triangle addresses are 32-bit offsets from a scalar base (global_load ... saddr), not 64-bit lane math.
  * Visibility bits are identical to k_shadow_trace_count's (tests/test_gpu_parity.py holds both against the oracle). */
 constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
@@ -351,8 +352,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
                                                               uint32_t kInnerMin, uint32_t* overflow) {
-    __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0 is the dummy below the stack */
+    __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
     int32_t* lds = s_stack + threadIdx.x;
+    lds[0] = kDone;
     const uint32_t n = *count;
     uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
     bool exhausted = false;                  /* wave-uniform */
@@ -425,14 +427,12 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 const bool swap = tr < tl;
                 const int32_t c0 = (int32_t)b.z, c1 = (int32_t)b.w;
                 const bool both = hl && hr, none = !(hl || hr);
-                int32_t next = both ? (swap ? c1 : c0) : (hl ? c0 : c1);
+                const bool second = both ? swap : !hl;               /* descend into child 1? (near child if both are hit) */
+                int32_t next = second ? c1 : c0;
                 const bool push = both && sp < STACK;
                 if (push) { ++sp; lds[sp * kBlock] = swap ? c0 : c1; }
                 if (both && !push) { res = 2u; next = kDone; }       /* needs a 17th entry: the tail kernel redoes this ray */
-                if (none) {
-                    next = sp > 0 ? top : kDone;                    /* stack empty: visible (res is still 0) */
-                    sp = sp > 0 ? sp - 1 : 0;
-                }
+                if (none) { next = top; --sp; }                      /* slot 0 holds kDone: popping an empty stack ends the ray (visible) */
                 cur = next;
             }
         }
@@ -459,8 +459,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                 }
             }
             if (hit) { res = 1u; cur = kDone; }
-            else if (sp > 0) { cur = lds[sp * kBlock]; --sp; }
-            else cur = kDone;                                        /* visible */
+            else { cur = lds[sp * kBlock]; --sp; }                   /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }
     }
 }
