@@ -92,7 +92,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # RTR_BENCH_FORCE_DIST=1 with one rank takes the N>1 code path (process group, gather, de-interleave, verify) through real
+    # RCCL on a single GPU: a rehearsal of the collective calls, not a measurement
+    dist_on = world > 1 or os.environ.get("RTR_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -123,7 +128,7 @@ def main():
     for fr, lo in zip(frames, locals_):
         fr.bind_external(A.IMAGE_SHADOWED, lo.data_ptr(), lo.numel() * 4)
     frame, local = frames[0], locals_[0]
-    gathered = [torch.zeros((world, rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if (rank == 0 and world > 1) else None
+    gathered = [torch.zeros((world, rows, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if (rank == 0 and dist_on) else None
     fulls = [torch.zeros((H, W), dtype=torch.int32, device=device) for _ in range(nbuf)] if rank == 0 else None
     full = fulls[0] if fulls else None
 
@@ -142,7 +147,7 @@ def main():
     fs = frame.stats()
     counts = torch.tensor([fs.numRays, fs.numPrimaryRays, fs.numShadowRays, fs.algorithmicBytes, fs.shadowTraceBytes],
                           dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     # a step of K accumulated frames issues K times the rays of one frame: ray counts do not depend on the frame number
     # (every hit issues numLights x light-triangles x shadow-rays rays; only the sample positions change)
@@ -180,7 +185,7 @@ def main():
             return
         works[buf].wait()
         works[buf] = None
-        if rank == 0 and world > 1:
+        if rank == 0 and dist_on:
             api.deinterleave_bands(ctxs[buf], gathered[buf].data_ptr(), fulls[buf].data_ptr(), W, H, args.band_rows, world)
 
     last_buf = [0]
@@ -205,7 +210,7 @@ def main():
             finish(b)                                   # its gather (stream-level wait) + de-interleave on rank 0
             render_step(frames[b], i, p_run, True)
             inflight[b] = True
-            if world > 1:
+            if dist_on:
                 works[b] = gather_async(b)              # RCCL gather to rank 0; runs under the other streams' kernels
 
     def drain():
@@ -215,7 +220,7 @@ def main():
                 finish(b)
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +236,7 @@ def main():
     torch.cuda.synchronize()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -322,7 +327,7 @@ def main():
     if rank == 0 and emu:
         out["emulated_rank_of"] = emu
         out["config"]["workload"] += f" [single-GPU rehearsal of ONE rank of {emu}: shard 0 only, no gather; value = this rank's rays/s]"
-    if rank == 0 and world == 1 and not emu and not args.no_cpu_baseline:
+    if rank == 0 and not dist_on and not emu and not args.no_cpu_baseline:
         from oracle import oracle_py as O
         threads = min(os.cpu_count() or 1, 16)
         bvh = scene.export_bvh()
@@ -353,7 +358,7 @@ def main():
             gpu = locals_[0].cpu().numpy().view(np.uint32)
             bad = int((gpu != r.images[A.IMAGE_SHADOWED]).sum())
             out["verify"] = {"pixels_checked": int(gpu.size), "pixels_differing_vs_oracle": bad}
-    elif rank == 0 and world == 1:
+    elif rank == 0 and not dist_on:
         out["cpu_baseline"] = None
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -367,7 +372,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

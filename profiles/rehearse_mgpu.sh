@@ -16,3 +16,5 @@ for n in 2 4 8; do
 done
 RTR_BENCH_SAME_DEVICE=1 timeout -k 5 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 7 --warmup 2 --backend gloo 2>/dev/null | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.readlines()[-1]); print('gloo 2 ranks on one GPU: verify', j['verify'])"
 RTR_BENCH_SAME_DEVICE=1 timeout -k 5 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 4 --steps 6 --warmup 1 --backend gloo 2>/dev/null | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.readlines()[-1]); print('gloo 4 ranks on one GPU: verify', j['verify'])"
+#  (3) RTR_BENCH_FORCE_DIST=1 : ONE rank through the real RCCL process group (init, async gather, de-interleave, verify)
+RTR_BENCH_FORCE_DIST=1 timeout -k 5 200 python bench.py --steps 12 --warmup 3 2>/dev/null | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.readlines()[-1]); print('RCCL, 1 rank: verify', j['verify'], j['value'], 'Mrays/s incl. the self-gather of the whole frame')"
