@@ -7,6 +7,9 @@
 //   * .hdr -> 8 bit: c = clamp(pow(c, 1/2.2) * 255 + 0.5), alpha 255 (the reference loads its 4k HDRI this way,
 //     src/app/application.cppm:250);
 //   * 16-bit PNG samples keep their high byte.
+//   * TGA (types 1/2/3 and their RLE forms 9/10/11; 8-bit grey, 8-bit colour-mapped, 15/16/24/32-bit true colour; either
+//     vertical origin) and BMP (BI_RGB 8-bit palettised / 24 / 32 bit, BI_BITFIELDS 32 bit; bottom-up or top-down; a 32-bit
+//     file whose alpha bytes are all zero is opaque, as in stb_image).  TGA has no signature: it is tried for ".tga" files.
 // JPEG and the other stb formats are not decoded: load_image throws "unsupported image format" rather than guess.
 #pragma once
 #include <algorithm>
@@ -280,6 +283,148 @@ inline void decode_hdr(const std::vector<uint8_t>& f, int& w, int& h, std::vecto
     }
 }
 
+inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// Truevision TGA 2.0 specification.  Output: 1 (grey), 3 or 4 samples per pixel, top row first.
+inline void decode_tga(const std::vector<uint8_t>& f, int& w, int& h, int& src_channels, std::vector<uint8_t>& px) {
+    auto bad = [](const char* m) { throw std::runtime_error(std::string("Failed to load image: bad TGA (") + m + ")"); };
+    if (f.size() < 18) bad("truncated header");
+    const int idLen = f[0], cmapType = f[1], type = f[2];
+    const int cmapFirst = le16(&f[3]), cmapLen = le16(&f[5]), cmapBits = f[7];
+    w = le16(&f[12]); h = le16(&f[14]);
+    const int bpp = f[16], desc = f[17];
+    const bool rle = type >= 9 && type <= 11;
+    const int base = rle ? type - 8 : type;
+    if (base < 1 || base > 3 || w <= 0 || h <= 0) bad("unsupported image type or size");
+    if ((base == 1) != (cmapType == 1)) bad("colour map / image type mismatch");
+    auto channels_of = [&](int bits, bool grey) -> int {
+        if (grey) return bits == 8 ? 1 : 0;
+        if (bits == 15 || bits == 16 || bits == 24) return 3;
+        if (bits == 32) return 4;
+        return 0;
+    };
+    const int pixBits = base == 1 ? cmapBits : bpp;
+    src_channels = channels_of(pixBits, base == 3);
+    if (src_channels == 0 || (base == 1 && bpp != 8)) bad("unsupported bit depth");
+    auto expand = [&](const uint8_t* s, int bits, uint8_t* d) {      // file order is B,G,R(,A); 15/16 bit is A1 R5 G5 B5
+        if (bits == 8) d[0] = s[0];
+        else if (bits == 15 || bits == 16) {
+            const int v = le16(s);
+            d[0] = (uint8_t)((((v >> 10) & 31) * 255) / 31); d[1] = (uint8_t)((((v >> 5) & 31) * 255) / 31); d[2] = (uint8_t)(((v & 31) * 255) / 31);
+        } else { d[0] = s[2]; d[1] = s[1]; d[2] = s[0]; if (bits == 32) d[3] = s[3]; }
+    };
+    size_t pos = 18 + (size_t)idLen;
+    std::vector<uint8_t> palette;
+    if (cmapType == 1) {
+        const int eb = (cmapBits + 7) / 8;
+        if (pos + (size_t)cmapLen * eb > f.size()) bad("truncated colour map");
+        if (base == 1) {
+            palette.resize((size_t)cmapLen * src_channels);
+            for (int i = 0; i < cmapLen; ++i) expand(&f[pos + (size_t)i * eb], cmapBits, &palette[(size_t)i * src_channels]);
+        }
+        pos += (size_t)cmapLen * eb;
+    }
+    const int fileBytes = (bpp + 7) / 8;
+    px.assign((size_t)w * h * src_channels, 0);
+    std::vector<uint8_t> raw((size_t)fileBytes);
+    size_t count = 0, total = (size_t)w * h;
+    auto put = [&](const uint8_t* s) {
+        uint8_t* d = &px[count * src_channels];
+        if (base == 1) {
+            const int idx = (int)s[0] - cmapFirst;
+            if (idx < 0 || idx >= cmapLen) bad("palette index out of range");
+            std::memcpy(d, &palette[(size_t)idx * src_channels], (size_t)src_channels);
+        } else expand(s, bpp, d);
+        ++count;
+    };
+    while (count < total) {
+        if (!rle) {
+            if (pos + (size_t)fileBytes > f.size()) bad("truncated pixel data");
+            put(&f[pos]); pos += (size_t)fileBytes;
+        } else {
+            if (pos >= f.size()) bad("truncated RLE stream");
+            const int head = f[pos++], n = (head & 127) + 1;
+            if (count + (size_t)n > total) bad("RLE packet overruns the image");
+            if (head & 128) {
+                if (pos + (size_t)fileBytes > f.size()) bad("truncated RLE stream");
+                for (int i = 0; i < n; ++i) put(&f[pos]);
+                pos += (size_t)fileBytes;
+            } else {
+                if (pos + (size_t)n * fileBytes > f.size()) bad("truncated RLE stream");
+                for (int i = 0; i < n; ++i) { put(&f[pos]); pos += (size_t)fileBytes; }
+            }
+        }
+    }
+    if (!(desc & 0x20)) {                                            // bit 5 clear: first row in the file is the bottom row
+        const size_t row = (size_t)w * src_channels;
+        for (int y = 0; y < h / 2; ++y) std::swap_ranges(px.begin() + (size_t)y * row, px.begin() + (size_t)(y + 1) * row, px.begin() + (size_t)(h - 1 - y) * row);
+    }
+    if (desc & 0x10) {                                               // bit 4: rows stored right to left
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w / 2; ++x)
+                std::swap_ranges(&px[((size_t)y * w + x) * src_channels], &px[((size_t)y * w + x + 1) * src_channels], &px[((size_t)y * w + (w - 1 - x)) * src_channels]);
+    }
+}
+
+// Windows BMP (BITMAPCOREHEADER / BITMAPINFOHEADER and later).  Output: 3 or 4 samples per pixel, top row first.
+inline void decode_bmp(const std::vector<uint8_t>& f, int& w, int& h, int& src_channels, std::vector<uint8_t>& px) {
+    auto bad = [](const char* m) { throw std::runtime_error(std::string("Failed to load image: bad BMP (") + m + ")"); };
+    if (f.size() < 26) bad("truncated header");
+    const uint32_t dataOff = le32(&f[10]), hdr = le32(&f[14]);
+    int bpp; uint32_t comp = 0; int32_t hs;
+    if (hdr == 12) { w = le16(&f[18]); hs = (int16_t)le16(&f[20]); bpp = le16(&f[24]); }
+    else if (hdr >= 40 && f.size() >= 14 + (size_t)hdr) { w = (int32_t)le32(&f[18]); hs = (int32_t)le32(&f[22]); bpp = le16(&f[28]); comp = le32(&f[30]); }
+    else { bad("unsupported header size"); return; }
+    const bool topDown = hs < 0;
+    h = topDown ? -hs : hs;
+    if (w <= 0 || h <= 0) bad("bad size");
+    uint32_t mr = 0x00ff0000u, mg = 0x0000ff00u, mb = 0x000000ffu, ma = 0xff000000u;
+    if (comp == 3) {
+        if (bpp != 32) bad("BI_BITFIELDS is decoded for 32-bit files only");
+        const size_t mo = hdr == 40 ? 54 : 54;                       // masks follow the 40-byte header / are fields of the V4+ headers
+        if (f.size() < mo + 12) bad("truncated bit masks");
+        mr = le32(&f[mo]); mg = le32(&f[mo + 4]); mb = le32(&f[mo + 8]);
+        ma = hdr >= 56 && f.size() >= mo + 16 ? le32(&f[mo + 12]) : 0u;
+        auto byte_mask = [](uint32_t m) { return m == 0u || m == 0xffu || m == 0xff00u || m == 0xff0000u || m == 0xff000000u; };
+        if (!byte_mask(mr) || !byte_mask(mg) || !byte_mask(mb) || !byte_mask(ma) || !mr || !mg || !mb) bad("only byte-aligned 8-bit masks are decoded");
+    } else if (comp != 0) bad("compressed BMP (RLE / JPEG / PNG payload) is not decoded");
+    if (bpp != 8 && bpp != 24 && bpp != 32) bad("only 8-bit palettised, 24-bit and 32-bit files are decoded");
+    std::vector<uint8_t> palette;
+    if (bpp == 8) {
+        const int eb = hdr == 12 ? 3 : 4;
+        uint32_t used = hdr >= 40 ? le32(&f[46]) : 0u;
+        if (used == 0 || used > 256) used = 256;
+        const size_t po = 14 + (size_t)hdr;
+        if (po + (size_t)used * eb > f.size()) bad("truncated palette");
+        palette.assign(256 * 3, 0);
+        for (uint32_t i = 0; i < used; ++i) { palette[i * 3] = f[po + i * eb + 2]; palette[i * 3 + 1] = f[po + i * eb + 1]; palette[i * 3 + 2] = f[po + i * eb]; }
+    }
+    src_channels = bpp == 32 ? 4 : 3;
+    const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+    if ((size_t)dataOff + stride * h > f.size()) bad("truncated pixel data");
+    px.assign((size_t)w * h * src_channels, 0);
+    auto shift_of = [](uint32_t m) { int s = 0; while (m && !(m & 1u)) { m >>= 1; ++s; } return s; };
+    const int sr = shift_of(mr), sg = shift_of(mg), sb = shift_of(mb), sa = shift_of(ma);
+    bool anyAlpha = false;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = &f[dataOff + stride * (size_t)(topDown ? y : h - 1 - y)];
+        for (int x = 0; x < w; ++x) {
+            uint8_t* d = &px[((size_t)y * w + x) * src_channels];
+            if (bpp == 8) { std::memcpy(d, &palette[(size_t)row[x] * 3], 3); }
+            else if (bpp == 24) { d[0] = row[x * 3 + 2]; d[1] = row[x * 3 + 1]; d[2] = row[x * 3]; }
+            else {
+                const uint32_t v = le32(&row[(size_t)x * 4]);
+                d[0] = (uint8_t)((v & mr) >> sr); d[1] = (uint8_t)((v & mg) >> sg); d[2] = (uint8_t)((v & mb) >> sb);
+                d[3] = ma ? (uint8_t)((v & ma) >> sa) : 255;
+                anyAlpha |= d[3] != 0;
+            }
+        }
+    }
+    if (bpp == 32 && !anyAlpha)                                      // all-zero alpha channel = an opaque image (stb_image does the same)
+        for (size_t i = 3; i < px.size(); i += 4) px[i] = 255;
+}
+
 inline std::vector<uint8_t> read_file(const std::string& path) {
     std::ifstream in(path, std::ios::binary | std::ios::ate);
     if (!in) throw std::runtime_error("Failed to load image: " + path);
@@ -300,6 +445,8 @@ inline Image load_image(const std::string& path, int desired_channels, bool flip
     static const uint8_t pngsig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (f.size() >= 8 && std::memcmp(f.data(), pngsig, 8) == 0) detail::decode_png(f, w, h, sc, px);
     else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) detail::decode_pnm(f, w, h, sc, px);
+    else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') detail::decode_bmp(f, w, h, sc, px);
+    else if (path.size() >= 4 && (path.compare(path.size() - 4, 4, ".tga") == 0 || path.compare(path.size() - 4, 4, ".TGA") == 0)) detail::decode_tga(f, w, h, sc, px);
     else if (f.size() >= 10 && (std::memcmp(f.data(), "#?RADIANCE", 10) == 0 || std::memcmp(f.data(), "#?RGBE", 6) == 0)) {
         std::vector<float> rgb;
         detail::decode_hdr(f, w, h, rgb);
@@ -310,7 +457,7 @@ inline Image load_image(const std::string& path, int desired_channels, bool flip
             if (z > 255.f) z = 255.f;
             px[i] = (uint8_t)(int)z;
         }
-    } else throw std::runtime_error("Failed to load image: " + path + " (unsupported image format: PNG, binary PGM/PPM and Radiance HDR are decoded)");
+    } else throw std::runtime_error("Failed to load image: " + path + " (unsupported image format: PNG, TGA, BMP, binary PGM/PPM and Radiance HDR are decoded)");
     Image out; out.width = w; out.height = h; out.channels = desired_channels;
     out.pixels.resize((size_t)w * h * desired_channels);
     for (int y = 0; y < h; ++y) {

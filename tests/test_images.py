@@ -88,6 +88,135 @@ def test_pnm_and_hdr(tmp_path):
         assert np.all(got[:, :, 3] == 255)
 
 
+def _tga(a, image_type, top_left, rle=False, palette=None, bits16=False):
+    """a: (h, w) uint8 for grey / palette indices, (h, w, 3|4) for true colour (RGB[A]); rows given top first"""
+    h, w = a.shape[:2]
+    if image_type == 1:
+        bpp, cmap = 8, b"".join(bytes([c[2], c[1], c[0]]) for c in palette)
+        head = struct.pack("<BBBHHBHHHHBB", 0, 1, 9 if rle else 1, 0, len(palette), 24, 0, 0, w, h, 8, 0x20 if top_left else 0)
+        pix = [bytes([v]) for v in a.reshape(-1)]
+    elif image_type == 3:
+        bpp, cmap = 8, b""
+        head = struct.pack("<BBBHHBHHHHBB", 0, 0, 11 if rle else 3, 0, 0, 0, 0, 0, w, h, 8, 0x20 if top_left else 0)
+        pix = [bytes([v]) for v in a.reshape(-1)]
+    else:
+        c = a.shape[2]
+        cmap = b""
+        if bits16:
+            bpp = 16
+            pix = [struct.pack("<H", ((int(p[0]) >> 3) << 10) | ((int(p[1]) >> 3) << 5) | (int(p[2]) >> 3)) for p in a.reshape(-1, c)]
+        else:
+            bpp = 8 * c
+            pix = [bytes([p[2], p[1], p[0]]) + (bytes([p[3]]) if c == 4 else b"") for p in a.reshape(-1, c)]
+        head = struct.pack("<BBBHHBHHHHBB", 0, 0, 10 if rle else 2, 0, 0, 0, 0, 0, w, h, bpp, (0x20 if top_left else 0) | (8 if c == 4 else 0))
+    rows = [pix[y * w:(y + 1) * w] for y in range(h)]
+    if not top_left:
+        rows = rows[::-1]
+    flat = [q for r in rows for q in r]
+    if not rle:
+        body = b"".join(flat)
+    else:
+        body, i = b"", 0
+        while i < len(flat):
+            run = 1
+            while i + run < len(flat) and run < 128 and flat[i + run] == flat[i]:
+                run += 1
+            if run > 1:
+                body += bytes([0x80 | (run - 1)]) + flat[i]; i += run
+            else:
+                n = 1
+                while i + n < len(flat) and n < 128 and (i + n + 1 >= len(flat) or flat[i + n] != flat[i + n + 1]):
+                    n += 1
+                body += bytes([n - 1]) + b"".join(flat[i:i + n]); i += n
+    return head + cmap + body
+
+
+def test_tga_variants(tmp_path):
+    """Truevision TGA: true colour 24/32/16 bit, grey, colour-mapped, RLE, both vertical origins (stb_image: .tga)."""
+    a = _rng_img(13, 21, 4, 7)
+    a[3:9, 2:19] = a[3, 2]                                # runs for the RLE packets
+    flip = lambda x: x[::-1]                              # stbi_set_flip_vertically_on_load(true)
+    for top_left in (True, False):
+        for rle in (False, True):
+            p = str(tmp_path / f"c{int(top_left)}{int(rle)}.tga")
+            open(p, "wb").write(_tga(a, 2, top_left, rle))
+            assert np.array_equal(host.load_image(p), flip(a)), (top_left, rle)
+            open(p, "wb").write(_tga(a[:, :, :3], 2, top_left, rle))
+            got = host.load_image(p)
+            assert np.array_equal(got[:, :, :3], flip(a[:, :, :3])) and np.all(got[:, :, 3] == 255)
+            s = flip(a[:, :, :3]).astype(np.uint32)
+            assert np.array_equal(host.load_image(p, grayscale=True)[:, :, 0], ((s[..., 0] * 77 + s[..., 1] * 150 + s[..., 2] * 29) >> 8).astype(np.uint8))
+            open(p, "wb").write(_tga(a[:, :, 0], 3, top_left, rle))
+            assert np.array_equal(host.load_image(p, grayscale=True)[:, :, 0], flip(a[:, :, 0]))
+            assert np.array_equal(host.load_image(p)[:, :, :3], flip(a[:, :, :1]).repeat(3, 2))
+            pal = [tuple(int(v) for v in c) for c in _rng_img(1, 40, 3, 9)[0]]
+            idx = (a[:, :, 0] % 40).astype(np.uint8)
+            open(p, "wb").write(_tga(idx, 1, top_left, rle, palette=pal))
+            assert np.array_equal(host.load_image(p)[:, :, :3], flip(np.array(pal, np.uint8)[idx]))
+    p = str(tmp_path / "r5g5b5.tga")
+    open(p, "wb").write(_tga(a[:, :, :3], 2, True, bits16=True))
+    exp = ((a[:, :, :3] >> 3).astype(np.uint32) * 255 // 31).astype(np.uint8)
+    assert np.array_equal(host.load_image(p)[:, :, :3], flip(exp))
+    bad = str(tmp_path / "trunc.tga")
+    open(bad, "wb").write(_tga(a, 2, True)[:100])
+    with pytest.raises(host.HostError):
+        host.load_image(bad)
+
+
+def _bmp(a, bpp, top_down=False, bitfields=False, palette=None):
+    h, w = a.shape[:2]
+    stride = ((w * bpp + 31) // 32) * 4
+    rows = []
+    for y in range(h):
+        r = a[y]
+        if bpp == 8:
+            raw = bytes(r.tolist())
+        elif bpp == 24:
+            raw = r[:, [2, 1, 0]].tobytes()
+        elif bitfields:                                    # masks: R = 0x000000ff, G = 0x0000ff00, B = 0x00ff0000, A = 0xff000000
+            raw = r[:, [0, 1, 2, 3]].tobytes()
+        else:
+            raw = r[:, [2, 1, 0, 3]].tobytes()
+        rows.append(raw + b"\0" * (stride - len(raw)))
+    if not top_down:
+        rows = rows[::-1]
+    pal = b"".join(bytes([c[2], c[1], c[0], 0]) for c in palette) if palette else b""
+    hdr_size = 56 if bitfields else 40
+    masks = struct.pack("<IIII", 0xff, 0xff00, 0xff0000, 0xff000000) if bitfields else b""
+    off = 14 + 40 + len(masks) + len(pal)
+    info = struct.pack("<IiiHHIIiiII", hdr_size, w, -h if top_down else h, 1, bpp, 3 if bitfields else 0, stride * h, 2835, 2835, len(palette) if palette else 0, 0)
+    return b"BM" + struct.pack("<IHHI", off + stride * h, 0, 0, off) + info + masks + pal + b"".join(rows)
+
+
+def test_bmp_variants(tmp_path):
+    """Windows BMP: 24-bit with row padding, 32-bit BI_RGB (all-zero alpha = opaque), 32-bit BI_BITFIELDS, 8-bit palettised,
+    bottom-up and top-down."""
+    a = _rng_img(11, 19, 4, 21)
+    flip = lambda x: x[::-1]
+    for top_down in (False, True):
+        p = str(tmp_path / f"t{int(top_down)}.bmp")
+        open(p, "wb").write(_bmp(a[:, :, :3], 24, top_down))
+        got = host.load_image(p)
+        assert np.array_equal(got[:, :, :3], flip(a[:, :, :3])) and np.all(got[:, :, 3] == 255)
+        open(p, "wb").write(_bmp(a, 32, top_down))
+        assert np.array_equal(host.load_image(p), flip(a))
+        z = a.copy(); z[:, :, 3] = 0
+        open(p, "wb").write(_bmp(z, 32, top_down))
+        got = host.load_image(p)
+        assert np.array_equal(got[:, :, :3], flip(a[:, :, :3])) and np.all(got[:, :, 3] == 255)
+        open(p, "wb").write(_bmp(a, 32, top_down, bitfields=True))
+        assert np.array_equal(host.load_image(p), flip(a))
+        pal = [tuple(int(v) for v in c) for c in _rng_img(1, 200, 3, 4)[0]]
+        idx = (a[:, :, 0] % 200).astype(np.uint8)
+        open(p, "wb").write(_bmp(idx, 8, top_down, palette=pal))
+        assert np.array_equal(host.load_image(p)[:, :, :3], flip(np.array(pal, np.uint8)[idx]))
+    bad = str(tmp_path / "rle.bmp")
+    data = bytearray(_bmp(a[:, :, 0], 8, palette=[(0, 0, 0)] * 256)); data[30] = 1          # BI_RLE8
+    open(bad, "wb").write(bytes(data))
+    with pytest.raises(host.HostError):
+        host.load_image(bad)
+
+
 def test_bad_images_raise(tmp_path):
     p = str(tmp_path / "x.jpg")
     open(p, "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
