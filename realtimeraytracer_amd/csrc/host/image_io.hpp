@@ -4,8 +4,8 @@
 // stb_image's documented channel conversions:
 //   * to 4 channels: grey -> (g,g,g,255), grey+alpha -> (g,g,g,a), RGB -> (r,g,b,255);
 //   * to 1 channel : luma y = (77 r + 150 g + 29 b) >> 8;
-//   * .hdr -> 8 bit: c = clamp(pow(c, 1/2.2) * 255 + 0.5), alpha 255 (the reference loads its 4k HDRI this way,
-//     src/app/application.cppm:250);
+//   * .hdr -> 8 bit: channel conversion on the float data first (grey = (r+g+b)/3), then c = clamp(pow(c, 1/2.2) * 255 + 0.5),
+//     alpha 255 (the reference loads its 4k HDRI this way, src/app/application.cppm:250);
 //   * 16-bit PNG samples keep their high byte.
 //   * TGA (types 1/2/3 and their RLE forms 9/10/11; 8-bit grey, 8-bit colour-mapped, 15/16/24/32-bit true colour; either
 //     vertical origin) and BMP (BI_RGB 8-bit palettised / 24 / 32 bit, BI_BITFIELDS 32 bit; bottom-up or top-down; a 32-bit
@@ -450,12 +450,19 @@ inline Image load_image(const std::string& path, int desired_channels, bool flip
     else if (f.size() >= 10 && (std::memcmp(f.data(), "#?RADIANCE", 10) == 0 || std::memcmp(f.data(), "#?RGBE", 6) == 0)) {
         std::vector<float> rgb;
         detail::decode_hdr(f, w, h, rgb);
-        sc = 3; px.resize((size_t)w * h * 3);
-        for (size_t i = 0; i < px.size(); ++i) {                    // stb_image hdr -> ldr: gamma 2.2, scale 1
-            float z = std::pow(rgb[i], 1.0f / 2.2f) * 255.0f + 0.5f;
-            if (z < 0.f) z = 0.f;
-            if (z > 255.f) z = 255.f;
-            px[i] = (uint8_t)(int)z;
+        // stb_image converts the channel count on the FLOAT data (grey = (r+g+b)/3, not the integer luma weights) and
+        // only then maps to 8 bits: (float)pow(x, 1/2.2f) * 255 + 0.5f with a double pow(); alpha is 1.0 -> 255
+        sc = desired_channels == 1 ? 1 : 3; px.resize((size_t)w * h * sc);
+        const double g = (double)(1.0f / 2.2f);
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
+            float v[3] = {rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]};
+            if (sc == 1) v[0] = (v[0] + v[1] + v[2]) / 3.0f;
+            for (int k = 0; k < sc; ++k) {
+                float z = (float)std::pow((double)(v[k] * 1.0f), g) * 255.0f + 0.5f;
+                if (z < 0.f) z = 0.f;
+                if (z > 255.f) z = 255.f;
+                px[i * sc + k] = (uint8_t)(int)z;
+            }
         }
     } else throw std::runtime_error("Failed to load image: " + path + " (unsupported image format: PNG, TGA, BMP, binary PGM/PPM and Radiance HDR are decoded)");
     Image out; out.width = w; out.height = h; out.channels = desired_channels;

@@ -58,7 +58,35 @@ def ingest_semantics(j):
             "materials": [{"name": m["name"], "diffuse": m["diffuse"], "specular": m["specular"]} for m in j["materials"]]}
 
 
+def image_hashes():
+    """4) image ingest: every file of tests/image_cases.py through the REAL stb_image of the reference tree
+    (oracle/_ref/stb_dump: flip on load, STBI_rgb_alpha and STBI_grey) -> tests/golden/image_stb_hashes.json"""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from image_cases import image_cases
+    stb = os.path.join(ROOT, "oracle", "_ref", "stb_dump")
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, data in image_cases():
+            p = os.path.join(d, name)
+            open(p, "wb").write(data)
+            out[name] = {"file_sha256": hashlib.sha256(data).hexdigest()}
+            for want in (4, 1):
+                raw = subprocess.run([stb, p, str(want)], check=True, capture_output=True).stdout
+                head, _, body = raw.partition(b"\n")
+                w, h, c = (int(x) for x in head.split())
+                assert len(body) == w * h * c
+                e = {"shape": [h, w, c], "sha256": hashlib.sha256(body).hexdigest()}
+                if name.endswith(".hdr"):
+                    e["bytes_hex"] = body.hex()          # compared with a tolerance of one code value (pow() in the hdr -> ldr step)
+                out[name][str(want)] = e
+    json.dump(out, open(os.path.join(HERE, "image_stb_hashes.json"), "w"), indent=1)
+    print("image_stb_hashes.json:", len(out), "files")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "images":
+        return image_hashes()
     from realtimeraytracer_amd import _abi as A
     from realtimeraytracer_amd import scenes
     from oracle import oracle_py as O
@@ -94,6 +122,7 @@ def main():
                         normal=r.images[6], position=r.images[7], hdr=r.hdr,
                         counters=np.array([r.stats.numRays, r.stats.numPrimaryRays, r.stats.numShadowRays, r.stats.numHits,
                                            r.stats.numLightFetches, r.stats.numLightTriFetches], dtype=np.uint64))
+    image_hashes()
     print("fixtures written to", HERE)
 
 

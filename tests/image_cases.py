@@ -1,0 +1,138 @@
+"""Deterministic image files for the ingest tests: the same bytes are fed to the product's decoders
+(csrc/host/image_io.hpp) and — by tests/golden/make_fixtures.py, where the reference tree exists — to the reference's
+real stb_image (oracle/_ref/stb_dump), whose output hashes are committed in tests/golden/image_stb_hashes.json."""
+import struct
+
+import numpy as np
+
+from realtimeraytracer_amd import scenes
+
+
+def _rng_img(h, w, c, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    a[: h // 2, : w // 2] = a[0, 0]            # some flat areas so LZ77 matches + long Huffman runs occur
+    return a
+
+
+def _tga(a, image_type, top_left, rle=False, palette=None, bits16=False):
+    """a: (h, w) uint8 for grey / palette indices, (h, w, 3|4) for true colour (RGB[A]); rows given top first"""
+    h, w = a.shape[:2]
+    if image_type == 1:
+        bpp, cmap = 8, b"".join(bytes([c[2], c[1], c[0]]) for c in palette)
+        head = struct.pack("<BBBHHBHHHHBB", 0, 1, 9 if rle else 1, 0, len(palette), 24, 0, 0, w, h, 8, 0x20 if top_left else 0)
+        pix = [bytes([v]) for v in a.reshape(-1)]
+    elif image_type == 3:
+        bpp, cmap = 8, b""
+        head = struct.pack("<BBBHHBHHHHBB", 0, 0, 11 if rle else 3, 0, 0, 0, 0, 0, w, h, 8, 0x20 if top_left else 0)
+        pix = [bytes([v]) for v in a.reshape(-1)]
+    else:
+        c = a.shape[2]
+        cmap = b""
+        if bits16:
+            bpp = 16
+            pix = [struct.pack("<H", ((int(p[0]) >> 3) << 10) | ((int(p[1]) >> 3) << 5) | (int(p[2]) >> 3)) for p in a.reshape(-1, c)]
+        else:
+            bpp = 8 * c
+            pix = [bytes([p[2], p[1], p[0]]) + (bytes([p[3]]) if c == 4 else b"") for p in a.reshape(-1, c)]
+        head = struct.pack("<BBBHHBHHHHBB", 0, 0, 10 if rle else 2, 0, 0, 0, 0, 0, w, h, bpp, (0x20 if top_left else 0) | (8 if c == 4 else 0))
+    rows = [pix[y * w:(y + 1) * w] for y in range(h)]
+    if not top_left:
+        rows = rows[::-1]
+    flat = [q for r in rows for q in r]
+    if not rle:
+        body = b"".join(flat)
+    else:
+        body, i = b"", 0
+        while i < len(flat):
+            run = 1
+            while i + run < len(flat) and run < 128 and flat[i + run] == flat[i]:
+                run += 1
+            if run > 1:
+                body += bytes([0x80 | (run - 1)]) + flat[i]; i += run
+            else:
+                n = 1
+                while i + n < len(flat) and n < 128 and (i + n + 1 >= len(flat) or flat[i + n] != flat[i + n + 1]):
+                    n += 1
+                body += bytes([n - 1]) + b"".join(flat[i:i + n]); i += n
+    return head + cmap + body
+
+
+def _bmp(a, bpp, top_down=False, bitfields=False, palette=None):
+    h, w = a.shape[:2]
+    stride = ((w * bpp + 31) // 32) * 4
+    rows = []
+    for y in range(h):
+        r = a[y]
+        if bpp == 8:
+            raw = bytes(r.tolist())
+        elif bpp == 24:
+            raw = r[:, [2, 1, 0]].tobytes()
+        elif bitfields:                                    # masks: R = 0x000000ff, G = 0x0000ff00, B = 0x00ff0000, A = 0xff000000
+            raw = r[:, [0, 1, 2, 3]].tobytes()
+        else:
+            raw = r[:, [2, 1, 0, 3]].tobytes()
+        rows.append(raw + b"\0" * (stride - len(raw)))
+    if not top_down:
+        rows = rows[::-1]
+    pal = b"".join(bytes([c[2], c[1], c[0], 0]) for c in palette) if palette else b""
+    # bitfields = "v4": BITMAPV4HEADER (108 bytes, the four masks are header fields, alpha used);
+    #             True: BITMAPINFOHEADER followed by three masks (no alpha mask -> opaque)
+    if bitfields == "v4":
+        hdr_size, masks = 108, struct.pack("<IIII", 0xff, 0xff00, 0xff0000, 0xff000000) + b"BGRs" + b"\0" * 48
+    elif bitfields:
+        hdr_size, masks = 40, struct.pack("<III", 0xff, 0xff00, 0xff0000)
+    else:
+        hdr_size, masks = 40, b""
+    off = 14 + 40 + len(masks) + len(pal)
+    info = struct.pack("<IiiHHIIiiII", hdr_size, w, -h if top_down else h, 1, bpp, 3 if bitfields else 0, stride * h, 2835, 2835, len(palette) if palette else 0, 0)
+    return b"BM" + struct.pack("<IHHI", off + stride * h, 0, 0, off) + info + masks + pal + b"".join(rows)
+
+
+def image_cases():
+    """[(file name, file bytes)] — PNG colour types x compression levels, PNM, HDR, TGA and BMP variants"""
+    import os
+    import tempfile
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        def via(path_writer, name, *args, **kw):
+            p = os.path.join(d, name)
+            path_writer(p, *args, **kw)
+            out.append((name, open(p, "rb").read()))
+        for c in (1, 2, 3, 4):
+            for level in (0, 1, 9):
+                a = _rng_img(37, 53, c, 10 * c + level)
+                via(scenes.write_png, f"png_c{c}_l{level}.png", a if c > 1 else a[:, :, 0], level=level)
+        a = _rng_img(9, 11, 3, 3)
+        via(scenes.write_pnm, "rgb.ppm", a)
+        via(scenes.write_pnm, "grey.pgm", a[:, :, 0])
+        rng = np.random.default_rng(5)
+        f = (rng.random((7, 40, 3)) * np.array([0.2, 1.0, 6.0])).astype(np.float32)
+        f[2, 5:30] = f[2, 5]
+        via(scenes.write_hdr, "rle.hdr", f, rle=True)
+        via(scenes.write_hdr, "flat.hdr", f, rle=False)
+    a = _rng_img(13, 21, 4, 7)
+    a[3:9, 2:19] = a[3, 2]
+    pal = [tuple(int(v) for v in c) for c in _rng_img(1, 40, 3, 9)[0]]
+    idx = (a[:, :, 0] % 40).astype(np.uint8)
+    for top_left in (True, False):
+        for rle in (False, True):
+            tag = f"{int(top_left)}{int(rle)}"
+            out.append((f"rgba_{tag}.tga", _tga(a, 2, top_left, rle)))
+            out.append((f"rgb_{tag}.tga", _tga(a[:, :, :3], 2, top_left, rle)))
+            out.append((f"grey_{tag}.tga", _tga(a[:, :, 0], 3, top_left, rle)))
+            out.append((f"pal_{tag}.tga", _tga(idx, 1, top_left, rle, palette=pal)))
+    out.append(("r5g5b5.tga", _tga(a[:, :, :3], 2, True, bits16=True)))
+    b = _rng_img(11, 19, 4, 21)
+    z = b.copy(); z[:, :, 3] = 0
+    pal2 = [tuple(int(v) for v in c) for c in _rng_img(1, 200, 3, 4)[0]]
+    idx2 = (b[:, :, 0] % 200).astype(np.uint8)
+    for top_down in (False, True):
+        t = int(top_down)
+        out.append((f"rgb24_{t}.bmp", _bmp(b[:, :, :3], 24, top_down)))
+        out.append((f"rgba32_{t}.bmp", _bmp(b, 32, top_down)))
+        out.append((f"zeroalpha32_{t}.bmp", _bmp(z, 32, top_down)))
+        out.append((f"bitfields32_{t}.bmp", _bmp(b, 32, top_down, bitfields=True)))
+        out.append((f"v4_32_{t}.bmp", _bmp(b, 32, top_down, bitfields="v4")))
+        out.append((f"pal8_{t}.bmp", _bmp(idx2, 8, top_down, palette=pal2)))
+    return out

@@ -8,13 +8,7 @@ import numpy as np
 import pytest
 
 from realtimeraytracer_amd import host, scenes
-
-
-def _rng_img(h, w, c, seed):
-    rng = np.random.default_rng(seed)
-    a = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
-    a[: h // 2, : w // 2] = a[0, 0]            # some flat areas so LZ77 matches + long Huffman runs occur
-    return a
+from image_cases import _bmp, _rng_img, _tga, image_cases
 
 
 @pytest.mark.parametrize("c", [1, 2, 3, 4])
@@ -88,49 +82,6 @@ def test_pnm_and_hdr(tmp_path):
         assert np.all(got[:, :, 3] == 255)
 
 
-def _tga(a, image_type, top_left, rle=False, palette=None, bits16=False):
-    """a: (h, w) uint8 for grey / palette indices, (h, w, 3|4) for true colour (RGB[A]); rows given top first"""
-    h, w = a.shape[:2]
-    if image_type == 1:
-        bpp, cmap = 8, b"".join(bytes([c[2], c[1], c[0]]) for c in palette)
-        head = struct.pack("<BBBHHBHHHHBB", 0, 1, 9 if rle else 1, 0, len(palette), 24, 0, 0, w, h, 8, 0x20 if top_left else 0)
-        pix = [bytes([v]) for v in a.reshape(-1)]
-    elif image_type == 3:
-        bpp, cmap = 8, b""
-        head = struct.pack("<BBBHHBHHHHBB", 0, 0, 11 if rle else 3, 0, 0, 0, 0, 0, w, h, 8, 0x20 if top_left else 0)
-        pix = [bytes([v]) for v in a.reshape(-1)]
-    else:
-        c = a.shape[2]
-        cmap = b""
-        if bits16:
-            bpp = 16
-            pix = [struct.pack("<H", ((int(p[0]) >> 3) << 10) | ((int(p[1]) >> 3) << 5) | (int(p[2]) >> 3)) for p in a.reshape(-1, c)]
-        else:
-            bpp = 8 * c
-            pix = [bytes([p[2], p[1], p[0]]) + (bytes([p[3]]) if c == 4 else b"") for p in a.reshape(-1, c)]
-        head = struct.pack("<BBBHHBHHHHBB", 0, 0, 10 if rle else 2, 0, 0, 0, 0, 0, w, h, bpp, (0x20 if top_left else 0) | (8 if c == 4 else 0))
-    rows = [pix[y * w:(y + 1) * w] for y in range(h)]
-    if not top_left:
-        rows = rows[::-1]
-    flat = [q for r in rows for q in r]
-    if not rle:
-        body = b"".join(flat)
-    else:
-        body, i = b"", 0
-        while i < len(flat):
-            run = 1
-            while i + run < len(flat) and run < 128 and flat[i + run] == flat[i]:
-                run += 1
-            if run > 1:
-                body += bytes([0x80 | (run - 1)]) + flat[i]; i += run
-            else:
-                n = 1
-                while i + n < len(flat) and n < 128 and (i + n + 1 >= len(flat) or flat[i + n] != flat[i + n + 1]):
-                    n += 1
-                body += bytes([n - 1]) + b"".join(flat[i:i + n]); i += n
-    return head + cmap + body
-
-
 def test_tga_variants(tmp_path):
     """Truevision TGA: true colour 24/32/16 bit, grey, colour-mapped, RLE, both vertical origins (stb_image: .tga)."""
     a = _rng_img(13, 21, 4, 7)
@@ -163,31 +114,6 @@ def test_tga_variants(tmp_path):
         host.load_image(bad)
 
 
-def _bmp(a, bpp, top_down=False, bitfields=False, palette=None):
-    h, w = a.shape[:2]
-    stride = ((w * bpp + 31) // 32) * 4
-    rows = []
-    for y in range(h):
-        r = a[y]
-        if bpp == 8:
-            raw = bytes(r.tolist())
-        elif bpp == 24:
-            raw = r[:, [2, 1, 0]].tobytes()
-        elif bitfields:                                    # masks: R = 0x000000ff, G = 0x0000ff00, B = 0x00ff0000, A = 0xff000000
-            raw = r[:, [0, 1, 2, 3]].tobytes()
-        else:
-            raw = r[:, [2, 1, 0, 3]].tobytes()
-        rows.append(raw + b"\0" * (stride - len(raw)))
-    if not top_down:
-        rows = rows[::-1]
-    pal = b"".join(bytes([c[2], c[1], c[0], 0]) for c in palette) if palette else b""
-    hdr_size = 56 if bitfields else 40
-    masks = struct.pack("<IIII", 0xff, 0xff00, 0xff0000, 0xff000000) if bitfields else b""
-    off = 14 + 40 + len(masks) + len(pal)
-    info = struct.pack("<IiiHHIIiiII", hdr_size, w, -h if top_down else h, 1, bpp, 3 if bitfields else 0, stride * h, 2835, 2835, len(palette) if palette else 0, 0)
-    return b"BM" + struct.pack("<IHHI", off + stride * h, 0, 0, off) + info + masks + pal + b"".join(rows)
-
-
 def test_bmp_variants(tmp_path):
     """Windows BMP: 24-bit with row padding, 32-bit BI_RGB (all-zero alpha = opaque), 32-bit BI_BITFIELDS, 8-bit palettised,
     bottom-up and top-down."""
@@ -204,8 +130,11 @@ def test_bmp_variants(tmp_path):
         open(p, "wb").write(_bmp(z, 32, top_down))
         got = host.load_image(p)
         assert np.array_equal(got[:, :, :3], flip(a[:, :, :3])) and np.all(got[:, :, 3] == 255)
-        open(p, "wb").write(_bmp(a, 32, top_down, bitfields=True))
+        open(p, "wb").write(_bmp(a, 32, top_down, bitfields="v4"))           # V4 header: four masks incl. alpha
         assert np.array_equal(host.load_image(p), flip(a))
+        open(p, "wb").write(_bmp(a, 32, top_down, bitfields=True))           # INFOHEADER + three masks: no alpha mask -> opaque
+        got = host.load_image(p)
+        assert np.array_equal(got[:, :, :3], flip(a[:, :, :3])) and np.all(got[:, :, 3] == 255)
         pal = [tuple(int(v) for v in c) for c in _rng_img(1, 200, 3, 4)[0]]
         idx = (a[:, :, 0] % 200).astype(np.uint8)
         open(p, "wb").write(_bmp(idx, 8, top_down, palette=pal))
@@ -246,3 +175,28 @@ def test_texture_table_of_created_scene(scene_cache):
     assert leaf_near.usesOpacityMap and leaf_near.opacityIndex == leaf_near.colorIndex == leaf_far.colorIndex   # same path -> one texture
     assert not block.usesColorMap and abs(block.metallic - 0.5) < 1e-7   # unknown_parameter["metallic"]
     assert d.hdri and d.hdri.contents.width == 128 and d.hdri.contents.height == 64 and d.hdri.contents.channels == 4
+
+
+def test_decoders_match_the_reference_stb_image(tmp_path):
+    """Every generated image decodes to the bytes the REAL stb_image of the reference tree produced for it
+    (tests/golden/image_stb_hashes.json, made by tests/golden/make_fixtures.py with oracle/_ref/stb_dump), for
+    STBI_rgb_alpha and STBI_grey, with the vertical flip — the way core::file::createTextureImage loads textures."""
+    import hashlib
+    import json
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "image_stb_hashes.json")))
+    seen = 0
+    for name, data in image_cases():
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        for want in (4, 1):
+            exp = golden[name][str(want)]
+            got = host.load_image(p, grayscale=(want == 1))
+            assert list(got.shape) == exp["shape"], (name, want)
+            if name.endswith(".hdr"):
+                # hdr -> ldr goes through pow(): the committed stb bytes and ours may differ by one code value across libm builds
+                ref = np.frombuffer(bytes.fromhex(exp["bytes_hex"]), np.uint8).reshape(exp["shape"])
+                assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1, (name, want)
+            else:
+                assert hashlib.sha256(got.tobytes()).hexdigest() == exp["sha256"], (name, want)
+            seen += 1
+    assert seen == 2 * len(golden) and seen >= 40
