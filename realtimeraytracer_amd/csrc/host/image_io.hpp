@@ -10,7 +10,9 @@
 //   * TGA (types 1/2/3 and their RLE forms 9/10/11; 8-bit grey, 8-bit colour-mapped, 15/16/24/32-bit true colour; either
 //     vertical origin) and BMP (BI_RGB 8-bit palettised / 24 / 32 bit, BI_BITFIELDS 32 bit; bottom-up or top-down; a 32-bit
 //     file whose alpha bytes are all zero is opaque, as in stb_image).  TGA has no signature: it is tried for ".tga" files.
-// JPEG and the other stb formats are not decoded: load_image throws "unsupported image format" rather than guess.
+//   * JPEG (baseline and progressive Huffman, 8 bit, grey or three components): jpeg_decode.hpp; one wanted channel takes
+//     the luma plane, as stb_image does.
+// The other stb formats (GIF, PSD, PIC) are not decoded: load_image throws "unsupported image format" rather than guess.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -22,6 +24,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "jpeg_decode.hpp"
 
 namespace rtr::img {
 
@@ -445,6 +449,7 @@ inline Image load_image(const std::string& path, int desired_channels, bool flip
     static const uint8_t pngsig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (f.size() >= 8 && std::memcmp(f.data(), pngsig, 8) == 0) detail::decode_png(f, w, h, sc, px);
     else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) detail::decode_pnm(f, w, h, sc, px);
+    else if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8 && f[2] == 0xff) detail::decode_jpeg(f, w, h, sc, px, desired_channels);
     else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') detail::decode_bmp(f, w, h, sc, px);
     else if (path.size() >= 4 && (path.compare(path.size() - 4, 4, ".tga") == 0 || path.compare(path.size() - 4, 4, ".TGA") == 0)) detail::decode_tga(f, w, h, sc, px);
     else if (f.size() >= 10 && (std::memcmp(f.data(), "#?RADIANCE", 10) == 0 || std::memcmp(f.data(), "#?RGBE", 6) == 0)) {
@@ -464,7 +469,7 @@ inline Image load_image(const std::string& path, int desired_channels, bool flip
                 px[i * sc + k] = (uint8_t)(int)z;
             }
         }
-    } else throw std::runtime_error("Failed to load image: " + path + " (unsupported image format: PNG, TGA, BMP, binary PGM/PPM and Radiance HDR are decoded)");
+    } else throw std::runtime_error("Failed to load image: " + path + " (unsupported image format: PNG, JPEG, TGA, BMP, binary PGM/PPM and Radiance HDR are decoded)");
     Image out; out.width = w; out.height = h; out.channels = desired_channels;
     out.pixels.resize((size_t)w * h * desired_channels);
     for (int y = 0; y < h; ++y) {

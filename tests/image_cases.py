@@ -135,4 +135,41 @@ def image_cases():
         out.append((f"bitfields32_{t}.bmp", _bmp(b, 32, top_down, bitfields=True)))
         out.append((f"v4_32_{t}.bmp", _bmp(b, 32, top_down, bitfields="v4")))
         out.append((f"pal8_{t}.bmp", _bmp(idx2, 8, top_down, palette=pal2)))
+    out += jpeg_cases()
     return out
+
+
+def _photo(h, w, seed):
+    """smooth gradients + a few hard edges + a little noise: runs of zero coefficients, empty blocks and busy blocks"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 9.0 + seed) * np.cos(y / 7.0), 40 + 3.0 * x + 1.5 * y, 255 - 2.5 * y + 20 * np.sin(x / 3.0)], -1)
+    img[h // 3: h // 2, w // 4: w // 2] = (250, 20, 60)
+    img[: h // 5, : w // 3] = 90                          # a flat area: EOB runs in the progressive scans
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def jpeg_cases():
+    import jpeg_writer as J
+    a = _photo(45, 67, 1)                                 # neither dimension a multiple of 8 or 16
+    b = _photo(32, 48, 2)
+    g = _photo(29, 37, 3)[:, :, 0]
+    return [
+        ("base_grey.jpg", J.encode(g)),
+        ("base_444.jpg", J.encode(a, "444")),
+        ("base_422.jpg", J.encode(a, "422")),
+        ("base_420.jpg", J.encode(a, "420")),
+        ("base_440.jpg", J.encode(a, "440")),
+        ("base_420_rst3.jpg", J.encode(a, "420", restart=3)),
+        ("base_444_scans.jpg", J.encode(b, "444", interleaved=False)),
+        ("base_420_scans_rst.jpg", J.encode(a, "420", interleaved=False, restart=5)),
+        ("base_rgb_ids.jpg", J.encode(b, "444", adobe_rgb=True)),
+        ("base_444_q5.jpg", J.encode(a, "444", scale=400)),       # coarse quantisation: long zero runs
+        ("base_444_q1.jpg", J.encode(b, "444", scale=1)),         # quantiser 1: large coefficients, ZRL symbols
+        ("prog_grey.jpg", J.encode(g, progressive=True)),
+        ("prog_444.jpg", J.encode(b, "444", progressive=True)),
+        ("prog_420.jpg", J.encode(a, "420", progressive=True)),
+        ("prog_420_rst.jpg", J.encode(a, "420", progressive=True, restart=2)),
+        ("prog_422_q1.jpg", J.encode(b, "422", progressive=True, scale=2)),
+    ]

@@ -147,8 +147,12 @@ def test_bmp_variants(tmp_path):
 
 
 def test_bad_images_raise(tmp_path):
+    p = str(tmp_path / "x.gif")
+    open(p, "wb").write(b"GIF89a" + b"\0" * 64)
+    with pytest.raises(host.HostError):
+        host.load_image(p)
     p = str(tmp_path / "x.jpg")
-    open(p, "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    open(p, "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)       # SOI + a segment of length 0: malformed
     with pytest.raises(host.HostError):
         host.load_image(p)
     with pytest.raises(host.HostError):
@@ -199,4 +203,30 @@ def test_decoders_match_the_reference_stb_image(tmp_path):
             else:
                 assert hashlib.sha256(got.tobytes()).hexdigest() == exp["sha256"], (name, want)
             seen += 1
-    assert seen == 2 * len(golden) and seen >= 40
+    assert seen == 2 * len(golden) and seen >= 120
+
+
+def test_jpeg_decodes_to_the_picture_that_was_encoded(tmp_path):
+    """Guards the test encoder itself (tests/jpeg_writer.py): every JPEG case must come back close to its source image,
+    so byte-equality with stb_image above is about real pictures, not about two decoders agreeing on noise."""
+    from image_cases import _photo
+    import jpeg_writer as J
+    a = _photo(45, 67, 1)
+    for name, kw, floor in (("b444", dict(sampling="444"), 30.0), ("b420r", dict(sampling="420", restart=3), 24.0),
+                            ("p420", dict(sampling="420", progressive=True), 24.0), ("p444", dict(sampling="444", progressive=True), 30.0),
+                            ("scans", dict(sampling="422", interleaved=False), 24.0)):
+        p = str(tmp_path / (name + ".jpg"))
+        open(p, "wb").write(J.encode(a, **kw))
+        got = host.load_image(p)[::-1, :, :3].astype(np.float64)       # undo the flip-on-load
+        mse = np.mean((got - a.astype(np.float64)) ** 2)
+        assert 10 * np.log10(255.0 ** 2 / mse) > floor, (name, mse)
+    g = a[:, :, 1]
+    p = str(tmp_path / "grey.jpg")
+    open(p, "wb").write(J.encode(g, progressive=True))
+    got = host.load_image(p, grayscale=True)[::-1, :, 0].astype(np.float64)
+    assert 10 * np.log10(255.0 ** 2 / np.mean((got - g) ** 2)) > 30.0
+    bad = str(tmp_path / "trunc.jpg")
+    data = J.encode(a, "420")
+    open(bad, "wb").write(data[:200])
+    with pytest.raises(host.HostError):
+        host.load_image(bad)
