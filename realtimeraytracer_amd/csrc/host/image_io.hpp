@@ -6,7 +6,8 @@
 //   * to 1 channel : luma y = (77 r + 150 g + 29 b) >> 8;
 //   * .hdr -> 8 bit: channel conversion on the float data first (grey = (r+g+b)/3), then c = clamp(pow(c, 1/2.2) * 255 + 0.5),
 //     alpha 255 (the reference loads its 4k HDRI this way, src/app/application.cppm:250);
-//   * 16-bit PNG samples keep their high byte.
+//   * 16-bit PNG samples keep their high byte; Adam7 interlacing and tRNS (palette alpha, or one transparent colour on grey /
+//     RGB images -> an added alpha channel) are decoded.
 //   * TGA (types 1/2/3 and their RLE forms 9/10/11; 8-bit grey, 8-bit colour-mapped, 15/16/24/32-bit true colour; either
 //     vertical origin) and BMP (BI_RGB 8-bit palettised / 24 / 32 bit, BI_BITFIELDS 32 bit; bottom-up or top-down; a 32-bit
 //     file whose alpha bytes are all zero is opaque, as in stb_image).  TGA has no signature: it is tried for ".tga" files.
@@ -148,7 +149,7 @@ inline std::vector<uint8_t> zlib_inflate(const uint8_t* data, size_t n, size_t e
 inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
 // decodes to `src_channels` (1,2,3 or 4) 8-bit samples, top row first
-inline void decode_png(const std::vector<uint8_t>& f, int& w, int& h, int& src_channels, std::vector<uint8_t>& px) {
+inline void decode_png(const std::vector<uint8_t>& f, int& w, int& h, int& src_channels, std::vector<uint8_t>& px, int desired_channels) {
     size_t pos = 8;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte, trns;
@@ -170,58 +171,104 @@ inline void decode_png(const std::vector<uint8_t>& f, int& w, int& h, int& src_c
         pos += 12 + len;
     }
     if (!haveHdr || w <= 0 || h <= 0 || w > 1 << 16 || h > 1 << 16) throw std::runtime_error("PNG: missing or bad IHDR");
-    if (interlace) throw std::runtime_error("PNG: interlaced images are not supported");
+    if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
     int samples;
     switch (ctype) { case 0: samples = 1; break; case 2: samples = 3; break; case 3: samples = 1; break; case 4: samples = 2; break; case 6: samples = 4; break;
                      default: throw std::runtime_error("PNG: bad colour type"); }
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) throw std::runtime_error("PNG: unsupported bit depth");
     if (ctype == 3 && depth == 16) throw std::runtime_error("PNG: bad palette depth");
-    const size_t bitsPerPixel = (size_t)samples * depth, stride = (bitsPerPixel * w + 7) / 8, bpp = std::max<size_t>(1, bitsPerPixel / 8);
-    std::vector<uint8_t> raw = zlib_inflate(idat.data(), idat.size(), (stride + 1) * h);
-    if (raw.size() < (stride + 1) * (size_t)h) throw std::runtime_error("PNG: not enough image data");
-    std::vector<uint8_t> img(stride * h);
-    for (int y = 0; y < h; ++y) {                                   // un-filter
-        const uint8_t* in = &raw[(stride + 1) * y];
-        uint8_t* out = &img[stride * y];
-        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-        int ft = in[0]; ++in;
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= bpp ? out[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, v;
-            switch (ft) {
-                case 0: v = in[i]; break;
-                case 1: v = in[i] + a; break;
-                case 2: v = in[i] + b; break;
-                case 3: v = in[i] + ((a + b) >> 1); break;
-                case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                          v = in[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
-                default: throw std::runtime_error("PNG: bad filter type");
+    const size_t bitsPerPixel = (size_t)samples * depth, bpp = std::max<size_t>(1, bitsPerPixel / 8);
+    // the passes of the image: one, or the seven of Adam7 (x origin, y origin, x spacing, y spacing)
+    static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const int whole[1][4] = {{0, 0, 1, 1}};
+    const int (*passes)[4] = interlace ? adam7 : whole;
+    const int npass = interlace ? 7 : 1;
+    size_t expect = 0;
+    for (int k = 0; k < npass; ++k) {
+        const int pw = (w - passes[k][0] + passes[k][2] - 1) / passes[k][2], ph = (h - passes[k][1] + passes[k][3] - 1) / passes[k][3];
+        if (pw > 0 && ph > 0) expect += (((size_t)bitsPerPixel * pw + 7) / 8 + 1) * ph;
+    }
+    std::vector<uint8_t> raw = zlib_inflate(idat.data(), idat.size(), expect);
+    if (raw.size() < expect) throw std::runtime_error("PNG: not enough image data");
+    std::vector<uint16_t> val((size_t)w * h * samples);            // raw sample values (full 16 bits for depth 16)
+    size_t rpos = 0;
+    std::vector<uint8_t> img;
+    for (int k = 0; k < npass; ++k) {
+        const int pw = (w - passes[k][0] + passes[k][2] - 1) / passes[k][2], ph = (h - passes[k][1] + passes[k][3] - 1) / passes[k][3];
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = ((size_t)bitsPerPixel * pw + 7) / 8;
+        img.assign(stride * ph, 0);
+        for (int y = 0; y < ph; ++y) {                              // un-filter
+            const uint8_t* in = &raw[rpos + (stride + 1) * y];
+            uint8_t* out = &img[stride * y];
+            const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+            int ft = in[0]; ++in;
+            for (size_t i = 0; i < stride; ++i) {
+                int a = i >= bpp ? out[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, v;
+                switch (ft) {
+                    case 0: v = in[i]; break;
+                    case 1: v = in[i] + a; break;
+                    case 2: v = in[i] + b; break;
+                    case 3: v = in[i] + ((a + b) >> 1); break;
+                    case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                              v = in[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
+                    default: throw std::runtime_error("PNG: bad filter type");
+                }
+                out[i] = (uint8_t)v;
             }
-            out[i] = (uint8_t)v;
+        }
+        rpos += (stride + 1) * ph;
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t* row = &img[stride * y];
+            for (int x = 0; x < pw; ++x)
+                for (int c = 0; c < samples; ++c) {
+                    const size_t idx = (size_t)x * samples + c;
+                    int v;
+                    if (depth == 8) v = row[idx];
+                    else if (depth == 16) v = (row[idx * 2] << 8) | row[idx * 2 + 1];
+                    else { const size_t bit = idx * depth; v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1); }
+                    val[(((size_t)(passes[k][1] + y * passes[k][3])) * w + (passes[k][0] + x * passes[k][2])) * samples + c] = (uint16_t)v;
+                }
         }
     }
-    // expand to 8-bit samples
-    auto sample = [&](int y, size_t idx) -> int {                   // idx-th sample of row y
-        const uint8_t* row = &img[stride * y];
-        if (depth == 8) return row[idx];
-        if (depth == 16) return row[idx * 2];                       // high byte
-        size_t bit = idx * depth; int v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-        return v;
-    };
+    // expand to 8-bit samples: palette look-up, bit-depth scaling (16 bit keeps its high byte), tRNS
+    auto to8 = [&](int v) -> uint8_t { return (uint8_t)(depth == 16 ? v >> 8 : (ctype == 0 && depth < 8 ? v * (255 / ((1 << depth) - 1)) : v)); };
     if (ctype == 3) {
         src_channels = trns.empty() ? 3 : 4;
         px.resize((size_t)w * h * src_channels);
-        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
-            int i = sample(y, x);
+        for (size_t q = 0; q < (size_t)w * h; ++q) {
+            const int i = val[q];
             if ((size_t)i * 3 + 2 >= plte.size()) throw std::runtime_error("PNG: palette index out of range");
-            uint8_t* o = &px[((size_t)y * w + x) * src_channels];
+            uint8_t* o = &px[q * src_channels];
             o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
             if (src_channels == 4) o[3] = (size_t)i < trns.size() ? trns[i] : 255;
         }
     } else {
-        src_channels = samples;
-        px.resize((size_t)w * h * samples);
-        const int scale = (ctype == 0 && depth < 8) ? 255 / ((1 << depth) - 1) : 1;
-        for (int y = 0; y < h; ++y) for (size_t i = 0; i < (size_t)w * samples; ++i) px[(size_t)y * w * samples + i] = (uint8_t)(sample(y, i) * scale);
+        // a tRNS chunk on a grey / RGB image names ONE transparent colour: it adds an alpha channel that is 0 there
+        const bool keyed = !trns.empty() && (ctype == 0 || ctype == 2);
+        if (keyed && trns.size() < (size_t)samples * 2) throw std::runtime_error("PNG: bad tRNS");
+        int key[3] = {0, 0, 0};
+        for (int c = 0; keyed && c < samples; ++c) key[c] = ((trns[2 * c] << 8) | trns[2 * c + 1]) & (depth == 16 ? 0xffff : 0xff);
+        src_channels = samples + (keyed ? 1 : 0);
+        if (depth == 16 && samples >= 3 && desired_channels == 1) {
+            // stb_image reduces a 16-bit colour image to grey on the 16-bit values and only then keeps the high byte
+            src_channels = 1;
+            px.resize((size_t)w * h);
+            for (size_t q = 0; q < (size_t)w * h; ++q) {
+                const uint32_t y16 = ((uint32_t)val[q * samples] * 77u + (uint32_t)val[q * samples + 1] * 150u + (uint32_t)val[q * samples + 2] * 29u) >> 8;
+                px[q] = (uint8_t)((y16 >> 8) & 0xffu);
+            }
+            return;
+        }
+        px.resize((size_t)w * h * src_channels);
+        for (size_t q = 0; q < (size_t)w * h; ++q) {
+            bool match = keyed;
+            for (int c = 0; c < samples; ++c) {
+                px[q * src_channels + c] = to8(val[q * samples + c]);
+                if (keyed && val[q * samples + c] != key[c]) match = false;
+            }
+            if (keyed) px[q * src_channels + samples] = match ? 0 : 255;
+        }
     }
 }
 
@@ -447,7 +494,7 @@ inline Image load_image(const std::string& path, int desired_channels, bool flip
     int w = 0, h = 0, sc = 0;
     std::vector<uint8_t> px;
     static const uint8_t pngsig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (f.size() >= 8 && std::memcmp(f.data(), pngsig, 8) == 0) detail::decode_png(f, w, h, sc, px);
+    if (f.size() >= 8 && std::memcmp(f.data(), pngsig, 8) == 0) detail::decode_png(f, w, h, sc, px, desired_channels);
     else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) detail::decode_pnm(f, w, h, sc, px);
     else if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8 && f[2] == 0xff) detail::decode_jpeg(f, w, h, sc, px, desired_channels);
     else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') detail::decode_bmp(f, w, h, sc, px);

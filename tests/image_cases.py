@@ -136,6 +136,92 @@ def image_cases():
         out.append((f"v4_32_{t}.bmp", _bmp(b, 32, top_down, bitfields="v4")))
         out.append((f"pal8_{t}.bmp", _bmp(idx2, 8, top_down, palette=pal2)))
     out += jpeg_cases()
+    out += png_feature_cases()
+    return out
+
+
+def _png(w, h, depth, ctype, rows_of, interlace=False, plte=None, trns=None, level=6):
+    """rows_of(x0, y0, dx, dy) -> list of rows (lists of sample tuples) of that pass; filter type cycles 0..4"""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    nsamp = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, nsamp * depth // 8)
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)] if interlace else [(0, 0, 1, 1)]
+    raw = bytearray()
+    ft = 0
+    for (x0, y0, dx, dy) in passes:
+        rows = rows_of(x0, y0, dx, dy)
+        prev = None
+        for r in rows:
+            if not r:
+                continue
+            flat = [v for px in r for v in px]
+            if depth == 16:
+                line = b"".join(struct.pack(">H", v) for v in flat)
+            elif depth == 8:
+                line = bytes(flat)
+            else:
+                bits = "".join(format(v, "0%db" % depth) for v in flat)
+                bits += "0" * ((-len(bits)) % 8)
+                line = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+            up = prev if prev is not None else bytes(len(line))
+            f = ft % 5; ft += 1
+            out = bytearray()
+            for i, v in enumerate(line):
+                a = line[i - bpp] if i >= bpp else 0
+                b = up[i]; c = up[i - bpp] if i >= bpp else 0
+                if f == 0: pr = 0
+                elif f == 1: pr = a
+                elif f == 2: pr = b
+                elif f == 3: pr = (a + b) >> 1
+                else:
+                    pp = a + b - c; pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                out.append((v - pr) & 255)
+            raw += bytes([f]) + out
+            prev = line
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        body += chunk(b"PLTE", bytes(v for c in plte for v in c))
+    if trns is not None:
+        body += chunk(b"tRNS", trns)
+    comp = zlib.compress(bytes(raw), level)
+    half = len(comp) // 2                                  # two IDAT chunks: the stream continues across chunk boundaries
+    return b"\x89PNG\r\n\x1a\n" + body + chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
+
+
+def png_feature_cases():
+    """Adam7 interlacing, tRNS in its three forms, 16-bit samples, sub-byte depths — all five filter types in every file"""
+    import struct
+    out = []
+    rng = np.random.default_rng(11)
+
+    def rows_from(a):
+        h, w = a.shape[:2]
+        return lambda x0, y0, dx, dy: [[tuple(int(v) for v in np.atleast_1d(a[y, x])) for x in range(x0, w, dx)] for y in range(y0, h, dy)]
+    a8 = rng.integers(0, 256, (11, 13, 4), dtype=np.uint8)
+    a8[2:7, 3:9] = a8[2, 3]
+    for il in (False, True):
+        t = "adam7" if il else "plain"
+        out.append((f"png_{t}_rgba8.png", _png(13, 11, 8, 6, rows_from(a8), il)))
+        out.append((f"png_{t}_rgb8_key.png", _png(13, 11, 8, 2, rows_from(a8[:, :, :3]), il, trns=struct.pack(">HHH", *[int(v) for v in a8[2, 3, :3]]))))
+        out.append((f"png_{t}_grey8_key.png", _png(13, 11, 8, 0, rows_from(a8[:, :, 0]), il, trns=struct.pack(">H", int(a8[2, 3, 0])))))
+        out.append((f"png_{t}_ga8.png", _png(13, 11, 8, 4, rows_from(a8[:, :, :2]), il)))
+        a16 = rng.integers(0, 65536, (7, 9, 3)).astype(np.int64); a16[1:4, 2:6] = a16[1, 2]
+        out.append((f"png_{t}_rgb16_key.png", _png(9, 7, 16, 2, rows_from(a16), il, trns=struct.pack(">HHH", *[int(v) for v in a16[1, 2]]))))
+        out.append((f"png_{t}_rgba16.png", _png(9, 7, 16, 6, rows_from(rng.integers(0, 65536, (7, 9, 4)).astype(np.int64)), il)))
+        for depth in (1, 2, 4):
+            g = rng.integers(0, 1 << depth, (9, 21)).astype(np.int64)
+            out.append((f"png_{t}_grey{depth}.png", _png(21, 9, depth, 0, rows_from(g), il)))
+            out.append((f"png_{t}_grey{depth}_key.png", _png(21, 9, depth, 0, rows_from(g), il, trns=struct.pack(">H", 1))))
+            pal = [tuple(int(v) for v in c) for c in rng.integers(0, 256, (1 << depth, 3))]
+            out.append((f"png_{t}_pal{depth}.png", _png(21, 9, depth, 3, rows_from(g), il, plte=pal)))
+        pal = [tuple(int(v) for v in c) for c in rng.integers(0, 256, (200, 3))]
+        idx = rng.integers(0, 200, (11, 13)).astype(np.int64)
+        out.append((f"png_{t}_pal8_trns.png", _png(13, 11, 8, 3, rows_from(idx), il, plte=pal, trns=bytes(int(v) for v in rng.integers(0, 256, 150)))))
     return out
 
 
