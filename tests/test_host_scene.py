@@ -112,3 +112,28 @@ def test_missing_textures_are_refused_loudly(scene_cache):
     st = A.rtr_scene_stats()
     rc = lib.rtr_host_build_bvh(C.byref(d), C.byref(st), None, 0, None, 0)
     assert rc == -1 and b"texture index 7" in lib.rtr_last_error()
+
+
+def test_reference_ltc_tables_known_answers_and_analytic_image(oracle, scene_cache):
+    """Where the reference tree exists: its real LTC tables (external/LUT/ltc_matrix.h, dumped by oracle/_ref/ltc_dump —
+    the data itself is not committed) satisfy SURVEY Appendix B and drive the oracle's analytic (LTC) image to a finite,
+    non-trivial result with BVH == brute force.  Elsewhere the synthetic stand-ins of scenes.synthetic_ltc() are used."""
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ltc_dump")
+    if not os.path.exists(tool):
+        pytest.skip("reference tree absent: oracle/_ref/ltc_dump not built")
+    a = np.frombuffer(subprocess.run([tool], check=True, capture_output=True).stdout, np.float32)
+    assert a.size == 2 * 16384
+    l1, l2 = a[:16384].reshape(64, 64, 4).copy(), a[16384:].reshape(64, 64, 4).copy()
+    assert l1.reshape(-1)[3] == np.float32(2e-05) and l2.reshape(-1)[:4].tolist() == [1.0, 0.0, 0.0, 0.0]
+    assert abs(float(l1.astype(np.float64).sum()) - 5409.868614) < 1e-5 and abs(float(l2.astype(np.float64).sum()) - 4783.065395) < 1e-5
+    from realtimeraytracer_amd import api
+    s = scenes.cornell_box(96, 96, ltc=(l1, l2))
+    p = api.make_params(96, 96, spp=1, images=A.IMAGES_RAYGEN5)
+    st, nodes, tris = api.host_build_bvh(s.desc)
+    r = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=(nodes, tris, st.grid), images=A.IMAGES_RAYGEN5, threads=8)
+    b = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=None, images=A.IMAGES_RAYGEN5, threads=8)
+    an = r.images[A.IMAGE_ANALYTIC].view(np.uint8).reshape(96, 96, 4)
+    assert np.array_equal(r.images[A.IMAGE_ANALYTIC], b.images[A.IMAGE_ANALYTIC])
+    assert np.all(an[..., 3] == 255) and an[..., :3].std() > 10 and an[..., :3].max() > 100
