@@ -326,7 +326,7 @@ inline Surface closest_hit_shader(const Scene& sc, const Hit& h, rtr_v3 rayDir, 
 struct PixelOut { rtr_v3 analytic, shadowed, unshadowed, avgNormal, avgPosition; };
 
 PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneInfo& info,
-                     const rtr_render_params& prm, uint32_t px, uint32_t py, bool wantAnalytic, Counters& c) {
+                     const rtr_render_params& prm, uint32_t px, uint32_t py, bool wantAnalytic, bool wantUnshadowed, Counters& c) {
     const rtr_scene_desc& D = sc.s->desc;
     PixelOut o;
     o.analytic = o.shadowed = o.unshadowed = o.avgNormal = o.avgPosition = rtr_mk(0, 0, 0);
@@ -417,6 +417,9 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
                     float lightDistance = rtr_length(lightVec);                           /* :222 */
                     Hit sh = trace(sc, shadowOrigin, sampledLightDir, 0.001f, lightDistance - 0.5f, true, c); /* :226-241 */
                     float currShadow = sh.hit ? 0.0f : 1.0f;                              /* :244 */
+                    /* an occluded sample adds contrib * 0 to the shadowed sum; when the unshadowed image is not an output its
+                     * BRDF is not evaluated (the product does the same; identical results whenever contrib is finite) */
+                    if (sh.hit && !wantUnshadowed) continue;
                     rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir)); /* :247 */
                     float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f); /* :250 */
                     float Dg = GGX_Distribution(hitNormal, halfVector, roughness);        /* :252 */
@@ -464,6 +467,7 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
         if (rtr_dot(hitNormal, directLightDir) <= 0.0f) continue;                         /* :293 */
         Hit sh = trace(sc, shadowOrigin, directLightDir, 0.001f, 10000.0f, true, c);      /* :303-313 */
         float currShadow = sh.hit ? 0.0f : 1.0f;                                          /* :316 */
+        if (sh.hit && !wantUnshadowed && !wantAnalytic) continue;                         /* contributes contrib * 0 to the only sum kept */
         rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, directLightDir));              /* :318 */
         float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);             /* :321 */
         float Dg = GGX_Distribution(hitNormal, halfVector, roughness);                    /* :323 */
@@ -594,7 +598,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
                 if (out->hdr && !prm.accumulate) { out->hdr[4 * p] = out->hdr[4 * p + 1] = out->hdr[4 * p + 2] = out->hdr[4 * p + 3] = 0; }
                 continue;
             }
-            PixelOut po = shade_pixel(sc, *cam, *info, prm, x, (uint32_t)gy, wantAnalytic, counters[(size_t)tid]);
+            PixelOut po = shade_pixel(sc, *cam, *info, prm, x, (uint32_t)gy, wantAnalytic, out->unshadowed != nullptr, counters[(size_t)tid]);
             rtr_v3 sh = po.shadowed;
             if (out->hdr) {
                 float* h = out->hdr + 4 * p;

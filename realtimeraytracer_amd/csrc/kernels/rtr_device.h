@@ -462,7 +462,11 @@ __device__ __forceinline__ bool fetch_surface(const DeviceScene& sc, const Rende
  * sequence of queries. */
 template <class Policy, bool STATS>
 __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
-                                            const Surface& sf, bool wantAnalytic, Accum& o, Policy& pol, LocalStats& st) {
+                                            const Surface& sf, uint32_t want, Accum& o, Policy& pol, LocalStats& st) {
+    /* want: bit 0 = the analytic (LTC) image is an output, bit 1 = the unshadowed image is.  When the unshadowed image is not
+     * asked for, an occluded sample contributes contrib * 0 to the only sum that is kept, so its BRDF is not evaluated
+     * (same rule in the oracle; identical results whenever contrib is finite). */
+    const bool wantAnalytic = (want & 1u) != 0u, wantUnshadowed = (want & 2u) != 0u;
     const rtr_v3 hitPoint = sf.hitPoint, hitNormal = sf.hitNormal, viewDir = sf.viewDir, color = sf.color;
     const rtr_v3 mDiffuse = sf.mDiffuse, mSpecular = sf.mSpecular;
     const float roughness = sf.roughness, om = sf.om;
@@ -502,7 +506,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
                 const rtr_v3 sampledLightDir = rtr_normalize(lightVec);
                 const float lightDistance = rtr_length(lightVec);
                 const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f);
-                if (Policy::kShade) {
+                if (Policy::kShade && (wantUnshadowed || !occ)) {
                     const float currShadow = occ ? 0.0f : 1.0f;
                     const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir));
                     const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
@@ -549,7 +553,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
     const rtr_v3 directLightDir = rtr_normalize(rtr_mk(-1.0f, 1.0f, -0.5f));
     if (rtr_dot(hitNormal, directLightDir) <= 0.0f) return;
     const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f);
-    if (Policy::kShade) {
+    if (Policy::kShade && (wantUnshadowed || wantAnalytic || !occ)) {
         const rtr_v3 directLightColor = rtr_mk(1.0f, 1.0f, 0.5f);
         const float directLightIntensity = 0.2f;
         const float currShadow = occ ? 0.0f : 1.0f;
@@ -578,11 +582,11 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
 /* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110, miss.rmiss:15-27). */
 template <class Policy, bool STATS>
 __device__ __forceinline__ void shade_sample(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
-                                             const HitRec& h, rtr_v3 rayDir, bool wantAnalytic, Accum& o,
+                                             const HitRec& h, rtr_v3 rayDir, uint32_t want, Accum& o,
                                              Policy& pol, LocalStats& st) {
     Surface sf;
-    if (!fetch_surface<Policy::kShade, STATS>(sc, ra, h, rayDir, wantAnalytic, o, sf, st)) return;
-    light_loops<Policy, STATS>(sc, ra, px, py, sf, wantAnalytic, o, pol, st);
+    if (!fetch_surface<Policy::kShade, STATS>(sc, ra, h, rayDir, (want & 1u) != 0u, o, sf, st)) return;
+    light_loops<Policy, STATS>(sc, ra, px, py, sf, want, o, pol, st);
 }
 
 __device__ __forceinline__ uint32_t tonemap_pack(rtr_v3 c) {                              /* raygen.rgen:345-357 */

@@ -92,14 +92,14 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
     Accum acc = zero_accum();
-    const bool wantAnalytic = fo.img[0] != nullptr;
+    const uint32_t want = (fo.img[0] != nullptr ? 1u : 0u) | (fo.img[2] != nullptr ? 2u : 0u);   /* analytic / unshadowed outputs */
     const rtr_v3 camPos = rtr_ld3(ra.cam.position);
     InlinePolicy<STATS, STACK> pol{sc, stack, st};
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const rtr_v3 dir = primary_dir(ra, px, py, i);
         HitRec h;
         trace<false, STATS, kBlock>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
-        shade_sample<InlinePolicy<STATS, STACK>, STATS>(sc, ra, px, py, h, dir, wantAnalytic, acc, pol, st);
+        shade_sample<InlinePolicy<STATS, STACK>, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
     write_pixel(ra, fo, (size_t)lrow * ra.width + px, acc);
     if (STATS) st.flush(stats);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
             const bool surf = fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);
-            if (surf) light_loops<CountPolicy, false>(sc, ra, px, py, sf, false, acc, cp, st);
+            if (surf) light_loops<CountPolicy, false>(sc, ra, px, py, sf, 0u, acc, cp, st);
             if (i == 0) { sf0 = sf; surf0 = surf; }
         }
         n = cp.n;
@@ -178,13 +178,13 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
         EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
         if (single) {
-            if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, false, acc, pol, st);
+            if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
             if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st))
-                light_loops<EmitPolicy, false>(sc, ra, px, py, sf, false, acc, pol, st);
+                light_loops<EmitPolicy, false>(sc, ra, px, py, sf, 0u, acc, pol, st);
         }
     }
 }
@@ -490,14 +490,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs r
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
     Accum acc = zero_accum();
-    const bool wantAnalytic = fo.img[0] != nullptr;
+    const uint32_t want = (fo.img[0] != nullptr ? 1u : 0u) | (fo.img[2] != nullptr ? 2u : 0u);   /* analytic / unshadowed outputs */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
         const rtr_v3 dir = primary_dir(ra, px, py, i);
         LookupPolicy pol{vis, (uint32_t)(k * ra.maxRaysPerSample)};
-        shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, wantAnalytic, acc, pol, st);
+        shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
     write_pixel(ra, fo, (size_t)lrow * ra.width + px, acc);
     if (STATS) st.flush(stats);
