@@ -5,13 +5,16 @@
 
 namespace rtrdev {
 
+constexpr uint32_t kQueueRegions = 8;                       /* one batch cursor per XCD: eight times the atomic rate of one counter */
+constexpr uint32_t kQueueCtrlWords = 16 + 16 * kQueueRegions;
+
 /* Scratch of the wavefront (staged) pipeline, owned by an rtr_frame. */
 struct Workspace {
     float4*   hitTuvp = nullptr;     /* per (pixel,sample): t,u,v,bits(primitiveID) */
     uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
     float4*   rayQueue = nullptr;    /* 2 x float4 per queued shadow ray: (o.xyz,tmax) (d.xyz,bits(slot)) */
     uint8_t*  vis = nullptr;         /* per slot: 1 = occluded */
-    uint32_t* queueCount = nullptr;  /* device counter of queued rays */
+    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [16 + 16 r] batch cursor of queue region r */
     uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail (capacity: one per slot) */
     int32_t*  spill = nullptr;       /* traversal-stack overflow of k_shadow_trace: 48 entries x (2048 workgroups x 256 lanes) */
     size_t    capPixelSamples = 0;

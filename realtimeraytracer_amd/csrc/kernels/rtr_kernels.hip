@@ -358,6 +358,13 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     const uint32_t n = *count;
     uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
     bool exhausted = false;                  /* wave-uniform */
+    /* The queue is cut into kQueueRegions contiguous regions with one batch cursor each (64 B apart).  A workgroup starts on
+     * region (blockIdx mod 8) — workgroups are dealt round-robin to the 8 XCDs — and moves on only when that region is empty.
+     * One counter sustains ~88 atomics/us, which is what forced 256-ray batches; eight counters allow batches small enough to
+     * balance the short queues of a 1/8-frame shard (launcher: kBatch shrinks with the queue). */
+    const uint32_t regionLen = ((n + kQueueRegions - 1) / kQueueRegions + kBatch - 1) / kBatch * kBatch;
+    const uint32_t myRegion = blockIdx.x % kQueueRegions;
+    uint32_t regionTry = 0;                  /* wave-uniform: regions found empty so far (cursors only grow) */
     int32_t cur = kDone;
     int sp = 0;                              /* entries held; the top is lds[sp * kBlock] */
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
@@ -382,11 +389,21 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
             }
             if (!exhausted) {
                 if (batchPos == batchEnd) {
-                    uint32_t b = 0;
-                    if ((threadIdx.x & 63u) == 0) b = atomicAdd(nextBatch, kBatch);
-                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                    if (b >= n) { exhausted = true; }
-                    else { batchPos = b; batchEnd = (b + kBatch < n) ? b + kBatch : n; }
+                    for (;;) {
+                        if (regionTry >= kQueueRegions) { exhausted = true; break; }
+                        const uint32_t r = (myRegion + regionTry) % kQueueRegions;
+                        const uint32_t lo = r * regionLen;
+                        uint32_t hi = lo + regionLen; if (hi > n) hi = n;
+                        uint32_t b = hi;
+                        if (lo < hi) {
+                            uint32_t got = 0;
+                            if ((threadIdx.x & 63u) == 0) got = atomicAdd(nextBatch + 16u * r, kBatch);
+                            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                            b = got < regionLen ? lo + got : hi;
+                        }
+                        if (b < hi) { batchPos = b; batchEnd = (b + kBatch < hi) ? b + kBatch : hi; break; }
+                        ++regionTry;
+                    }
                 }
                 if (!exhausted) {
                     const uint32_t avail = batchEnd - batchPos;
@@ -552,7 +569,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
                          Counters* stats, hipStream_t s, hipEvent_t* ev) {
     const uint32_t blocks = (padded_pixels(ra) + kBlock - 1) / kBlock;
     hipError_t e;
-    if ((e = hipMemsetAsync(ws.queueCount, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] batch cursor */
+    if ((e = hipMemsetAsync(ws.queueCount, 0, kQueueCtrlWords * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] / [16 + 16 r] batch cursors */
     if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
     if (ev) hipEventRecord(ev[0], s);
     if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
@@ -568,12 +585,13 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
+    static const uint32_t kBatchProd = env_u32("RTR_TRACE_BATCH_PROD", kBatch, 64u, 1u << 20);
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 20u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
     if (stats) hipLaunchKernelGGL((k_shadow_trace_count<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
     else {
-        hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
+        hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatchProd, kRefill, kInnerMin, ws.overflow);
         hipLaunchKernelGGL(k_shadow_tail, dim3(64), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis);
     }
     if (ev) hipEventRecord(ev[3], s);

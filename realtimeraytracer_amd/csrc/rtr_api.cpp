@@ -772,7 +772,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     if (wave) {
         if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); }
         if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); HIP_TRY(f->overflow.alloc(nSlots + 1)); }
-        if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(2));
+        if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(rtrdev::kQueueCtrlWords));
         if (!f->spill.p) HIP_TRY(f->spill.alloc((size_t)48 * 2048 * 256));      /* (64 - 16) entries x the largest persistent grid */
         Workspace ws;
         ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
