@@ -120,7 +120,7 @@ inline std::vector<uint8_t> zlib_inflate(const uint8_t* data, size_t n, size_t e
             static const short order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             int nlen = br.bits(5) + 257, ndist = br.bits(5) + 1, ncode = br.bits(4) + 4;
             if (nlen > 286 || ndist > 30) throw std::runtime_error("PNG: bad dynamic block counts");
-            short l[320]; Huffman lc, dc;
+            short l[320]; Huffman lc;
             for (int i = 0; i < 19; ++i) l[i] = 0;
             for (int i = 0; i < ncode; ++i) l[order[i]] = (short)br.bits(3);
             build(lc, l, 19);
