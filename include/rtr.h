@@ -173,6 +173,8 @@ typedef struct rtr_frame_stats {
 /* ---- context -------------------------------------------------------------------------- */
 /* replaces Instance+Device creation (src/app/application.cppm:65-69): picks HIP device `ordinal`. */
 int  rtr_ctx_create(int deviceOrdinal, rtr_ctx** out);
+/* Scenes and frames created on a context may be destroyed after it (garbage-collected bindings do that): the context's
+ * resources are released when its last child is gone.  Creating new objects on a destroyed context is an error. */
 void rtr_ctx_destroy(rtr_ctx* ctx);
 /* Use an existing HIP stream (e.g. torch's current stream) for all work of this ctx; NULL -> own stream. */
 int  rtr_ctx_set_stream(rtr_ctx* ctx, void* hipStream);

@@ -72,7 +72,20 @@ struct rtr_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     hipDeviceProp_t prop;
+    /* scenes and frames keep a pointer to their context: a context destroyed while it still has children lives on,
+     * unusable, until the last child is gone (garbage-collected bindings destroy objects in any order) */
+    int children = 0;
+    bool destroyed = false;
 };
+
+static void ctx_free(rtr_ctx* c) {
+    (void)hipSetDevice(c->device);
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+static void ctx_release_child(rtr_ctx* c) {
+    if (--c->children == 0 && c->destroyed) ctx_free(c);
+}
 
 struct rtr_scene {
     rtr_ctx* ctx = nullptr;
@@ -180,10 +193,9 @@ int rtr_ctx_create(int ordinal, rtr_ctx** out) {
 }
 
 void rtr_ctx_destroy(rtr_ctx* c) {
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    if (!c || c->destroyed) return;
+    if (c->children > 0) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); c->destroyed = true; return; }
+    ctx_free(c);
 }
 
 int rtr_ctx_set_stream(rtr_ctx* c, void* s) {
@@ -409,6 +421,7 @@ static void instance_tables(uint32_t numInstances, const RtrInstance* instances,
 
 int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: null ctx/out");
+    if (ctx->destroyed) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: the context has been destroyed");
     *out = nullptr;
     int rc = validate_desc(d);
     if (rc != RTR_OK) return rc;
@@ -428,7 +441,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     }
 
     rtr_scene* s = new rtr_scene();
-    s->ctx = ctx;
+    s->ctx = ctx; ++ctx->children;
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -465,7 +478,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
         hdri = rtrdev::DeviceTexture{s->hdriPixels.p, d->hdri->width, d->hdri->height, d->hdri->channels, 0};
     }
     if (e != hipSuccess) {
-        delete s;
+        delete s; ctx_release_child(ctx);
         return fail(e == hipErrorOutOfMemory ? RTR_ERR_OUT_OF_MEMORY : RTR_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
     }
     s->numLights = d->numLights; s->numObjects = d->numObjects; s->numVertices = d->numVertices; s->numIndices = d->numIndices;
@@ -475,7 +488,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     if (d->numObjects) s->hostObjects.assign(d->objects, d->objects + d->numObjects);
     if (deviceBuild) {
         rc = build_on_device(s, d, totalPrims);
-        if (rc != RTR_OK) { delete s; return rc; }
+        if (rc != RTR_OK) { delete s; ctx_release_child(ctx); return rc; }
     } else {
         fill_stats(s->stats, bvh, stackEntries, numTris);
         s->hostNodes.swap(bvh.nodes);
@@ -589,9 +602,11 @@ int rtr_scene_update_instances(rtr_scene* s, const RtrInstance* instances, uint3
 
 void rtr_scene_destroy(rtr_scene* s) {
     if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
+    rtr_ctx* c = s->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     delete s;
+    ctx_release_child(c);
 }
 
 int rtr_scene_get_stats(const rtr_scene* s, rtr_scene_stats* out) {
@@ -633,6 +648,7 @@ int rtr_scene_update_lights(rtr_scene* s, const RtrAreaLightInfo* lights, uint32
 /* ---- frame -------------------------------------------------------------------------------- */
 int rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t images, rtr_frame** out) {
     if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: null ctx/out");
+    if (ctx->destroyed) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: the context has been destroyed");
     *out = nullptr;
     if (width == 0 || rows == 0 || width > 65536 || rows > 65536) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: bad extent %ux%u", width, rows);
     if (images == 0) images = RTR_IMAGES_FRAMEBUFFER;
@@ -640,7 +656,7 @@ int rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t image
     if (images & ~known) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: unknown image bits 0x%x", images & ~known);
     HIP_TRY(hipSetDevice(ctx->device));
     rtr_frame* f = new rtr_frame();
-    f->ctx = ctx; f->width = width; f->rows = rows; f->images = images;
+    f->ctx = ctx; ++ctx->children; f->width = width; f->rows = rows; f->images = images;
     const size_t px = (size_t)width * rows;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 8 && e == hipSuccess; ++i)
@@ -661,7 +677,9 @@ void rtr_frame_destroy(rtr_frame* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : f->evMega) if (e) (void)hipEventDestroy(e);
+    rtr_ctx* c = f->ctx;
     delete f;
+    ctx_release_child(c);
 }
 
 int rtr_frame_bind_external(rtr_frame* f, int which, void* dptr, size_t bytes) {

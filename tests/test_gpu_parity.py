@@ -456,3 +456,19 @@ def test_deep_stack_rays_take_the_tail_kernel(gpu_ctx, oracle):
     fm = api.Frame(gpu_ctx, W, H)
     api.render(scene, cam, info, api.make_params(W, H, spp=1, pipeline=1), fm)
     _assert_same(fm.download(), imgs[1], "megakernel on the deep-stack scene")
+
+
+def test_context_may_be_destroyed_before_its_children(gpu_ctx, scene_cache):
+    """Garbage-collected bindings destroy objects in any order: a context outlives its last scene / frame internally."""
+    s = scenes.cornell_box(64, 64)
+    ctx = api.Context(0)
+    scene = api.Scene(ctx, s.desc)
+    frame = api.Frame(ctx, 64, 64)
+    api.render(scene, s.camera, s.scene_info(0), api.make_params(64, 64), frame)
+    before = frame.download()
+    ctx.close()                                   # children still alive
+    assert np.array_equal(frame.download(), before)
+    frame.close()
+    scene.close()                                 # the last child releases the context
+    ctx2 = api.Context(0)
+    ctx2.close()
