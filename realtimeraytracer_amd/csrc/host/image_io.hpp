@@ -170,7 +170,7 @@ inline void decode_png(const std::vector<uint8_t>& f, int& w, int& h, int& src_c
         else if (type == "IEND") break;
         pos += 12 + len;
     }
-    if (!haveHdr || w <= 0 || h <= 0 || w > 1 << 16 || h > 1 << 16) throw std::runtime_error("PNG: missing or bad IHDR");
+    if (!haveHdr || w <= 0 || h <= 0 || w > 1 << 16 || h > 1 << 16 || (size_t)w * (size_t)h > ((size_t)1 << 28)) throw std::runtime_error("PNG: missing or bad IHDR (or more than 2^28 pixels)");
     if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
     int samples;
     switch (ctype) { case 0: samples = 1; break; case 2: samples = 3; break; case 3: samples = 1; break; case 4: samples = 2; break; case 6: samples = 4; break;
@@ -288,6 +288,7 @@ inline void decode_pnm(const std::vector<uint8_t>& f, int& w, int& h, int& src_c
     src_channels = f[1] == '5' ? 1 : 3;
     w = next_int(); h = next_int(); int maxv = next_int();
     if (maxv != 255) throw std::runtime_error("PNM: only maxval 255 is supported");
+    if (w <= 0 || h <= 0 || (size_t)w * (size_t)h > ((size_t)1 << 28)) throw std::runtime_error("PNM: bad size");
     ++pos;                                                          // single whitespace after maxval
     size_t n = (size_t)w * h * src_channels;
     if (w <= 0 || h <= 0 || pos + n > f.size()) throw std::runtime_error("PNM: truncated data");
@@ -304,7 +305,7 @@ inline void decode_hdr(const std::vector<uint8_t>& f, int& w, int& h, std::vecto
     for (;;) { std::string l = line(); if (l.empty()) break; if (l == "FORMAT=32-bit_rle_rgbe") fmt = true; if (pos >= f.size()) break; }
     if (!fmt) throw std::runtime_error("HDR: unsupported format");
     std::string res = line();
-    if (std::sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) throw std::runtime_error("HDR: unsupported data layout");
+    if (std::sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0 || (size_t)w * (size_t)h > ((size_t)1 << 28)) throw std::runtime_error("HDR: unsupported data layout (or more than 2^28 pixels)");
     rgb.resize((size_t)w * h * 3);
     std::vector<uint8_t> scan((size_t)w * 4);
     auto to_float = [](const uint8_t* c, float* o) {
@@ -347,7 +348,7 @@ inline void decode_tga(const std::vector<uint8_t>& f, int& w, int& h, int& src_c
     const int bpp = f[16], desc = f[17];
     const bool rle = type >= 9 && type <= 11;
     const int base = rle ? type - 8 : type;
-    if (base < 1 || base > 3 || w <= 0 || h <= 0) bad("unsupported image type or size");
+    if (base < 1 || base > 3 || w <= 0 || h <= 0 || (size_t)w * (size_t)h > ((size_t)1 << 28)) bad("unsupported image type or size");
     if ((base == 1) != (cmapType == 1)) bad("colour map / image type mismatch");
     auto channels_of = [&](int bits, bool grey) -> int {
         if (grey) return bits == 8 ? 1 : 0;
@@ -429,7 +430,7 @@ inline void decode_bmp(const std::vector<uint8_t>& f, int& w, int& h, int& src_c
     else { bad("unsupported header size"); return; }
     const bool topDown = hs < 0;
     h = topDown ? -hs : hs;
-    if (w <= 0 || h <= 0) bad("bad size");
+    if (w <= 0 || h <= 0 || (size_t)w * (size_t)h > ((size_t)1 << 28)) bad("bad size (or more than 2^28 pixels)");
     uint32_t mr = 0x00ff0000u, mg = 0x0000ff00u, mb = 0x000000ffu, ma = 0xff000000u;
     if (comp == 3) {
         if (bpp != 32) bad("BI_BITFIELDS is decoded for 32-bit files only");
@@ -488,9 +489,13 @@ inline std::vector<uint8_t> read_file(const std::string& path) {
 }  // namespace detail
 
 // stbi_load(path, ..., desired_channels) + optional vertical flip.  desired_channels: 1 (STBI_grey) or 4 (STBI_rgb_alpha).
+inline Image decode_image(const std::vector<uint8_t>& f, const std::string& path, int desired_channels, bool flip_vertically);
 inline Image load_image(const std::string& path, int desired_channels, bool flip_vertically) {
+    return decode_image(detail::read_file(path), path, desired_channels, flip_vertically);
+}
+// The same from memory (`path` only names the file in messages and, for TGA, supplies the extension).
+inline Image decode_image(const std::vector<uint8_t>& f, const std::string& path, int desired_channels, bool flip_vertically) {
     if (desired_channels != 1 && desired_channels != 4) throw std::runtime_error("load_image: desired_channels must be 1 or 4");
-    std::vector<uint8_t> f = detail::read_file(path);
     int w = 0, h = 0, sc = 0;
     std::vector<uint8_t> px;
     static const uint8_t pngsig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};

@@ -270,6 +270,7 @@ struct JpegDecoder {
         if (get8() != 8) jpeg_fail("only 8-bit samples are decoded");
         imgy = get16(); imgx = get16(); ncomp = get8();
         if (imgx <= 0 || imgy <= 0) jpeg_fail("bad size");
+        if ((size_t)imgx * (size_t)imgy > ((size_t)1 << 28)) jpeg_fail("image larger than 2^28 pixels");
         if (ncomp != 1 && ncomp != 3) jpeg_fail("only 1- and 3-component files are decoded (no CMYK / YCCK)");
         if (len != 6 + 3 * ncomp) jpeg_fail("bad SOF length");
         static const char rgb[3] = {'R', 'G', 'B'};

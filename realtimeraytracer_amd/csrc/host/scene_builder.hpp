@@ -33,6 +33,12 @@ struct MeshData {
 };
 
 inline Vertex make_vertex(const rtr::obj::attrib_t& attrib, const rtr::obj::index_t& index) {
+    // the reference indexes attrib blindly (file.cppm:151-183); a face that names a vertex / normal / uv the file does not
+    // define is refused here instead of reading out of bounds
+    if (index.vertex_index < 0 || 3 * (size_t)index.vertex_index + 2 >= attrib.vertices.size() ||
+        (index.normal_index >= 0 && 3 * (size_t)index.normal_index + 2 >= attrib.normals.size()) ||
+        (index.texcoord_index >= 0 && 2 * (size_t)index.texcoord_index + 1 >= attrib.texcoords.size()))
+        throw std::runtime_error("OBJ: a face references a vertex, normal or texture coordinate that is not defined");
     Vertex vertex{};
     vertex.position = {attrib.vertices[3 * index.vertex_index + 0], attrib.vertices[3 * index.vertex_index + 1],
                        attrib.vertices[3 * index.vertex_index + 2]};
