@@ -237,6 +237,16 @@ static int validate_desc(const rtr_scene_desc* d) {
         seen[in.customIndex] = 1;
         if (in.customIndex >= d->numLights && in.customIndex - d->numLights >= d->numObjects)
             return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: customIndex %u has no ObjectInfo (numLights %u, numObjects %u)", i, in.customIndex, d->numLights, d->numObjects);
+        if (in.customIndex >= d->numLights) {
+            /* the hit shader reads indices / vertices through the ObjectInfo's offsets (closesthit.rchit:59-65), which the
+             * reference sets to the mesh's own when it builds the TLAS (tlas.cppm:58-71): anything else would fetch another
+             * mesh's data, or none */
+            const RtrObjectInfo& oi = d->objects[in.customIndex - d->numLights];
+            const RtrMesh& me = d->meshes[in.meshIndex];
+            if (oi.vertexOffset != me.vertexOffset || oi.indexOffset != me.indexOffset)
+                return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: ObjectInfo offsets (%u, %u) differ from its mesh's (%u, %u)", i, oi.vertexOffset, oi.indexOffset,
+                            me.vertexOffset, me.indexOffset);
+        }
         for (int k = 0; k < 12; ++k)
             if (!(in.transform[k] == in.transform[k]) || in.transform[k] > 3.0e38f || in.transform[k] < -3.0e38f)
                 return fail(RTR_ERR_INVALID_ARGUMENT, "instance %u: non-finite transform", i);

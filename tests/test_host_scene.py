@@ -137,3 +137,22 @@ def test_reference_ltc_tables_known_answers_and_analytic_image(oracle, scene_cac
     an = r.images[A.IMAGE_ANALYTIC].view(np.uint8).reshape(96, 96, 4)
     assert np.array_equal(r.images[A.IMAGE_ANALYTIC], b.images[A.IMAGE_ANALYTIC])
     assert np.all(an[..., 3] == 255) and an[..., :3].std() > 10 and an[..., :3].max() > 100
+
+
+def test_desc_with_inconsistent_object_offsets_is_refused(scene_cache):
+    """The hit shader fetches through ObjectInfo.vertexOffset / indexOffset: a desc whose ObjectInfo disagrees with the mesh of
+    its instance would read another mesh's data (or past the arrays) on the device, so scene creation refuses it."""
+    import ctypes as C
+    from realtimeraytracer_amd import api
+    s = scenes.cornell_box(32, 32)
+    api.host_build_bvh(s.desc)                                        # the honest desc is accepted
+    d = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc))
+    objs = (A.RtrObjectInfo * d.numObjects)(*[A.RtrObjectInfo.from_buffer_copy(bytes(d.objects[i])) for i in range(d.numObjects)])
+    objs[1].vertexOffset += 3
+    d.objects = C.cast(objs, C.POINTER(A.RtrObjectInfo))
+    with pytest.raises(api.RtrError):
+        api.host_build_bvh(d)
+    objs[1].vertexOffset -= 3
+    objs[2].indexOffset = 10 ** 9
+    with pytest.raises(api.RtrError):
+        api.host_build_bvh(d)
