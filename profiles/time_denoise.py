@@ -21,3 +21,21 @@ for it in (4,):
         frame.denoise_combine(it)
     torch.cuda.synchronize()
     print(f"denoise x{it} (2 images each) + combine at {W}x{H}: {(time.perf_counter() - t0) * 1e3 / n:.3f} ms per call")
+# the whole frame the reference presents: ray-gen with all five images (analytic LTC, shadowed, unshadowed, normal, position),
+# four denoise steps, combine
+for _ in range(3):
+    api.render(scene, s.camera, s.scene_info(0), p, frame)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(n):
+    api.render(scene, s.camera, s.scene_info(i), p, frame)
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+st = frame.stats()
+print(f"ray-gen dispatch with 5 images: {(t1 - t0) * 1e3 / n:.3f} ms per frame (primary {st.primaryMs:.3f} gen {st.shadowGenMs:.3f} trace {st.shadowTraceMs:.3f} resolve {st.resolveMs:.3f})")
+t0 = time.perf_counter()
+for i in range(n):
+    api.render(scene, s.camera, s.scene_info(i), p, frame)
+    frame.denoise_combine(4)
+torch.cuda.synchronize()
+print(f"ray-gen (5 images) + denoise x4 + combine: {(time.perf_counter() - t0) * 1e3 / n:.3f} ms per presented frame")
