@@ -42,4 +42,8 @@ hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDevic
  * from the new root bounds and re-quantise. */
 hipError_t bvh_refit(const BvhInputs& in, uint32_t numPrims, uint32_t numNodes, const BvhDeviceArrays& a, hipStream_t s);
 
+/* The 4-wide view of a finished (quantised) tree that the any-hit kernel walks: numNodes x 4 uint4, see k_wide_nodes.
+ * parentOrNull: the refit parent array (entries outside the tree are skipped) or null. */
+hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, const RtrBvhGrid* grid, uint4* wide, hipStream_t s);
+
 }  // namespace rtrdev

@@ -282,6 +282,52 @@ __global__ __launch_bounds__(kB) void k_quantize(uint32_t numNodes, const float4
     nodes[(size_t)i * 2] = w0; nodes[(size_t)i * 2 + 1] = w1;
 }
 
+/* 4-wide view of the tree for the any-hit kernel (rtr_kernels.hip, k_shadow_trace4): entry n starts from the two children of
+ * BVH2 node n and, while a slot is free, opens the inner entry with the largest box into its own two children; boxes are
+ * copied from the BVH2 nodes that own them and child codes keep BVH2 node ids, so entry 0 roots a complete 4-wide tree.
+ * Word layout (16 words): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16), then the four child codes; an empty
+ * slot has the code 0x80000000. */
+__global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
+                                                   const RtrBvhGrid* __restrict__ grid, uint4* __restrict__ wide) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= numNodes) return;
+    uint32_t o[16];
+    for (int k = 0; k < 16; ++k) o[k] = 0u;
+    for (int k = 12; k < 16; ++k) o[k] = 0x80000000u;
+    if (!parent || parent[i] != -2) {
+        const float sx = grid->scale[0], sy = grid->scale[1], sz = grid->scale[2];
+        /* an entry = (owner node, side); its three plane words and its code come from the owner */
+        uint32_t own[4]; int side[4]; int k = 2;
+        own[0] = own[1] = i; side[0] = 0; side[1] = 1;
+        auto words = [&](uint32_t n, int sd, uint32_t& wmin, uint32_t& wmax, uint32_t& wz, int32_t& code) {
+            const uint4 a = nodes[(size_t)n * 2], b = nodes[(size_t)n * 2 + 1];
+            wmin = sd ? a.z : a.x; wmax = sd ? a.w : a.y; wz = sd ? b.y : b.x; code = (int32_t)(sd ? b.w : b.z);
+        };
+        auto area = [&](uint32_t wmin, uint32_t wmax, uint32_t wz) {
+            const float dx = (float)((wmax & 0xffffu) - (wmin & 0xffffu)) * sx, dy = (float)((wmax >> 16) - (wmin >> 16)) * sy;
+            const float dz = (float)((wz >> 16) - (wz & 0xffffu)) * sz;
+            return dx * dy + dy * dz + dz * dx;
+        };
+        while (k < 4) {
+            int best = -1; float bestA = -1.0f; int32_t bestCode = 0;
+            for (int j = 0; j < k; ++j) {
+                uint32_t wmin, wmax, wz; int32_t code;
+                words(own[j], side[j], wmin, wmax, wz, code);
+                if (code >= 0 && (uint32_t)code < numNodes) { const float a = area(wmin, wmax, wz); if (a > bestA) { bestA = a; best = j; bestCode = code; } }
+            }
+            if (best < 0) break;
+            own[best] = (uint32_t)bestCode; side[best] = 0;
+            own[k] = (uint32_t)bestCode; side[k] = 1; ++k;
+        }
+        for (int j = 0; j < k; ++j) {
+            uint32_t wmin, wmax, wz; int32_t code;
+            words(own[j], side[j], wmin, wmax, wz, code);
+            o[j * 3] = wmin; o[j * 3 + 1] = wmax; o[j * 3 + 2] = wz; o[12 + j] = (uint32_t)code;
+        }
+    }
+    for (int q = 0; q < 4; ++q) wide[(size_t)i * 4 + q] = make_uint4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);
+}
+
 /* ---- host-side drivers ------------------------------------------------------------------------------ */
 #define BV_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -315,6 +361,11 @@ hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDevic
     hipLaunchKernelGGL(k_fit, gn, dim3(kB), 0, s, numNodes, a.nodesF, a.boxMin, a.boxMax, a.parent, a.counters, a.depth, a.red, a.red + 7);
     hipLaunchKernelGGL(k_grid, dim3(1), dim3(64), 0, s, a.nodesF, a.grid);
     hipLaunchKernelGGL(k_quantize, gn, dim3(kB), 0, s, numNodes, a.nodesF, a.parent, a.grid, a.nodes);
+    return hipGetLastError();
+}
+
+hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, const RtrBvhGrid* grid, uint4* wide, hipStream_t s) {
+    hipLaunchKernelGGL(k_wide_nodes, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, nodes, parentOrNull, grid, wide);
     return hipGetLastError();
 }
 

@@ -92,6 +92,7 @@ struct rtr_scene {
     DevBuf<uint4> nodes;                 /* RtrBvhNode, 2 x uint4 each */
     DevBuf<float4> nodesF;               /* rtr::BvhNodeF, 4 x float4 each: device build / refit only */
     DevBuf<RtrBvhGrid> grid;
+    DevBuf<uint4> nodes4;                /* 4-wide view of the tree for the any-hit kernel, 4 x uint4 per BVH2 node id (kernels/rtr_bvh.hip) */
     DevBuf<float4> tris;
     DevBuf<RtrVertex> vertices;
     DevBuf<uint32_t> indices;
@@ -362,6 +363,16 @@ static void make_prim_tables(const rtr_scene_desc* d, const RtrInstance* instanc
     }
 }
 
+/* (re)builds the 4-wide view of the tree the any-hit kernel walks, on the device, from the quantised BVH2 nodes */
+static int make_wide_nodes(rtr_scene* s) {
+    const uint32_t n = (uint32_t)s->hostNodes.size();
+    if (!s->nodes4.p) HIP_TRY(s->nodes4.alloc((size_t)n * 4));
+    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4.p, s->ctx->stream);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node build: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    return RTR_OK;
+}
+
 static rtrdev::BvhDeviceArrays device_arrays(rtr_scene* s) {
     rtrdev::BvhDeviceArrays a{};
     a.nodes = s->nodes.p; a.nodesF = s->nodesF.p; a.grid = s->grid.p; a.tris = s->tris.p; a.boxMin = s->boxMin.p; a.boxMax = s->boxMax.p; a.parent = s->parent.p;
@@ -506,8 +517,10 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
         s->numPrims = (uint32_t)s->hostTris.size(); s->numNodeSlots = (uint32_t)s->hostNodes.size();
     }
 
+    rc = make_wide_nodes(s);
+    if (rc != RTR_OK) { delete s; ctx_release_child(ctx); return rc; }
     DeviceScene& dv = s->dev;
-    dv.nodes = s->nodes.p; dv.grid = s->grid.p; dv.tris = s->tris.p;
+    dv.nodes = s->nodes.p; dv.nodes4 = s->nodes4.p; dv.grid = s->grid.p; dv.tris = s->tris.p;
     dv.vertices = s->vertices.p; dv.indices = s->indices.p;
     dv.objects = s->objects.p; dv.lights = s->lights.p;
     dv.xforms = s->xforms.p; dv.nmats = s->nmats.p;
@@ -602,6 +615,7 @@ int rtr_scene_update_instances(rtr_scene* s, const RtrInstance* instances, uint3
     HIP_TRY(hipMemcpy(s->hostNodes.data(), s->nodes.p, s->hostNodes.size() * sizeof(RtrBvhNode), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(s->hostTris.data(), s->tris.p, s->hostTris.size() * 48, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&s->stats.grid, s->grid.p, sizeof(RtrBvhGrid), hipMemcpyDeviceToHost));
+    { const int rc4 = make_wide_nodes(s); if (rc4 != RTR_OK) return rc4; }
     HIP_TRY(hipMemcpy(red, s->red.p, sizeof red, hipMemcpyDeviceToHost));
     float mabs; memcpy(&mabs, &red[6], 4);
     s->stats.boxPad = (mabs > 1e-6f ? mabs : 1e-6f) * 3.814697265625e-06f;
