@@ -630,19 +630,22 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace4(DeviceScene sc, const 
     }
 }
 
-/* Finishes the rays the production k_shadow_trace abandoned (stack deeper than its 16 LDS entries): one ray per lane,
- * full-depth 64-entry LDS stack, plain trace<true>().  Usually zero rays; the grid is small and exits at once. */
+/* Finishes the rays the production kernels abandoned (stack deeper than their 16 LDS entries): one ray per lane, plain
+ * trace<true>() with a full-depth 64-entry stack.  Usually zero rays.  The stack lives in GLOBAL memory (the frame's spill
+ * area): a 64-KiB LDS stack could not become resident next to another frame's persistent traversal kernel, so with frames
+ * in flight this small launch used to wait for that kernel to drain and held up its own frame's resolve behind it. */
+constexpr int kTailBlocks = 64;
 __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const float4* __restrict__ queue, const uint32_t* __restrict__ overflow,
-                                                        uint8_t* __restrict__ vis) {
-    __shared__ int32_t s_stack[64 * kBlock];
-    int32_t* stack = s_stack + threadIdx.x;
+                                                        uint8_t* __restrict__ vis, int32_t* __restrict__ spill) {
     const uint32_t n = overflow[0];
+    if (n == 0) return;
+    int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;          /* depth stride = every lane of the grid */
     LocalStats st;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += kTailBlocks * kBlock) {
         const uint32_t r = overflow[1u + i];
         const float4 a = queue[(size_t)r * 2], b = queue[(size_t)r * 2 + 1];
         HitRec h;
-        const bool occ = trace<true, false, kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
+        const bool occ = trace<true, false, kTailBlocks * kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
         vis[__float_as_uint(b.w)] = occ ? 1 : 0;
     }
 }
@@ -729,7 +732,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     /* persistent waves: as many workgroups as stay resident (16 KiB of LDS stack per workgroup -> 8 per CU, the
      * 32-wave hardware maximum), each pulling batches until the queue is empty */
     const size_t maxRays = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
-    uint32_t tblocks = 256u * 8u;
+    uint32_t tblocks = 256u * 8u;         /* leaving wave slots free for the other frames' kernels (6-7 per CU) bought no throughput */
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
@@ -744,7 +747,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
         static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);
         if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatchProd, kRefill, kInnerMin, ws.overflow);
         else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatchProd, kRefill, kInnerMin, ws.overflow);
-        hipLaunchKernelGGL(k_shadow_tail, dim3(64), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis);
+        hipLaunchKernelGGL(k_shadow_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill);
     }
     if (ev) hipEventRecord(ev[3], s);
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
