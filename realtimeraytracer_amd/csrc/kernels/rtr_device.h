@@ -159,7 +159,10 @@ __device__ __forceinline__ bool slab_pair(uint32_t wmin, uint32_t wmax, uint32_t
  * storage order, closest = min over (t, customIndex, primitiveID).
  * `stack` points at this lane's slot 0; consecutive depths are `BLOCK` ints apart.
  * ------------------------------------------------------------------------------------------ */
-template <bool ANY, bool STATS, int BLOCK>
+/* LIMIT > 0: the stack holds only LIMIT entries; a ray that needs more is abandoned with best.custom = RTR_STACK_OVERFLOW (the
+ * caller re-traces it with a full-depth stack), so the common case can run with a small LDS footprint. */
+#define RTR_STACK_OVERFLOW 0xfffffffeu
+template <bool ANY, bool STATS, int BLOCK, int LIMIT = 0>
 __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict__ stack,
                                       rtr_v3 o, rtr_v3 d, float tmin, float tmax, HitRec& best, LocalStats& st) {
     if (STATS) { st.rays++; if (ANY) st.shadow++; else st.primary++; }
@@ -190,6 +193,7 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;
                 const int32_t farC = swap ? ch.x : ch.y;
+                if (LIMIT > 0 && sp >= LIMIT) { best.custom = RTR_STACK_OVERFLOW; best.prim = RTR_MISS; best.t = tmax; return false; }
                 stack[sp * BLOCK] = farC; ++sp;
                 cur = nearC;
                 continue;

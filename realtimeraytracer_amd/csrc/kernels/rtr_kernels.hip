@@ -106,10 +106,15 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
 }
 
 /* ---- wavefront stage 1: primary visibility ---------------------------------------------------- */
+/* The production form (STATS = false) always runs with a 16-entry LDS stack (16 KiB per workgroup): ordered traversal seldom
+ * holds more, the kernel fits next to another frame's persistent traversal kernel much earlier (frames in flight: +3 %), and
+ * the rare ray that needs more is listed in `redo` and re-traced by k_primary_tail with a full-depth stack in global memory.
+ * The counting form keeps the depth-bound stack so its counters are exactly the oracle's. */
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
-                                                    Counters* stats) {
-    __shared__ int32_t s_stack[STACK * kBlock];
+                                                    Counters* stats, uint32_t* redo) {
+    constexpr int kLds = STATS ? STACK : 16;
+    __shared__ int32_t s_stack[kLds * kBlock];
     int32_t* stack = s_stack + threadIdx.x;
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     uint32_t px, lrow, py;
@@ -119,13 +124,34 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const rtr_v3 dir = primary_dir(ra, px, py, i);
         HitRec h;
-        trace<false, STATS, kBlock>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
+        trace<false, STATS, kBlock, STATS ? 0 : 16>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
         /* sample-major planes keep each store of a wave contiguous */
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
+        if (!STATS && h.custom == RTR_STACK_OVERFLOW) { redo[1u + atomicAdd(redo, 1u)] = (uint32_t)k; continue; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
     }
     if (STATS) st.flush(stats);
+}
+
+/* Re-traces the pixel-samples k_primary abandoned: full-depth stack in global memory (no LDS, so it can always run). */
+__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
+                                                         const uint32_t* __restrict__ redo, int32_t* __restrict__ spill, uint32_t planeStride) {
+    const uint32_t n = redo[0];
+    if (n == 0) return;
+    int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;
+    LocalStats st;
+    const rtr_v3 camPos = rtr_ld3(ra.cam.position);
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const uint32_t k = redo[1u + j];
+        const uint32_t i = k / planeStride, q = k % planeStride;           /* sample index, pixel slot */
+        uint32_t px, lrow, py;
+        if (!pixel_of(ra, q, px, lrow, py)) continue;
+        HitRec h;
+        trace<false, false, 64 * kBlock>(sc, stack, camPos, primary_dir(ra, px, py, i), 0.001f, 10000.0f, h, st);
+        hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+        hitCustom[k] = h.custom;
+    }
 }
 
 /* ---- wavefront stage 2: shadow-ray generation into the compacted queue ------------------------- */
@@ -201,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
  *     finished), then all leaves are intersected together;
  * A lane's own sequence of node visits / triangle tests is exactly that of trace<true>() — and of the
  * oracle's trace_bvh() — so visibility bits AND work counters are unchanged. */
+constexpr int kTailBlocks = 64;            /* grid of the two "redo" kernels; their global stacks are strided by 64 * kBlock lanes */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
 constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
 constexpr uint32_t kRefillDefault = 28;    /* idle lanes that trigger a refill */
@@ -634,7 +661,6 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace4(DeviceScene sc, const 
  * trace<true>() with a full-depth 64-entry stack.  Usually zero rays.  The stack lives in GLOBAL memory (the frame's spill
  * area): a 64-KiB LDS stack could not become resident next to another frame's persistent traversal kernel, so with frames
  * in flight this small launch used to wait for that kernel to drain and held up its own frame's resolve behind it. */
-constexpr int kTailBlocks = 64;
 __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const float4* __restrict__ queue, const uint32_t* __restrict__ overflow,
                                                         uint8_t* __restrict__ vis, int32_t* __restrict__ spill) {
     const uint32_t n = overflow[0];
@@ -724,8 +750,14 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if ((e = hipMemsetAsync(ws.queueCount, 0, kQueueCtrlWords * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] / [16 + 16 r] batch cursors */
     if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
     if (ev) hipEventRecord(ev[0], s);
-    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats);
+    /* ws.overflow is used twice per frame: first as k_primary's redo list (consumed by k_primary_tail), then — reset — as the
+     * any-hit kernel's overflow list */
+    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.overflow);
+    else {
+        hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.overflow);
+        hipLaunchKernelGGL(k_primary_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.overflow, ws.spill, blocks * kBlock);
+        if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+    }
     if (ev) hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(k_shadow_gen, dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount);
     if (ev) hipEventRecord(ev[2], s);

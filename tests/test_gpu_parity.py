@@ -456,6 +456,33 @@ def test_deep_stack_rays_take_the_tail_kernel(gpu_ctx, oracle):
     fm = api.Frame(gpu_ctx, W, H)
     api.render(scene, cam, info, api.make_params(W, H, spp=1, pipeline=1), fm)
     _assert_same(fm.download(), imgs[1], "megakernel on the deep-stack scene")
+    # PRIMARY rays that need more than k_primary's 16 LDS entries: the same row squeezed to 0.01 units per triangle (primary
+    # rays end at t = 10000) and a camera at its head looking down its length — ordered traversal keeps one pending far child
+    # per level of the ~20-level tree -> k_primary_tail re-traces those pixel-samples.  (At this grazing angle Moeller-Trumbore's
+    # |a| < EPSILON rule rejects every triangle, so the picture is sky: what is checked is that the abandoned pixel-samples get
+    # their hit records from the tail kernel at all.)
+    tri2 = tri.copy(); tri2[:, 0] *= np.float32(0.01)
+    verts2 = np.concatenate([lightq * np.array([0.01, 1, 1], np.float32), recv, tri2])
+    d2, keep2 = _desc_from_arrays(verts2, idx, meshes, [(0, 0), (1, 1), (2, 2)], objs, [L])
+    scene2 = api.Scene(gpu_ctx, d2)
+    assert scene2.stats().maxDepth > 16
+    bvh2 = scene2.export_bvh()
+    end = float(N) * 0.01
+    cam2 = host.Camera(0.004, (-30.0, -0.995, 0.0), (0.8 * end, -1.0, 0.0), (0.0, 1.0, 0.0), W, H).getGPUData()    # inside the boxes' padding all the way
+    info2 = host.scene_info(1, 1, (-30.0, -0.995, 0.0))
+    out = {}
+    for collect in (0, 1):
+        p = api.make_params(W, H, spp=2, collect_stats=collect, pipeline=2)
+        f2 = api.Frame(gpu_ctx, W, H)
+        api.render(scene2, cam2, info2, p, f2)
+        out[collect] = f2.download()
+        if collect:
+            ref2 = oracle.render(d2, cam2, info2, p, bvh=bvh2, threads=16)
+            _assert_same(out[1], ref2.images[A.IMAGE_SHADOWED], "skimming primary rays, counting kernels")
+            g2 = f2.stats()
+            assert (g2.numNodeVisits, g2.numTriTests, g2.numHits) == (ref2.stats.numNodeVisits, ref2.stats.numTriTests, ref2.stats.numHits)
+            assert (g2.numNodeVisits - g2.numShadowNodeVisits) / g2.numPrimaryRays > 1000, "primary rays must walk a long stretch of the row"
+    _assert_same(out[0], out[1], "production k_primary (16 LDS entries + redo tail) vs counting kernel")
 
 
 def test_context_may_be_destroyed_before_its_children(gpu_ctx, scene_cache):
