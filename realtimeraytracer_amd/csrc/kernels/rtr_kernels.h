@@ -14,7 +14,7 @@ struct Workspace {
     uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
     float4*   rayQueue = nullptr;    /* 2 x float4 per queued shadow ray: (o.xyz,tmax) (d.xyz,bits(slot)) */
     uint8_t*  vis = nullptr;         /* per slot: 1 = occluded */
-    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [16 + 16 r] batch cursor of queue region r */
+    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [16 + 16 r] batch cursor of queue region r */
     uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail (capacity: one per slot) */
     int32_t*  spill = nullptr;       /* traversal-stack overflow of k_shadow_trace: 48 entries x (2048 workgroups x 256 lanes) */
     size_t    capPixelSamples = 0;

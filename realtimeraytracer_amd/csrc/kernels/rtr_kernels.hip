@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
  * The counting form keeps the depth-bound stack so its counters are exactly the oracle's. */
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
-                                                    Counters* stats, uint32_t* redo) {
+                                                    Counters* stats, uint32_t* redoCount, uint32_t* redoList) {
     constexpr int kLds = STATS ? STACK : 16;
     __shared__ int32_t s_stack[kLds * kBlock];
     int32_t* stack = s_stack + threadIdx.x;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
         trace<false, STATS, kBlock, STATS ? 0 : 16>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
         /* sample-major planes keep each store of a wave contiguous */
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
-        if (!STATS && h.custom == RTR_STACK_OVERFLOW) { redo[1u + atomicAdd(redo, 1u)] = (uint32_t)k; continue; }
+        if (!STATS && h.custom == RTR_STACK_OVERFLOW) { redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k; continue; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
     }
@@ -136,14 +136,15 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
 
 /* Re-traces the pixel-samples k_primary abandoned: full-depth stack in global memory (no LDS, so it can always run). */
 __global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
-                                                         const uint32_t* __restrict__ redo, int32_t* __restrict__ spill, uint32_t planeStride) {
-    const uint32_t n = redo[0];
+                                                         const uint32_t* __restrict__ redoCount, const uint32_t* __restrict__ redoList,
+                                                         int32_t* __restrict__ spill, uint32_t planeStride) {
+    const uint32_t n = *redoCount;
     if (n == 0) return;
     int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;
     LocalStats st;
     const rtr_v3 camPos = rtr_ld3(ra.cam.position);
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const uint32_t k = redo[1u + j];
+        const uint32_t k = redoList[j];
         const uint32_t i = k / planeStride, q = k % planeStride;           /* sample index, pixel slot */
         uint32_t px, lrow, py;
         if (!pixel_of(ra, q, px, lrow, py)) continue;
@@ -750,13 +751,12 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if ((e = hipMemsetAsync(ws.queueCount, 0, kQueueCtrlWords * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] / [16 + 16 r] batch cursors */
     if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
     if (ev) hipEventRecord(ev[0], s);
-    /* ws.overflow is used twice per frame: first as k_primary's redo list (consumed by k_primary_tail), then — reset — as the
-     * any-hit kernel's overflow list */
-    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.overflow);
+    /* the storage of ws.overflow is used twice per frame: first as k_primary's redo list (count in queueCount[2], consumed by
+     * k_primary_tail), then as the any-hit kernel's overflow list (count in overflow[0]) */
+    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1);
     else {
-        hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.overflow);
-        hipLaunchKernelGGL(k_primary_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.overflow, ws.spill, blocks * kBlock);
-        if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1);
+        hipLaunchKernelGGL(k_primary_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, blocks * kBlock);
     }
     if (ev) hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(k_shadow_gen, dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount);
