@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
 constexpr int kTailBlocks = 64;            /* grid of the two "redo" kernels; their global stacks are strided by 64 * kBlock lanes */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
 constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
-constexpr uint32_t kRefillDefault = 28;    /* idle lanes that trigger a refill */
+constexpr uint32_t kRefillDefault = 20;    /* idle lanes that trigger a refill (re-swept for the 4-wide kernel: profiles/r01/sweep_trace_wide.log) */
 
 /* Stack policy of the persistent kernel.  Ordered traversal rarely holds more than ~10 entries, so every lane gets 16
  * LDS entries (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum; the depth-bound 32-entry
@@ -771,7 +771,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
     static const uint32_t kBatchProd = env_u32("RTR_TRACE_BATCH_PROD", kBatch, 64u, 1u << 20);
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
-    static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 20u, 0u, 63u);
+    static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 28u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
     if (stats) hipLaunchKernelGGL((k_shadow_trace_count<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
     else {
