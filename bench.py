@@ -224,6 +224,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not warm-up: every frame object allocates its scratch (ray queue, hit records ...) on its first render; with
+    # fewer warm-up steps than frames in flight that first render — a few synchronous hipMallocs — would land in the timed region
+    for b in range(nbuf):
+        render_step(frames[b], 0, p_run, False)
     for i in range(args.warmup):
         step(i)
     drain()
