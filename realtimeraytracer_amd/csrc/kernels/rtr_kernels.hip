@@ -768,8 +768,8 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
+    /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
-    static const uint32_t kBatchProd = env_u32("RTR_TRACE_BATCH_PROD", kBatch, 64u, 1u << 20);
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 28u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
@@ -777,8 +777,8 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     else {
         /* the 4-wide kernel is the production path; RTR_TRACE_BVH4=0 selects the 2-wide one (same results, for comparison) */
         static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);
-        if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatchProd, kRefill, kInnerMin, ws.overflow);
-        else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatchProd, kRefill, kInnerMin, ws.overflow);
+        if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
+        else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
         hipLaunchKernelGGL(k_shadow_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill);
     }
     if (ev) hipEventRecord(ev[3], s);
