@@ -162,10 +162,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArgs ra, const float4* hitTuvp,
-                                                       const uint32_t* hitCustom, float4* queue, uint32_t* count) {
-    __shared__ uint32_t s_off[kBlock / 64];
-    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+/* 1024-thread workgroups (16 waves): the queue is reserved once per workgroup, see below; planeStride = the sample-plane stride
+ * of the hit records k_primary wrote (its grid x 256). */
+constexpr uint32_t kGenBlock = 1024;
+__global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, RenderArgs ra, const float4* hitTuvp,
+                                                          const uint32_t* hitCustom, float4* queue, uint32_t* count, uint32_t planeStride) {
+    __shared__ uint32_t s_off[kGenBlock / 64], s_tot[kGenBlock / 64], s_base;
+    const uint32_t q = blockIdx.x * kGenBlock + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t px = 0, lrow = 0, py = 0;
     const bool live = pixel_of(ra, q, px, lrow, py);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
     if (live) {
         CountPolicy cp{0};
         for (uint32_t i = 0; i < ra.spp; ++i) {
-            const size_t k = (size_t)i * gridDim.x * kBlock + q;
+            const size_t k = (size_t)i * planeStride + q;
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
@@ -191,18 +194,24 @@ __global__ __launch_bounds__(kBlock) void k_shadow_gen(DeviceScene sc, RenderArg
         }
         n = cp.n;
     }
-    /* one reservation per wave (all 64 lanes take part in the reduction) */
+    /* ONE reservation per workgroup: the sixteen waves add up their totals in LDS and lane 0 does the atomic.  A single
+     * address sustains ~88 atomics/us, so one per wave (32 400 at 1080p) cost 0.37 of this kernel's 0.41 ms; one per
+     * 1024-thread workgroup is 2 025.  (Every thread of the block reaches both barriers: padding lanes are not retired early.) */
     const uint32_t total = wave_sum(n);
-    uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0) {
-        if (total) base = atomicAdd(count, total);
-        s_off[wave] = 0;
+    if ((threadIdx.x & 63u) == 0) { s_tot[wave] = total; s_off[wave] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < kGenBlock / 64; ++w) t += s_tot[w];
+        s_base = t ? atomicAdd(count, t) : 0u;
     }
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wave; ++w) base += s_tot[w];
     if (!live || n == 0) return;
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
-        const size_t k = (size_t)i * gridDim.x * kBlock + q;
+        const size_t k = (size_t)i * planeStride + q;
         EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
         if (single) {
             if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
@@ -759,7 +768,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
         hipLaunchKernelGGL(k_primary_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, blocks * kBlock);
     }
     if (ev) hipEventRecord(ev[1], s);
-    hipLaunchKernelGGL(k_shadow_gen, dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount);
+    hipLaunchKernelGGL(k_shadow_gen, dim3((blocks * kBlock + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
     /* persistent waves: as many workgroups as stay resident (16 KiB of LDS stack per workgroup -> 8 per CU, the
      * 32-wave hardware maximum), each pulling batches until the queue is empty */
