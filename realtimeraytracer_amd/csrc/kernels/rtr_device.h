@@ -152,6 +152,39 @@ __device__ __forceinline__ bool slab_pair(uint32_t wmin, uint32_t wmax, uint32_t
     return lo <= hi * RTR_BOX_WIDEN;
 }
 
+/* The same test when the signs of the ray's direction are known at compile time (OCT bit a = ga.a < 0): q -> q * ga + gb is
+ * monotone, so the entry plane of an axis is the box's min plane for ga >= 0 and its max plane otherwise, and min(t0, t1) /
+ * max(t0, t1) ARE those two values — the six per-axis min/max disappear, the result is bit-identical (boxes have
+ * qmin <= qmax on every axis: rtr_quant_lo/hi; tests/test_gpu_bvh.py checks the exported tree). */
+template <int OCT>
+__device__ __forceinline__ bool slab_oct(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gb,
+                                         float tmin, float tmax, float& t_entry) {
+    const rtr_f2 axy = {ga.x, ga.y}, bxy = {gb.x, gb.y}, az = {ga.z, ga.z}, bz = {gb.z, gb.z};
+    const rtr_f2 t0 = __builtin_elementwise_fma(rtr_f2{(float)(wmin & 0xffffu), (float)(wmin >> 16)}, axy, bxy);
+    const rtr_f2 t1 = __builtin_elementwise_fma(rtr_f2{(float)(wmax & 0xffffu), (float)(wmax >> 16)}, axy, bxy);
+    const rtr_f2 tz = __builtin_elementwise_fma(rtr_f2{(float)(wz & 0xffffu), (float)(wz >> 16)}, az, bz);
+    const float nx = (OCT & 1) ? t1.x : t0.x, fx = (OCT & 1) ? t0.x : t1.x;
+    const float ny = (OCT & 2) ? t1.y : t0.y, fy = (OCT & 2) ? t0.y : t1.y;
+    const float nz = (OCT & 4) ? tz.y : tz.x, fz = (OCT & 4) ? tz.x : tz.y;
+    const float lo = rtr_hwmax(rtr_hwmax(nx, ny), rtr_hwmax(nz, tmin));
+    const float hi = rtr_hwmin(rtr_hwmin(fx, fy), rtr_hwmin(fz, tmax));
+    t_entry = lo;
+    return lo <= hi * RTR_BOX_WIDEN;
+}
+template <>
+__device__ __forceinline__ bool slab_oct<8>(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gb,
+                                            float tmin, float tmax, float& t_entry) {
+    return slab_pair(wmin, wmax, wz, ga, gb, tmin, tmax, t_entry);       /* 8 = signs differ between the lanes of the wave */
+}
+
+/* Direction signs of a ray as trace() will see them (bit a = the grid-space slope of axis a is negative). */
+__device__ __forceinline__ uint32_t ray_octant(const DeviceScene& sc, rtr_v3 o, rtr_v3 d) {
+    const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+    rtr_v3 ga, gb;
+    rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
+    return (ga.x < 0.f ? 1u : 0u) | (ga.y < 0.f ? 2u : 0u) | (ga.z < 0.f ? 4u : 0u);
+}
+
 /* ------------------------------------------------------------------------------------------
  * BVH traversal.  Restates, operation for operation, the algorithm of oracle/oracle_render.cpp
  * trace_bvh(): ordered descent (near child first, ties -> left), far child pushed, box culled iff
@@ -162,7 +195,8 @@ __device__ __forceinline__ bool slab_pair(uint32_t wmin, uint32_t wmax, uint32_t
 /* LIMIT > 0: the stack holds only LIMIT entries; a ray that needs more is abandoned with best.custom = RTR_STACK_OVERFLOW (the
  * caller re-traces it with a full-depth stack), so the common case can run with a small LDS footprint. */
 #define RTR_STACK_OVERFLOW 0xfffffffeu
-template <bool ANY, bool STATS, int BLOCK, int LIMIT = 0>
+/* OCT 0..7: every lane that calls has these direction signs (slab_oct); 8 = any. */
+template <bool ANY, bool STATS, int BLOCK, int LIMIT = 0, int OCT = 8>
 __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict__ stack,
                                       rtr_v3 o, rtr_v3 d, float tmin, float tmax, HitRec& best, LocalStats& st) {
     if (STATS) { st.rays++; if (ANY) st.shadow++; else st.primary++; }
@@ -187,8 +221,8 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
             const int2 ch = make_int2((int)b.z, (int)b.w);
             if (STATS) { st.nodes++; if (ANY) st.shadowNodes++; }
             float tl, tr;
-            const bool hl = slab_pair(a.x, a.y, b.x, ga, gb, tmin, limit, tl);
-            const bool hr = slab_pair(a.z, a.w, b.y, ga, gb, tmin, limit, tr);
+            const bool hl = slab_oct<OCT>(a.x, a.y, b.x, ga, gb, tmin, limit, tl);
+            const bool hr = slab_oct<OCT>(a.z, a.w, b.y, ga, gb, tmin, limit, tr);
             if (hl && hr) {
                 const bool swap = tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;

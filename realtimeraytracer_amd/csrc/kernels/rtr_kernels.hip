@@ -124,7 +124,23 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const rtr_v3 dir = primary_dir(ra, px, py, i);
         HitRec h;
-        trace<false, STATS, kBlock, STATS ? 0 : 16>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
+        if (STATS) trace<false, STATS, kBlock, 0>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
+        else {
+            /* camera rays of one 8x8 tile nearly always share their direction signs: run the traversal compiled for that octant */
+            const uint32_t oct = ray_octant(sc, camPos, dir);
+            const uint32_t woct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
+            switch (__ballot(oct != woct) != 0ull ? 8u : woct) {
+                case 0: trace<false, false, kBlock, 16, 0>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 1: trace<false, false, kBlock, 16, 1>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 2: trace<false, false, kBlock, 16, 2>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 3: trace<false, false, kBlock, 16, 3>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 4: trace<false, false, kBlock, 16, 4>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 5: trace<false, false, kBlock, 16, 5>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 6: trace<false, false, kBlock, 16, 6>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                case 7: trace<false, false, kBlock, 16, 7>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+                default: trace<false, false, kBlock, 16, 8>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            }
+        }
         /* sample-major planes keep each store of a wave contiguous */
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
         if (!STATS && h.custom == RTR_STACK_OVERFLOW) { redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k; continue; }
@@ -518,14 +534,57 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     }
 }
 
+/* The inner-node loop of k_shadow_trace4, compiled per direction octant (OCT 0..7; 8 = any signs, see slab_oct). */
+template <int STACK, int OCT>
+__device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, int32_t* lds, int32_t& cur, int& sp, uint32_t& res,
+                                             const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (;;) {
+        const unsigned long long innerMask = __ballot(cur >= 0);
+        if (innerMask == 0ull) break;
+        if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
+        if (cur >= 0) {
+            const int32_t nodeOff = cur << 6;                   /* one 64-B four-wide node = the whole visit */
+            const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, 0);
+            const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, 0);
+            const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, 0);
+            const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, 0);
+            const int32_t top = lds[sp * kBlock];              /* speculative: hides the pop's LDS latency under the node loads */
+            const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
+            float t0, t1, t2, t3;
+            const bool h0 = slab_oct<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);            /* slot 0 is never empty */
+            const bool h1 = slab_oct<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmax, t1);
+            const bool h2 = slab_oct<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmax, t2) && c2 != kDone;
+            const bool h3 = slab_oct<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmax, t3) && c3 != kDone;
+            /* descend into the nearest child that is hit; the others go on the stack in slot order.  (Ordering them too —
+             * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
+             * 2.15 / 2.22 ms against 2.05.) */
+            int32_t next = kDone;
+            bool ovf = false;
+            float tn = 3.0e38f;
+            if (h0) { tn = t0; next = c0; }
+            if (h1 && t1 < tn) { tn = t1; next = c1; }
+            if (h2 && t2 < tn) { tn = t2; next = c2; }
+            if (h3 && t3 < tn) { tn = t3; next = c3; }
+            if (h0 && c0 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c0; } else ovf = true; }
+            if (h1 && c1 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c1; } else ovf = true; }
+            if (h2 && c2 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c2; } else ovf = true; }
+            if (h3 && c3 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c3; } else ovf = true; }
+            if (ovf) { res = 2u; next = kDone; }                 /* needs more than the LDS stack: the tail kernel redoes this ray */
+            if (next == kDone && !ovf) { next = top; --sp; }    /* nothing hit: pop (slot 0 holds kDone) */
+            cur = next;
+        }
+    }
+}
+
 /* The same kernel over the 4-wide view of the tree (DeviceScene::nodes4, built by k_wide_nodes): a visit is one 64-B record
  * (four loads issued together) holding up to four child boxes, so a ray makes about half as many DEPENDENT visits; the
  * instruction and look-up totals stay about the same.  2.17 -> 2.05 ms on the bench frame; identical visibility bits. */
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
-                                                              uint32_t kInnerMin, uint32_t* overflow) {
+                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms) {
     __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
@@ -602,41 +661,26 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace4(DeviceScene sc, const 
             if (exhausted) break;                /* every lane is idle and was retired above (nIdle == 64) */
             continue;
         }
-        /* ---- inner nodes ("while-while" with an early exit, see k_shadow_trace_count) ---- */
-        for (;;) {
-            const unsigned long long innerMask = __ballot(cur >= 0);
-            if (innerMask == 0ull) break;
-            if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
-            if (cur >= 0) {
-                const int32_t nodeOff = cur << 6;                   /* one 64-B four-wide node = the whole visit */
-                const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, 0);
-                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, 0);
-                const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, 0);
-                const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, 0);
-                const int32_t top = lds[sp * kBlock];              /* speculative: hides the pop's LDS latency under the node loads */
-                const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
-                float t0, t1, t2, t3;
-                const bool h0 = slab_pair(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);            /* slot 0 is never empty */
-                const bool h1 = slab_pair(q0.w, q1.x, q1.y, ga, gb, tmin, tmax, t1);
-                const bool h2 = slab_pair(q1.z, q1.w, q2.x, ga, gb, tmin, tmax, t2) && c2 != kDone;
-                const bool h3 = slab_pair(q2.y, q2.z, q2.w, ga, gb, tmin, tmax, t3) && c3 != kDone;
-                /* descend into the nearest child that is hit; the others go on the stack in slot order.  (Ordering them too —
-                 * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
-                 * 2.15 / 2.22 ms against 2.05.) */
-                int32_t next = kDone;
-                bool ovf = false;
-                float tn = 3.0e38f;
-                if (h0) { tn = t0; next = c0; }
-                if (h1 && t1 < tn) { tn = t1; next = c1; }
-                if (h2 && t2 < tn) { tn = t2; next = c2; }
-                if (h3 && t3 < tn) { tn = t3; next = c3; }
-                if (h0 && c0 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c0; } else ovf = true; }
-                if (h1 && c1 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c1; } else ovf = true; }
-                if (h2 && c2 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c2; } else ovf = true; }
-                if (h3 && c3 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c3; } else ovf = true; }
-                if (ovf) { res = 2u; next = kDone; }                 /* needs more than the LDS stack: the tail kernel redoes this ray */
-                if (next == kDone && !ovf) { next = top; --sp; }    /* nothing hit: pop (slot 0 holds kDone) */
-                cur = next;
+        /* ---- inner nodes ("while-while" with an early exit, see k_shadow_trace_count) ----
+         * When every lane that is at an inner node has the same direction signs (usual: a wave's rays are neighbouring pixels
+         * aimed at the same light triangle), the loop runs in the form compiled for that octant, without the per-axis min/max. */
+        {
+            const unsigned long long innerNow = __ballot(cur >= 0);
+            if (innerNow != 0ull) {
+                const uint32_t oct = (ga.x < 0.f ? 1u : 0u) | (ga.y < 0.f ? 2u : 0u) | (ga.z < 0.f ? 4u : 0u);
+                const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
+                const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
+                switch ((mixed || octForms == 0u) ? 8u : woct) {
+                    case 0: inner_nodes4<STACK, 0>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 1: inner_nodes4<STACK, 1>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 2: inner_nodes4<STACK, 2>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 3: inner_nodes4<STACK, 3>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 4: inner_nodes4<STACK, 4>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 5: inner_nodes4<STACK, 5>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 6: inner_nodes4<STACK, 6>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    case 7: inner_nodes4<STACK, 7>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                    default: inner_nodes4<STACK, 8>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin); break;
+                }
             }
         }
         /* ---- leaves ---- */
@@ -786,7 +830,8 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     else {
         /* the 4-wide kernel is the production path; RTR_TRACE_BVH4=0 selects the 2-wide one (same results, for comparison) */
         static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);
-        if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
+        static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u);
+        if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct);
         else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
         hipLaunchKernelGGL(k_shadow_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill);
     }
