@@ -59,7 +59,19 @@ def _soup(seed, directory):
     return obj, directory + "/", cam, lights
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def _seeds():
+    """RTR_FUZZ_SEEDS="100-180" (or "3,9,27") runs a soak over other seeds; the default eight are the committed regression set."""
+    spec = os.environ.get("RTR_FUZZ_SEEDS", "")
+    if not spec:
+        return [1, 2, 3, 4, 5, 6, 7, 8]
+    out = []
+    for part in spec.split(","):
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_soup_parity(gpu_ctx, oracle, tmp_path, seed):
     W, H = 160, 96
     obj, mtldir, cam, lights = _soup(seed, str(tmp_path))
@@ -78,7 +90,8 @@ def test_random_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             assert np.array_equal(got, ref.images[A.IMAGE_SHADOWED]), (seed, flags, pipeline, int((got != ref.images[A.IMAGE_SHADOWED]).sum()))
             g = frame.stats()
             assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits), (seed, flags, pipeline)
-            assert g.numHits > 20, (seed, g.numHits)                    # the soup is actually in view
+            if not os.environ.get("RTR_FUZZ_SEEDS"):
+                assert g.numHits > 20, (seed, g.numHits)                # the committed seeds have the soup in view
             # the production (non-counting) kernels produce the same picture
             p0 = api.make_params(W, H, spp=2, pipeline=pipeline)
             api.render(scene, s.camera, s.scene_info(seed), p0, frame)
