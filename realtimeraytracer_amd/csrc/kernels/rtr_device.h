@@ -155,7 +155,7 @@ __device__ __forceinline__ bool slab_pair(uint32_t wmin, uint32_t wmax, uint32_t
 /* The same test when the signs of the ray's direction are known at compile time (OCT bit a = ga.a < 0): q -> q * ga + gb is
  * monotone, so the entry plane of an axis is the box's min plane for ga >= 0 and its max plane otherwise, and min(t0, t1) /
  * max(t0, t1) ARE those two values — the six per-axis min/max disappear, the result is bit-identical (boxes have
- * qmin <= qmax on every axis: rtr_quant_lo/hi; tests/test_gpu_bvh.py checks the exported tree). */
+ * qmin <= qmax on every axis: rtr_quant_lo/hi; tests/test_oracle_bvh.py::_check_bvh asserts it on host- and device-built and re-fitted trees). */
 template <int OCT>
 __device__ __forceinline__ bool slab_oct(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gb,
                                          float tmin, float tmax, float& t_entry) {

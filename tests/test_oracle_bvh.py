@@ -52,6 +52,9 @@ def _check_bvh(desc, st, nodes, tris, grid=None):
     n_tri = st.numTriangles
     assert st.bvhLayoutVersion == 3 and C.sizeof(A.RtrBvhNode) == 32
     nd = _decode_boxes(nodes, grid if grid is not None else st.grid)
+    # every stored box has min <= max on every axis: the octant forms of the slab test (slab_oct) read the entry plane straight
+    # from the direction sign instead of taking min/max of the two plane distances
+    assert (nd[:, :, 0, :] <= nd[:, :, 1, :]).all()
     ch = np.frombuffer(nodes, dtype=np.int32).reshape(-1, 8)[:, 6:8]
     tr = np.frombuffer(tris, dtype=np.float32).reshape(-1, 12)
     ids = np.frombuffer(tris, dtype=np.uint32).reshape(-1, 12)
