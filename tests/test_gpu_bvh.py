@@ -2,6 +2,7 @@
 with the host-SAH tree (results do not depend on the tree), oracle parity with the device-built tree, and refit after
 instance transforms change (TLAS::updateTransform/refit counterpart)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -105,6 +106,70 @@ def test_refit_matches_fresh_build(gpu_ctx, oracle, scene_cache, flags):
     # refit back to the original transforms restores the original image bit for bit
     scene.update_instances(s.host.instances(), s.host.lightInfos())
     assert np.array_equal(_render(gpu_ctx, scene, s, p).download(), before)
+
+
+def _refit_seeds():
+    spec = os.environ.get("RTR_FUZZ_SEEDS", "")
+    if not spec:
+        return [11, 12, 13, 14]
+    out = []
+    for part in spec.split(","):
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+@pytest.mark.parametrize("seed", _refit_seeds())
+def test_refit_random_affine_transforms(gpu_ctx, oracle, scene_cache, seed):
+    """Every instance (lights included) gets a random affine transform — rotation, non-uniform scale, shear, mirroring, moves far
+    outside the old bounds (the quantisation grid must follow) — by refit; the image must equal a fresh build's and the
+    oracle's brute-force loop, for both kinds of tree."""
+    rng = np.random.default_rng(seed)
+    W, H = 192, 120
+    s = scenes.cornell_box(W, H)
+    base = [A.RtrInstance.from_buffer_copy(bytes(i)) for i in s.host.instances()]
+    base_l = [A.RtrAreaLightInfo.from_buffer_copy(bytes(l)) for l in s.host.lightInfos()]
+    centre = np.array([278.0, 273.0, 280.0])
+    inst, lights = [], [A.RtrAreaLightInfo.from_buffer_copy(bytes(l)) for l in base_l]
+    for k, b in enumerate(base):
+        m = np.array(b.transform[:], np.float64).reshape(3, 4)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        lin = q @ np.diag(rng.uniform(0.3, 1.8, 3) * rng.choice([1.0, 1.0, 1.0, -1.0], 3))
+        if rng.random() < 0.3:
+            lin = lin + np.triu(rng.normal(0, 0.3, (3, 3)), 1)                       # shear
+        if k < len(base_l):
+            lin = np.eye(3) * rng.uniform(0.6, 1.5)                                  # lights: keep them facing the room
+        move = rng.normal(0, 60, 3) + (rng.normal(0, 900, 3) if rng.random() < 0.15 else 0)
+        a = np.eye(4); a[:3, :3] = lin; a[:3, 3] = centre - lin @ centre + move      # about the room centre, then moved
+        full = np.eye(4); full[:3, :] = m
+        out = (a @ full)[:3, :].astype(np.float32)
+        i2 = A.RtrInstance.from_buffer_copy(bytes(b))
+        for j, v in enumerate(out.reshape(-1)):
+            i2.transform[j] = float(v)
+        inst.append(i2)
+        if k < len(base_l):
+            cm = np.zeros((4, 4), np.float32); cm[:3, :] = out; cm[3, 3] = 1
+            for j, v in enumerate(cm.T.reshape(-1)):
+                lights[k].transform[j] = float(v)
+    d2 = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc))
+    iarr = (A.RtrInstance * len(inst))(*inst)
+    larr = (A.RtrAreaLightInfo * len(lights))(*lights)
+    d2.instances = C.cast(iarr, C.POINTER(A.RtrInstance))
+    d2.lights = C.cast(larr, C.POINTER(A.RtrAreaLightInfo))
+    p = api.make_params(W, H, spp=1, collect_stats=1)
+    brute = oracle.render(d2, s.camera, s.scene_info(seed), p, bvh=None, threads=8).images[A.IMAGE_SHADOWED]
+    for flags in (A.BUILD_HOST_SAH, A.BUILD_DEVICE_LBVH):
+        scene = api.Scene(gpu_ctx, _with_flags(s.desc, flags))
+        scene.update_instances(inst, lights)
+        img = _render(gpu_ctx, scene, s, p, frame_no=seed).download()
+        nodes, tris, grid = scene.export_bvh()
+        _check_bvh(d2, scene.stats(), nodes, tris, grid)
+        assert np.array_equal(img, brute), (seed, flags, int((img != brute).sum()))
+        fresh = api.Scene(gpu_ctx, _with_flags(d2, flags))
+        assert np.array_equal(_render(gpu_ctx, fresh, s, p, frame_no=seed).download(), img), (seed, flags)
+        p0 = api.make_params(W, H, spp=1)
+        assert np.array_equal(_render(gpu_ctx, scene, s, p0, frame_no=seed).download(), img), (seed, flags, "production kernels")
+        scene.close(); fresh.close()
 
 
 def test_update_instances_rejects_topology_changes(gpu_ctx, scene_cache):
