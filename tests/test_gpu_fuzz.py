@@ -101,3 +101,95 @@ def test_random_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             assert np.array_equal(ref.images[A.IMAGE_SHADOWED], ref_brute), (seed, flags, "oracle BVH vs brute force")
             frame.close()
         scene.close()
+
+
+def _textured_soup(seed, directory):
+    """Random triangles with random uvs (negative, far outside [0,1]) over materials with random texture maps: map_Kd, map_Ks
+    (R8), map_Pm, map_d (alpha cut-out in the any-hit test), odd texture sizes (1x1, 1xN, non powers of two), optional .hdr sky."""
+    rng = np.random.default_rng(seed)
+    tdir = os.path.join(directory, f"tex_{seed}")
+    os.makedirs(tdir, exist_ok=True)
+
+    def tex(name, channels):
+        h, w = [int(x) for x in rng.choice([1, 2, 3, 5, 8, 17, 32, 61], 2)]
+        a = rng.integers(0, 256, (h, w, channels), dtype=np.uint8)
+        if channels == 4 or name.startswith("op"):
+            blocks = rng.random((h, w)) < 0.55                  # opacity.rahit reads .r: >= 0.9 keeps the hit
+            a[..., 0] = np.where(blocks, 255, rng.integers(0, 229, (h, w)))
+        scenes.write_png(os.path.join(tdir, name), a[..., 0] if channels == 1 else a)
+        return f"tex_{seed}/{name}"
+
+    mtl = []
+    nmat = int(rng.integers(2, 6))
+    for k in range(nmat):
+        kd, ks = rng.random(3) * 0.9 + 0.05, float(rng.random() * 0.8)
+        lines = [f"newmtl m{k}", "Kd %r %r %r" % tuple(float(x) for x in kd), f"Ks {ks!r} {ks!r} {ks!r}"]
+        if rng.random() < 0.5: lines.append(f"metallic {float(rng.random())!r}")
+        if rng.random() < 0.7: lines.append("map_Kd " + tex(f"kd{k}.png", int(rng.choice([3, 4]))))
+        if rng.random() < 0.4: lines.append("map_Ks " + tex(f"ks{k}.png", 1))
+        if rng.random() < 0.4: lines.append("map_Pm " + tex(f"pm{k}.png", 1))
+        if rng.random() < 0.5: lines.append("map_d " + tex(f"op{k}.png", int(rng.choice([1, 3, 4]))))
+        mtl.append("\n".join(lines) + "\n\n")
+    with open(os.path.join(directory, f"tsoup_{seed}.mtl"), "w") as f:
+        f.write("".join(mtl))
+    o = [f"mtllib tsoup_{seed}.mtl\n"]
+    for s in range(int(rng.integers(2, 7))):
+        n = int(rng.integers(1, 120))
+        centre = rng.normal(0, 50, 3)
+        size = float(rng.choice([6, 25, 90]))
+        a = centre + rng.normal(0, 35, (n, 3)); b = a + rng.normal(0, size, (n, 3)); c = a + rng.normal(0, size, (n, 3))
+        uv = rng.normal(0, float(rng.choice([0.5, 3.0, 40.0])), (n, 3, 2))
+        fn = np.cross(b - a, c - a); fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-12)
+        o.append(f"o s{s}\nusemtl m{int(rng.integers(0, nmat))}\n")
+        for i in range(n):
+            for p_, t_ in zip((a[i], b[i], c[i]), uv[i]):
+                o.append("v %r %r %r\nvt %r %r\n" % (float(p_[0]), float(p_[1]), float(p_[2]), float(t_[0]), float(t_[1])))
+            o.append("vn %r %r %r\nf -3/-3/-1 -2/-2/-1 -1/-1/-1\n" % tuple(float(x) for x in fn[i]))
+    obj = os.path.join(directory, f"tsoup_{seed}.obj")
+    with open(obj, "w") as f:
+        f.write("".join(o))
+    sky = None
+    if rng.random() < 0.5:
+        sky = os.path.join(directory, f"sky_{seed}.hdr")
+        scenes.write_hdr(sky, (rng.random((int(rng.integers(1, 24)), int(rng.integers(1, 40)), 3)) * 3.0).astype(np.float32))
+    lights = [(float(rng.uniform(2, 9)), tuple(rng.random(3) * 0.8 + 0.2), tuple(rng.normal(0, 70, 3)), tuple(rng.uniform(20, 120, 3)),
+               tuple(rng.uniform(0, 180, 3))) for _ in range(int(rng.integers(1, 3)))]
+    cam = tuple(rng.normal(0, 1, 3) * 230.0)
+    return obj, directory + "/", cam, lights, sky
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_textured_soup_parity(gpu_ctx, oracle, tmp_path, seed):
+    from realtimeraytracer_amd import host
+    W, H = 144, 88
+    obj, mtldir, cam, lights, sky = _textured_soup(seed, str(tmp_path))
+    hs = host.HostScene()
+    for (intensity, color, move, scale, rotate) in lights:
+        hs.addAreaLight(intensity, color, bool(seed & 1)).move(move).scale(scale).rotate(rotate)
+    hs.addObjMtlPair(obj, mtldir)
+    hs.setSky((0.5, 0.7, 1.0))
+    if sky:
+        hs.setHDRI(sky)
+    hs.build()
+    s = scenes.SceneSetup(f"tsoup_{seed}", hs, host.Camera(60.0, cam, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), W, H), cam, W, H)
+    brute = None
+    for flags in (A.BUILD_HOST_SAH, A.BUILD_DEVICE_LBVH):
+        d = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc)); d.buildFlags = flags
+        scene = api.Scene(gpu_ctx, d)
+        bvh = scene.export_bvh()
+        for pipeline in (1, 2):
+            p = api.make_params(W, H, spp=2, collect_stats=1, pipeline=pipeline)
+            frame = api.Frame(gpu_ctx, W, H)
+            api.render(scene, s.camera, s.scene_info(seed), p, frame)
+            ref = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, threads=8)
+            got = frame.download()
+            assert np.array_equal(got, ref.images[A.IMAGE_SHADOWED]), (seed, flags, pipeline, int((got != ref.images[A.IMAGE_SHADOWED]).sum()))
+            g = frame.stats()
+            assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits), (seed, flags, pipeline)
+            api.render(scene, s.camera, s.scene_info(seed), api.make_params(W, H, spp=2, pipeline=pipeline), frame)
+            assert np.array_equal(frame.download(), got), (seed, flags, pipeline, "counting vs production kernels")
+            if brute is None:
+                brute = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=None, threads=8).images[A.IMAGE_SHADOWED]
+            assert np.array_equal(ref.images[A.IMAGE_SHADOWED], brute), (seed, flags, "oracle BVH vs brute force")
+            frame.close()
+        scene.close()
