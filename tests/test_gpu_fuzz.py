@@ -170,6 +170,7 @@ def test_random_textured_soup_parity(gpu_ctx, oracle, tmp_path, seed):
     hs.setSky((0.5, 0.7, 1.0))
     if sky:
         hs.setHDRI(sky)
+    hs.setLTC(*scenes.synthetic_ltc())
     hs.build()
     s = scenes.SceneSetup(f"tsoup_{seed}", hs, host.Camera(60.0, cam, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), W, H), cam, W, H)
     brute = None
@@ -193,3 +194,22 @@ def test_random_textured_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             assert np.array_equal(ref.images[A.IMAGE_SHADOWED], brute), (seed, flags, "oracle BVH vs brute force")
             frame.close()
         scene.close()
+    # all five ray-gen images + the float HDR buffer (analytic through synthetic LTC tables), then the denoise/combine chain
+    all8 = 0xff
+    images = A.IMAGES_RAYGEN5 | A.IMG_BIT(A.IMAGE_HDR)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    frame = api.Frame(gpu_ctx, W, H, all8 | A.IMG_BIT(A.IMAGE_HDR))
+    p = api.make_params(W, H, spp=2, images=images, pipeline=1 + (seed & 1))
+    api.render(scene, s.camera, s.scene_info(seed), p, frame)
+    ref = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, images=images, threads=8)
+    src = {}
+    for which in (0, 1, 2, 6, 7):
+        src[which] = frame.download(which)
+        assert np.array_equal(src[which], ref.images[which]), (seed, "image", which, int((src[which] != ref.images[which]).sum()))
+    assert np.array_equal(frame.download(A.IMAGE_HDR).view(np.uint32), ref.hdr.view(np.uint32)), (seed, "HDR bits")
+    frame.denoise_combine(4)
+    dref = oracle.denoise_combine(src[0], src[1], src[2], src[6], src[7], iterations=4)
+    for which in (A.IMAGE_SHADOWED, A.IMAGE_UNSHADOWED, A.IMAGE_DENOISED_SHADOWED, A.IMAGE_DENOISED_UNSHADOWED, A.IMAGE_FINAL):
+        assert np.array_equal(frame.download(which), dref[which]), (seed, "denoise/combine image", which)
+    frame.close(); scene.close()
