@@ -33,6 +33,8 @@ struct DeviceScene {
     const uint32_t* indices;
     const RtrObjectInfo* objects;
     const RtrAreaLightInfo* lights;
+    const float4* lightTris;         /* per light triangle, 4 x float4: {P0, area} {P1, pdf} {P2, -} {unit normal, -} in world space (k_light_tris) */
+    const uint32_t* lightTriFirst;   /* first record of light l */
     const float* xforms;             /* 12 floats (3x4 row-major object->world) per customIndex */
     const float* nmats;              /* 12 floats (9 used: transpose(inverse(mat3))) per customIndex */
     const float* ltc1;               /* 64x64x4 or null */
@@ -517,21 +519,18 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
         if (STATS) st.lightFetch++;
         const rtr_v3 lcol = rtr_ld3(L->color);
         const float lintensity = L->intensity;
-        const uint32_t lvOff = L->vertexOffset, liOff = L->indexOffset, lnt = L->numTriangles;
+        const uint32_t lnt = L->numTriangles;
         const bool twoSided = L->isTwoSided != 0u;
         for (uint32_t ti = 0; ti < lnt; ++ti) {                                           /* :172 */
             if (STATS) st.lightTriFetch++;
-            const uint32_t j0 = sc.indices[ti * 3u + 0u + liOff];
-            const uint32_t j1 = sc.indices[ti * 3u + 1u + liOff];
-            const uint32_t j2 = sc.indices[ti * 3u + 2u + liOff];
+            /* corners, area, pdf and normal of the light triangle are the same for every pixel: k_light_tris computed them once
+             * (raygen.rgen:174-196, same operations) and the addresses are wave-uniform, so these are scalar loads */
+            const float4* rec = sc.lightTris + (size_t)(sc.lightTriFirst[li] + ti) * 4u;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             rtr_v3 P[3];
-            P[0] = rtr_xform_point44cm(L->transform, rtr_ld3(sc.vertices[j0 + lvOff].position));
-            P[1] = rtr_xform_point44cm(L->transform, rtr_ld3(sc.vertices[j1 + lvOff].position));
-            P[2] = rtr_xform_point44cm(L->transform, rtr_ld3(sc.vertices[j2 + lvOff].position));
-            rtr_v3 lightNormal = rtr_cross(rtr_sub(P[2], P[1]), rtr_sub(P[0], P[1]));
-            const float area = rtr_length(lightNormal) * 0.5f;
-            const float pdf = 1.0f / (area * 0.7f);
-            lightNormal = rtr_normalize(lightNormal);
+            P[0] = rtr_mk(r0.x, r0.y, r0.z); P[1] = rtr_mk(r1.x, r1.y, r1.z); P[2] = rtr_mk(r2.x, r2.y, r2.z);
+            const float pdf = r1.w;
+            const rtr_v3 lightNormal = rtr_mk(r3.x, r3.y, r3.z);
             if (!twoSided) {
                 if (rtr_dot(lightNormal, rtr_sub(hitPoint, P[0])) < 0.0f) continue;
             }
@@ -616,6 +615,27 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
         o.unshadowed = rtr_add(o.unshadowed, contrib);
         o.analytic = rtr_add(o.analytic, contrib);
     }
+}
+
+/* The per-light-triangle part of raygen.rgen:174-196, hoisted out of the pixel loops (see light_loops). */
+__device__ __forceinline__ void light_tri_record(const RtrAreaLightInfo* L, const RtrVertex* vertices, const uint32_t* indices,
+                                                 uint32_t ti, float4* rec) {
+    const uint32_t lvOff = L->vertexOffset, liOff = L->indexOffset;
+    const uint32_t j0 = indices[ti * 3u + 0u + liOff];
+    const uint32_t j1 = indices[ti * 3u + 1u + liOff];
+    const uint32_t j2 = indices[ti * 3u + 2u + liOff];
+    rtr_v3 P[3];
+    P[0] = rtr_xform_point44cm(L->transform, rtr_ld3(vertices[j0 + lvOff].position));
+    P[1] = rtr_xform_point44cm(L->transform, rtr_ld3(vertices[j1 + lvOff].position));
+    P[2] = rtr_xform_point44cm(L->transform, rtr_ld3(vertices[j2 + lvOff].position));
+    rtr_v3 lightNormal = rtr_cross(rtr_sub(P[2], P[1]), rtr_sub(P[0], P[1]));
+    const float area = rtr_length(lightNormal) * 0.5f;
+    const float pdf = 1.0f / (area * 0.7f);
+    lightNormal = rtr_normalize(lightNormal);
+    rec[0] = make_float4(P[0].x, P[0].y, P[0].z, area);
+    rec[1] = make_float4(P[1].x, P[1].y, P[1].z, pdf);
+    rec[2] = make_float4(P[2].x, P[2].y, P[2].z, 0.f);
+    rec[3] = make_float4(lightNormal.x, lightNormal.y, lightNormal.z, 0.f);
 }
 
 /* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110, miss.rmiss:15-27). */

@@ -30,6 +30,9 @@ hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const 
 hipError_t launch_wavefront(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, const Workspace& ws,
                             int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev);
 
+/* fills DeviceScene::lightTris (4 x float4 per light triangle, light l from first[l]); after create and after light transforms change */
+hipError_t launch_light_tris(const RtrAreaLightInfo* lights, const RtrVertex* vertices, const uint32_t* indices, const uint32_t* first,
+                             uint32_t numLights, float4* out, hipStream_t stream);
 hipError_t launch_deinterleave(const uint32_t* gathered, uint32_t* dst, uint32_t width, uint32_t height,
                                uint32_t bandRows, uint32_t shardCount, uint32_t localRows, hipStream_t stream);
 

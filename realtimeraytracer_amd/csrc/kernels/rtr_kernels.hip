@@ -765,6 +765,16 @@ __global__ __launch_bounds__(kBlock) void k_deinterleave(const uint32_t* __restr
     }
 }
 
+/* One lane per light: the world-space corners, area, pdf and unit normal of its triangles (read by light_loops in every pixel). */
+__global__ __launch_bounds__(64) void k_light_tris(const RtrAreaLightInfo* __restrict__ lights, const RtrVertex* __restrict__ vertices,
+                                                   const uint32_t* __restrict__ indices, const uint32_t* __restrict__ first,
+                                                   uint32_t numLights, float4* __restrict__ out) {
+    const uint32_t l = blockIdx.x * 64u + threadIdx.x;
+    if (l >= numLights) return;
+    const RtrAreaLightInfo* L = lights + l;
+    for (uint32_t ti = 0; ti < L->numTriangles; ++ti) light_tri_record(L, vertices, indices, ti, out + (size_t)(first[l] + ti) * 4u);
+}
+
 /* ---- launchers ------------------------------------------------------------------------------- */
 static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
     const char* v = getenv(name);
@@ -850,6 +860,13 @@ hipError_t launch_wavefront(const DeviceScene& sc, const RenderArgs& ra, const F
         case 64: return wave_t<64>(sc, ra, fo, ws, stats, stream, ev);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_light_tris(const RtrAreaLightInfo* lights, const RtrVertex* vertices, const uint32_t* indices, const uint32_t* first,
+                             uint32_t numLights, float4* out, hipStream_t stream) {
+    if (numLights == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_light_tris, dim3((numLights + 63u) / 64u), dim3(64), 0, stream, lights, vertices, indices, first, numLights, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_deinterleave(const uint32_t* gathered, uint32_t* dst, uint32_t width, uint32_t height,

@@ -98,6 +98,8 @@ struct rtr_scene {
     DevBuf<uint32_t> indices;
     DevBuf<RtrObjectInfo> objects;
     DevBuf<RtrAreaLightInfo> lights;
+    DevBuf<float4> lightTris;            /* 4 x float4 per light triangle (rtrdev::launch_light_tris) */
+    DevBuf<uint32_t> lightTriFirst;      /* first record of light l */
     DevBuf<float> xforms, nmats, ltc1, ltc2;
     std::vector<DevBuf<uint8_t>> texPixels;
     DevBuf<uint8_t> hdriPixels;
@@ -364,6 +366,15 @@ static void make_prim_tables(const rtr_scene_desc* d, const RtrInstance* instanc
 }
 
 /* (re)builds the 4-wide view of the tree the any-hit kernel walks, on the device, from the quantised BVH2 nodes */
+/* (re)computes the per-light-triangle records light_loops reads; the light transforms live in s->lights on the device */
+static int make_light_tris(rtr_scene* s) {
+    if (s->numLights == 0) return RTR_OK;
+    hipError_t e = rtrdev::launch_light_tris(s->lights.p, s->vertices.p, s->indices.p, s->lightTriFirst.p, s->numLights, s->lightTris.p, s->ctx->stream);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "light-triangle records: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));     /* frames of other contexts may render this scene next */
+    return RTR_OK;
+}
+
 static int make_wide_nodes(rtr_scene* s) {
     const uint32_t n = (uint32_t)s->hostNodes.size();
     if (!s->nodes4.p) HIP_TRY(s->nodes4.alloc((size_t)n * 4));
@@ -476,6 +487,13 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     chk(s->indices.upload(d->indices, d->numIndices, st));
     chk(s->objects.upload(d->objects, d->numObjects, st));
     chk(s->lights.upload(d->lights, d->numLights, st));
+    {
+        std::vector<uint32_t> first(d->numLights);
+        uint32_t total = 0;
+        for (uint32_t l = 0; l < d->numLights; ++l) { first[l] = total; total += d->lights[l].numTriangles; }
+        chk(s->lightTriFirst.upload(first.data(), first.size(), st));
+        chk(s->lightTris.alloc((size_t)total * 4u));
+    }
     chk(s->xforms.upload(xforms.data(), xforms.size(), st));
     chk(s->nmats.upload(nmats.data(), nmats.size(), st));
     if (d->ltc1) {
@@ -518,11 +536,13 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     }
 
     rc = make_wide_nodes(s);
+    if (rc == RTR_OK) rc = make_light_tris(s);
     if (rc != RTR_OK) { delete s; ctx_release_child(ctx); return rc; }
     DeviceScene& dv = s->dev;
     dv.nodes = s->nodes.p; dv.nodes4 = s->nodes4.p; dv.grid = s->grid.p; dv.tris = s->tris.p;
     dv.vertices = s->vertices.p; dv.indices = s->indices.p;
     dv.objects = s->objects.p; dv.lights = s->lights.p;
+    dv.lightTris = s->lightTris.p; dv.lightTriFirst = s->lightTriFirst.p;
     dv.xforms = s->xforms.p; dv.nmats = s->nmats.p;
     dv.ltc1 = s->hasLtc ? s->ltc1.p : nullptr; dv.ltc2 = s->hasLtc ? s->ltc2.p : nullptr;
     for (int k = 0; k < 3; ++k) dv.skyLinear[k] = rtr_to_linear(d->skyColor[k]);
@@ -616,6 +636,7 @@ int rtr_scene_update_instances(rtr_scene* s, const RtrInstance* instances, uint3
     HIP_TRY(hipMemcpy(s->hostTris.data(), s->tris.p, s->hostTris.size() * 48, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&s->stats.grid, s->grid.p, sizeof(RtrBvhGrid), hipMemcpyDeviceToHost));
     { const int rc4 = make_wide_nodes(s); if (rc4 != RTR_OK) return rc4; }
+    if (lights && numLights) { const int rcl = make_light_tris(s); if (rcl != RTR_OK) return rcl; }
     HIP_TRY(hipMemcpy(red, s->red.p, sizeof red, hipMemcpyDeviceToHost));
     float mabs; memcpy(&mabs, &red[6], 4);
     s->stats.boxPad = (mabs > 1e-6f ? mabs : 1e-6f) * 3.814697265625e-06f;
