@@ -328,6 +328,22 @@ __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint
     for (int q = 0; q < 4; ++q) wide[(size_t)i * 4 + q] = make_uint4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);
 }
 
+/* Moves the 4-wide entries into the order the host chose (breadth-first from the root: rtr_api.cpp, make_wide_nodes), so the
+ * top of the tree is entries 0..K-1 — the part k_shadow_trace4 keeps in LDS.  Inner child codes are renumbered with it. */
+__global__ __launch_bounds__(kB) void k_permute_wide(uint32_t numNodes, const uint4* __restrict__ in, const uint32_t* __restrict__ remap,
+                                                     uint4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= numNodes) return;
+    const size_t dst = (size_t)remap[i] * 4;
+    for (int q = 0; q < 3; ++q) out[dst + q] = in[(size_t)i * 4 + q];
+    uint4 c = in[(size_t)i * 4 + 3];
+    if ((int32_t)c.x >= 0) c.x = remap[c.x];
+    if ((int32_t)c.y >= 0) c.y = remap[c.y];
+    if ((int32_t)c.z >= 0) c.z = remap[c.z];
+    if ((int32_t)c.w >= 0) c.w = remap[c.w];
+    out[dst + 3] = c;
+}
+
 /* ---- host-side drivers ------------------------------------------------------------------------------ */
 #define BV_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -366,6 +382,11 @@ hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDevic
 
 hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, const RtrBvhGrid* grid, uint4* wide, hipStream_t s) {
     hipLaunchKernelGGL(k_wide_nodes, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, nodes, parentOrNull, grid, wide);
+    return hipGetLastError();
+}
+
+hipError_t bvh_permute_wide(const uint4* in, uint32_t numNodes, const uint32_t* remap, uint4* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute_wide, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, in, remap, out);
     return hipGetLastError();
 }
 

@@ -27,7 +27,8 @@ struct DeviceTexture { const uint8_t* pixels; uint32_t width, height, channels, 
 struct DeviceScene {
     const uint4* nodes;              /* RtrBvhNode (layout version 3) as 2 x uint4 */
     const RtrBvhGrid* grid;          /* the grid the 16-bit planes live on; device memory so a refit can rewrite it */
-    const uint4* nodes4;             /* 4-wide view for the any-hit kernel (4 x uint4 per BVH2 node id), or null */
+    const uint4* nodes4;             /* 4-wide view for the any-hit kernel (4 x uint4 per entry, breadth-first order), or null */
+    uint32_t numNodes4;              /* entries in nodes4 */
     const float4* tris;              /* RtrBvhTri  as 3 x float4 */
     const RtrVertex* vertices;
     const uint32_t* indices;

@@ -92,6 +92,9 @@ struct rtr_scene {
     DevBuf<uint4> nodes;                 /* RtrBvhNode, 2 x uint4 each */
     DevBuf<float4> nodesF;               /* rtr::BvhNodeF, 4 x float4 each: device build / refit only */
     DevBuf<RtrBvhGrid> grid;
+    DevBuf<uint4> nodes4tmp;             /* the 4-wide entries in BVH2-id order, before the breadth-first permutation */
+    DevBuf<uint32_t> wideRemap;
+    uint32_t wideReached = 0;            /* entries the 4-wide tree reaches (they come first in nodes4) */
     DevBuf<uint4> nodes4;                /* 4-wide view of the tree for the any-hit kernel, 4 x uint4 per BVH2 node id (kernels/rtr_bvh.hip) */
     DevBuf<float4> tris;
     DevBuf<RtrVertex> vertices;
@@ -377,10 +380,29 @@ static int make_light_tris(rtr_scene* s) {
 
 static int make_wide_nodes(rtr_scene* s) {
     const uint32_t n = (uint32_t)s->hostNodes.size();
-    if (!s->nodes4.p) HIP_TRY(s->nodes4.alloc((size_t)n * 4));
-    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4.p, s->ctx->stream);
+    if (!s->nodes4.p) { HIP_TRY(s->nodes4.alloc((size_t)n * 4)); HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); }
+    hipStream_t st = s->ctx->stream;
+    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4tmp.p, st);
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node build: %s", hipGetErrorString(e));
-    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    /* breadth-first order of the 4-wide tree (child codes = the 4th 16 bytes of every entry), so its top levels are the first
+     * entries: k_shadow_trace4 keeps those in LDS.  Entries the 4-wide tree does not reach keep the ids after them. */
+    std::vector<uint32_t> codes((size_t)n * 4), remap(n, 0xffffffffu), order;
+    HIP_TRY(hipMemcpy2DAsync(codes.data(), 16, reinterpret_cast<const char*>(s->nodes4tmp.p) + 48, 64, 16, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    order.reserve(n);
+    order.push_back(0); remap[0] = 0;
+    for (size_t head = 0; head < order.size(); ++head)
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c = (int32_t)codes[(size_t)order[head] * 4 + k];
+            if (c >= 0 && (uint32_t)c < n && remap[c] == 0xffffffffu) { remap[c] = (uint32_t)order.size(); order.push_back((uint32_t)c); }
+        }
+    uint32_t next = (uint32_t)order.size();
+    for (uint32_t i = 0; i < n; ++i) if (remap[i] == 0xffffffffu) remap[i] = next++;
+    HIP_TRY(hipMemcpyAsync(s->wideRemap.p, remap.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    e = rtrdev::bvh_permute_wide(s->nodes4tmp.p, n, s->wideRemap.p, s->nodes4.p, st);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node order: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(st));
+    s->wideReached = (uint32_t)order.size();
     return RTR_OK;
 }
 
@@ -539,7 +561,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     if (rc == RTR_OK) rc = make_light_tris(s);
     if (rc != RTR_OK) { delete s; ctx_release_child(ctx); return rc; }
     DeviceScene& dv = s->dev;
-    dv.nodes = s->nodes.p; dv.nodes4 = s->nodes4.p; dv.grid = s->grid.p; dv.tris = s->tris.p;
+    dv.nodes = s->nodes.p; dv.nodes4 = s->nodes4.p; dv.numNodes4 = (uint32_t)s->hostNodes.size(); dv.grid = s->grid.p; dv.tris = s->tris.p;
     dv.vertices = s->vertices.p; dv.indices = s->indices.p;
     dv.objects = s->objects.p; dv.lights = s->lights.p;
     dv.lightTris = s->lightTris.p; dv.lightTriFirst = s->lightTriFirst.p;
