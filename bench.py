@@ -297,6 +297,8 @@ def main():
                         # instruction occupies one for 4 clocks) at the 2.4 GHz engine clock
                         "limits": {"l1_tag_lookup_frac": round(lookups / (256 * 2.4e9 * trace_ms * 1e-3), 4) if lookups else None,
                                    "valu_busy_frac": round(valu * 4 / (1024 * 2.4e9 * trace_ms * 1e-3), 4) if valu else None,
+                                   # with the 4.2 clocks per instruction the issue-rate microbenchmark measures for this mix
+                                   "valu_issue_frac_at_4p2_clk": round(valu * 4.2 / (1024 * 2.4e9 * trace_ms * 1e-3), 4) if valu else None,
                                    "source": "profiles/pmc_traffic.json"},
                         "bvh_layout_version": int(sstats.bvhLayoutVersion)}
         elif trace_ms == 0 and kern["primary"] > 0:
