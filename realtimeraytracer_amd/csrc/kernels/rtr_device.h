@@ -24,6 +24,8 @@ namespace rtrdev {
 
 struct DeviceTexture { const uint8_t* pixels; uint32_t width, height, channels, _pad; };
 
+constexpr uint32_t kLightTriRecord = 6;     /* float4s per light-triangle record */
+
 struct DeviceScene {
     const uint4* nodes;              /* RtrBvhNode (layout version 3) as 2 x uint4 */
     const RtrBvhGrid* grid;          /* the grid the 16-bit planes live on; device memory so a refit can rewrite it */
@@ -34,7 +36,7 @@ struct DeviceScene {
     const uint32_t* indices;
     const RtrObjectInfo* objects;
     const RtrAreaLightInfo* lights;
-    const float4* lightTris;         /* per light triangle, 4 x float4: {P0, area} {P1, pdf} {P2, -} {unit normal, -} in world space (k_light_tris) */
+    const float4* lightTris;         /* per light triangle, kLightTriRecord x float4: {P0, area} {P1, pdf} {P2, -} {unit normal, -} {min corner, -} {max corner, -} in world space (k_light_tris) */
     const uint32_t* lightTriFirst;   /* first record of light l */
     const float* xforms;             /* 12 floats (3x4 row-major object->world) per customIndex */
     const float* nmats;              /* 12 floats (9 used: transpose(inverse(mat3))) per customIndex */
@@ -499,7 +501,7 @@ __device__ __forceinline__ bool fetch_surface(const DeviceScene& sc, const Rende
     return true;
 }
 
-/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax) answers the
+/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax, rawDir) (rawDir: dir before normalisation, only its signs are meaningful) answers the
  * shadow query; Policy::kShade == false (counting / emitting the queries) skips the BRDF arithmetic but keeps the exact
  * sequence of queries. */
 template <class Policy, bool STATS>
@@ -526,7 +528,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
             if (STATS) st.lightTriFetch++;
             /* corners, area, pdf and normal of the light triangle are the same for every pixel: k_light_tris computed them once
              * (raygen.rgen:174-196, same operations) and the addresses are wave-uniform, so these are scalar loads */
-            const float4* rec = sc.lightTris + (size_t)(sc.lightTriFirst[li] + ti) * 4u;
+            const float4* rec = sc.lightTris + (size_t)(sc.lightTriFirst[li] + ti) * kLightTriRecord;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             rtr_v3 P[3];
             P[0] = rtr_mk(r0.x, r0.y, r0.z); P[1] = rtr_mk(r1.x, r1.y, r1.z); P[2] = rtr_mk(r2.x, r2.y, r2.z);
@@ -534,6 +536,21 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
             const rtr_v3 lightNormal = rtr_mk(r3.x, r3.y, r3.z);
             if (!twoSided) {
                 if (rtr_dot(lightNormal, rtr_sub(hitPoint, P[0])) < 0.0f) continue;
+            }
+            if constexpr (Policy::kOctantOnly) {
+                /* counting pass of the octant-binned queue: a surface point that lies clear of the light triangle's bounding box on
+                 * every axis sees all its samples in one octant — no need to draw them.  The margin is far above the rounding
+                 * of the sample position, so this never disagrees with the per-sample signs the emission pass takes. */
+                const float4 bmn = rec[4], bmx = rec[5];
+                const float mx = rtr_max(rtr_max(bmx.x - bmn.x, bmx.y - bmn.y), bmx.z - bmn.z) * 1.0e-3f +
+                                 (rtr_abs(bmn.x) + rtr_abs(bmx.x) + rtr_abs(bmn.y) + rtr_abs(bmx.y) + rtr_abs(bmn.z) + rtr_abs(bmx.z)) * 1.0e-5f;
+                const bool px_ = hitPoint.x < bmn.x - mx, nx_ = hitPoint.x > bmx.x + mx;
+                const bool py_ = hitPoint.y < bmn.y - mx, ny_ = hitPoint.y > bmx.y + mx;
+                const bool pz_ = hitPoint.z < bmn.z - mx, nz_ = hitPoint.z > bmx.z + mx;
+                if ((px_ || nx_) && (py_ || ny_) && (pz_ || nz_)) {
+                    pol.add((nx_ ? 1u : 0u) | (ny_ ? 2u : 0u) | (nz_ ? 4u : 0u), ra.numShadowRays);
+                    continue;
+                }
             }
             rtr_v3 shadowedSample = rtr_mk(0, 0, 0), unshadowedSample = rtr_mk(0, 0, 0);
             for (uint32_t s = 0; s < ra.numShadowRays; ++s) {                             /* :206 */
@@ -544,7 +561,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
                 const rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
                 const rtr_v3 sampledLightDir = rtr_normalize(lightVec);
                 const float lightDistance = rtr_length(lightVec);
-                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f);
+                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f, lightVec);
                 if (Policy::kShade && (wantUnshadowed || !occ)) {
                     const float currShadow = occ ? 0.0f : 1.0f;
                     const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir));
@@ -591,7 +608,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
     /* directional light, raygen.rgen:289-338 */
     const rtr_v3 directLightDir = rtr_normalize(rtr_mk(-1.0f, 1.0f, -0.5f));
     if (rtr_dot(hitNormal, directLightDir) <= 0.0f) return;
-    const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f);
+    const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f, directLightDir);
     if (Policy::kShade && (wantUnshadowed || wantAnalytic || !occ)) {
         const rtr_v3 directLightColor = rtr_mk(1.0f, 1.0f, 0.5f);
         const float directLightIntensity = 0.2f;
@@ -637,6 +654,8 @@ __device__ __forceinline__ void light_tri_record(const RtrAreaLightInfo* L, cons
     rec[1] = make_float4(P[1].x, P[1].y, P[1].z, pdf);
     rec[2] = make_float4(P[2].x, P[2].y, P[2].z, 0.f);
     rec[3] = make_float4(lightNormal.x, lightNormal.y, lightNormal.z, 0.f);
+    rec[4] = make_float4(rtr_min(rtr_min(P[0].x, P[1].x), P[2].x), rtr_min(rtr_min(P[0].y, P[1].y), P[2].y), rtr_min(rtr_min(P[0].z, P[1].z), P[2].z), 0.f);
+    rec[5] = make_float4(rtr_max(rtr_max(P[0].x, P[1].x), P[2].x), rtr_max(rtr_max(P[0].y, P[1].y), P[2].y), rtr_max(rtr_max(P[0].z, P[1].z), P[2].z), 0.f);
 }
 
 /* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110, miss.rmiss:15-27). */

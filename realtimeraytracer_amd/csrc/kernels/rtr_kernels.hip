@@ -28,9 +28,9 @@ constexpr int kBlock = 256;
 
 template <bool STATS, int STACK>
 struct InlinePolicy {
-    static constexpr bool kShade = true;
+    static constexpr bool kShade = true, kOctantOnly = false;
     const DeviceScene& sc; int32_t* stack; LocalStats& st;
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax) {
+    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
         HitRec h;
         return trace<true, STATS, kBlock>(sc, stack, o, d, 0.001f, tmax, h, st);
     }
@@ -48,16 +48,16 @@ struct InlinePolicy {
  * Entries of one emission step are contiguous, so k_shadow_trace's waves get rays of neighbouring
  * pixels aimed at the same light triangle / sample index. */
 struct CountPolicy {
-    static constexpr bool kShade = false;
+    static constexpr bool kShade = false, kOctantOnly = false;
     uint32_t n;
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float) { ++n; return false; }
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { ++n; return false; }
 };
 
 struct EmitPolicy {
-    static constexpr bool kShade = false;
+    static constexpr bool kShade = false, kOctantOnly = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;     /* keeps the access a ds_read/ds_write, not a flat_load */
     float4* queue; lds_word waveOffset; uint32_t base; uint32_t slot;
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax) {
+    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         const uint32_t off = *waveOffset;                      /* same LDS word for the whole wave: broadcast read */
@@ -71,9 +71,53 @@ struct EmitPolicy {
 };
 
 struct LookupPolicy {
-    static constexpr bool kShade = true;
+    static constexpr bool kShade = true, kOctantOnly = false;
     const uint8_t* vis; uint32_t slot;
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float) { return vis[slot++] != 0; }
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { return vis[slot++] != 0; }
+};
+
+/* The same two phases with the queue binned by direction octant (k_shadow_gen_oct): a workgroup's chunk of the queue is laid
+ * out octant by octant, and every run of one octant is cut into batches that are appended to that octant's batch list, from
+ * which k_shadow_trace4's waves draw — so the rays a wave holds share their direction signs and the inner-node loop runs in its
+ * octant form (slab_oct) nearly always instead of a third of the time.  The octant is taken from the un-normalised direction in
+ * both phases (a component that underflows in the normalisation must not move a ray between the count and the emission). */
+__device__ __forceinline__ uint32_t raw_octant(rtr_v3 r) {
+    return (r.x < 0.f ? 1u : 0u) | (r.y < 0.f ? 2u : 0u) | (r.z < 0.f ? 4u : 0u);
+}
+
+struct CountOctPolicy {
+    static constexpr bool kShade = false, kOctantOnly = true;     /* kOctantOnly: light_loops may count a whole light triangle at once */
+    unsigned long long lo, hi;                 /* eight 16-bit counters: octants 0-3, 4-7 */
+    __device__ __forceinline__ void add(uint32_t oct, uint32_t n) {
+        const unsigned long long v = (unsigned long long)n << ((oct & 3u) * 16u);
+        if (oct < 4u) lo += v; else hi += v;
+    }
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3 raw) { add(raw_octant(raw), 1u); return false; }
+};
+
+struct EmitOctPolicy {
+    static constexpr bool kShade = false, kOctantOnly = false;
+    typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;
+    float4* queue; lds_word run; uint32_t slot;         /* run[o]: next queue index of this wave's part of the octant-o run */
+    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw) {
+        const uint32_t oct = raw_octant(raw);
+        unsigned long long rem = __ballot(1);
+        while (rem != 0ull) {                            /* one round per octant present among the lanes of this emission step */
+            const uint32_t oo = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)rem) - 1);
+            const unsigned long long mo = __ballot(oct == oo);
+            if (oct == oo) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
+                const uint32_t pos = run[oo];
+                if (prefix == 0) run[oo] = pos + (uint32_t)__popcll(mo);
+                const size_t idx = (size_t)(pos + prefix) * 2;
+                queue[idx] = make_float4(o.x, o.y, o.z, tmax);
+                queue[idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
+            }
+            rem &= ~mo;
+        }
+        ++slot;
+        return false;
+    }
 };
 
 __device__ __forceinline__ Accum zero_accum() {
@@ -237,6 +281,89 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, Render
             Surface sf;
             if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st))
                 light_loops<EmitPolicy, false>(sc, ra, px, py, sf, 0u, acc, pol, st);
+        }
+    }
+}
+
+constexpr size_t kBinnedMinRays = (size_t)8 << 20;   /* queue capacity from which the binned queue is used by default */
+constexpr uint32_t kGenOctBlock = 512;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
+/* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
+ * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
+__global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc, RenderArgs ra, const float4* hitTuvp, const uint32_t* hitCustom,
+                                                              float4* queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
+                                                              uint32_t listStride, uint32_t kBatch) {
+    constexpr uint32_t kWaves = kGenOctBlock / 64;
+    __shared__ uint32_t s_tot[kWaves][8], s_run[kWaves][8], s_first[8], s_len[8];
+    const uint32_t q = blockIdx.x * kGenOctBlock + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t px = 0, lrow = 0, py = 0;
+    const bool live = pixel_of(ra, q, px, lrow, py);
+    LocalStats st;
+    Accum acc = zero_accum();
+    const bool single = ra.spp == 1u;
+    Surface sf0;
+    bool surf0 = false;
+    CountOctPolicy cp{0ull, 0ull};
+    if (live) {
+        for (uint32_t i = 0; i < ra.spp; ++i) {
+            const size_t k = (size_t)i * planeStride + q;
+            const float4 r = hitTuvp[k];
+            HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
+            Surface sf;
+            const bool surf = fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);
+            if (surf) light_loops<CountOctPolicy, false>(sc, ra, px, py, sf, 0u, acc, cp, st);
+            if (i == 0) { sf0 = sf; surf0 = surf; }
+        }
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t o = 0; o < 8; ++o) {
+        const uint32_t c = (uint32_t)(((o < 4 ? cp.lo : cp.hi) >> ((o & 3u) * 16u)) & 0xffffull);
+        mine += c;
+        const uint32_t t = wave_sum(c);
+        if ((threadIdx.x & 63u) == 0) s_tot[wave][o] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                       /* ONE reservation per workgroup (see k_shadow_gen), then the runs inside it */
+        uint32_t total = 0;
+        for (uint32_t o = 0; o < 8; ++o) { uint32_t t = 0; for (uint32_t w = 0; w < kWaves; ++w) t += s_tot[w][o]; s_len[o] = t; total += t; }
+        uint32_t at = total ? atomicAdd(ctrl, total) : 0u;
+        for (uint32_t o = 0; o < 8; ++o) { s_first[o] = at; at += s_len[o]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kQueueLists) {              /* one lane per (octant, list): the waves' write cursors; the run's batches */
+        const uint32_t o = threadIdx.x / kQueueRegions, x = threadIdx.x % kQueueRegions;
+        if (x == 0) {
+            uint32_t at = s_first[o];
+            for (uint32_t w = 0; w < kWaves; ++w) { s_run[w][o] = at; at += s_tot[w][o]; }
+        }
+        const uint32_t len = s_len[o];
+        /* the run's batches are dealt round-robin to the eight lists of this octant (one per consumer XCD); every lane makes its
+         * own reservation, so the workgroup waits for one atomic's round trip, not eight in a row */
+        const uint32_t nb = (len + kBatch - 1) / kBatch;
+        const uint32_t b0 = (x + kQueueRegions - blockIdx.x % kQueueRegions) % kQueueRegions;     /* first batch that goes to list x */
+        if (b0 < nb) {
+            const uint32_t cnt = (nb - b0 + kQueueRegions - 1) / kQueueRegions;
+            const uint32_t pos = atomicAdd(ctrl + kQueueListLens + threadIdx.x, cnt);
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t f = (b0 + j * kQueueRegions) * kBatch;
+                lists[(size_t)threadIdx.x * listStride + pos + j] = make_uint2(s_first[o] + f, len - f < kBatch ? len - f : kBatch);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live || mine == 0) return;
+    for (uint32_t i = 0; i < ra.spp; ++i) {
+        const size_t k = (size_t)i * planeStride + q;
+        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)(k * ra.maxRaysPerSample)};
+        if (single) {
+            if (surf0) light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
+        } else {
+            const float4 r = hitTuvp[k];
+            HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
+            Surface sf;
+            if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st))
+                light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf, 0u, acc, pol, st);
         }
     }
 }
@@ -593,27 +720,42 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
 /* The same kernel over the 4-wide view of the tree (DeviceScene::nodes4, built by k_wide_nodes): a visit is one 64-B record
  * (four loads issued together) holding up to four child boxes, so a ray makes about half as many DEPENDENT visits; the
  * instruction and look-up totals stay about the same.  2.17 -> 2.05 ms on the bench frame; identical visibility bits. */
-template <int STACK>
+template <int STACK, bool LISTS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
-                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount) {
+                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
+                                                              const uint2* __restrict__ lists, uint32_t listStride) {
     __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
     for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kBlock) s_top[i] = sc.nodes4[i];
     __syncthreads();
-    const uint32_t n = *count;
     uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
     bool exhausted = false;                  /* wave-uniform */
-    /* The queue is cut into kQueueRegions contiguous regions with one batch cursor each (64 B apart).  A workgroup starts on
-     * region (blockIdx mod 8) — workgroups are dealt round-robin to the 8 XCDs — and moves on only when that region is empty.
-     * One counter sustains ~88 atomics/us, which is what forced 256-ray batches; eight counters allow batches small enough to
-     * balance the short queues of a 1/8-frame shard (launcher: kBatch shrinks with the queue). */
+    /* LISTS == false: the plain queue, cut into kQueueRegions contiguous regions with one batch cursor each (64 B apart).  A
+     * workgroup starts on region (blockIdx mod 8) — workgroups are dealt round-robin to the 8 XCDs, so a cursor is hammered by
+     * one XCD's waves — and moves on only when that region is empty (one counter sustains ~88 atomics/us).
+     * LISTS == true: the queue was binned by direction octant (k_shadow_gen_oct): list r = octant * 8 + xcd holds batches
+     * {first, count} (length lens[r], cursor nextBatch[16 r]).  A workgroup starts on the octant its share of the launch falls
+     * into — octants get workgroups in proportion to their batches — and there on the list of its own XCD, then takes the other
+     * XCDs' lists of that octant, then the next octant: the rays in a wave share their direction signs except around such a move.
+     * (With one list per octant, shared by all XCDs, the same kernel took 3.8 ms instead of 1.9.) */
+    const uint32_t* __restrict__ lens = nextBatch - 16 + kQueueListLens;
+    const uint32_t n = LISTS ? 0u : *count;
     const uint32_t regionLen = ((n + kQueueRegions - 1) / kQueueRegions + kBatch - 1) / kBatch * kBatch;
-    const uint32_t myRegion = blockIdx.x % kQueueRegions;
-    uint32_t regionTry = 0;                  /* wave-uniform: regions found empty so far (cursors only grow) */
+    const uint32_t myXcd = blockIdx.x % kQueueRegions;
+    uint32_t myRegion = myXcd;
+    if (LISTS) {
+        uint32_t total = 0;
+        for (uint32_t r = 0; r < kQueueLists; ++r) total += lens[r];
+        const uint32_t target = (uint32_t)(((unsigned long long)blockIdx.x * total) / gridDim.x);
+        uint32_t upTo = 0;
+        myRegion = 0;
+        for (uint32_t r = 0; r < kQueueLists; ++r) { upTo += lens[r]; if (target < upTo) { myRegion = r / kQueueRegions; break; } }
+    }
+    uint32_t regionTry = 0;                  /* wave-uniform: regions / lists found empty so far (cursors only grow) */
     int32_t cur = kDone;
     int sp = 0;                              /* entries held; the top is lds[sp * kBlock] */
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
@@ -639,18 +781,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (!exhausted) {
                 if (batchPos == batchEnd) {
                     for (;;) {
-                        if (regionTry >= kQueueRegions) { exhausted = true; break; }
-                        const uint32_t r = (myRegion + regionTry) % kQueueRegions;
-                        const uint32_t lo = r * regionLen;
-                        uint32_t hi = lo + regionLen; if (hi > n) hi = n;
-                        uint32_t b = hi;
-                        if (lo < hi) {
-                            uint32_t got = 0;
-                            if ((threadIdx.x & 63u) == 0) got = atomicAdd(nextBatch + 16u * r, kBatch);
-                            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                            b = got < regionLen ? lo + got : hi;
+                        if (regionTry >= (LISTS ? kQueueLists : kQueueRegions)) { exhausted = true; break; }
+                        if (LISTS) {
+                            const uint32_t r = (myRegion + regionTry / kQueueRegions) % kQueueRegions * kQueueRegions + (myXcd + regionTry) % kQueueRegions;
+                            const uint32_t len = lens[r];
+                            if (len != 0u) {
+                                uint32_t got = 0;
+                                if ((threadIdx.x & 63u) == 0) got = atomicAdd(nextBatch + 16u * r, 1u);
+                                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                                if (got < len) {
+                                    const uint2 dsc = lists[(size_t)r * listStride + got];
+                                    batchPos = dsc.x; batchEnd = dsc.x + dsc.y;
+                                    break;
+                                }
+                            }
+                        } else {
+                            const uint32_t r = (myRegion + regionTry) % kQueueRegions;
+                            const uint32_t lo = r * regionLen;
+                            uint32_t hi = lo + regionLen; if (hi > n) hi = n;
+                            uint32_t b = hi;
+                            if (lo < hi) {
+                                uint32_t got = 0;
+                                if ((threadIdx.x & 63u) == 0) got = atomicAdd(nextBatch + 16u * r, kBatch);
+                                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                                b = got < regionLen ? lo + got : hi;
+                            }
+                            if (b < hi) { batchPos = b; batchEnd = (b + kBatch < hi) ? b + kBatch : hi; break; }
                         }
-                        if (b < hi) { batchPos = b; batchEnd = (b + kBatch < hi) ? b + kBatch : hi; break; }
                         ++regionTry;
                     }
                 }
@@ -788,7 +945,7 @@ __global__ __launch_bounds__(64) void k_light_tris(const RtrAreaLightInfo* __res
     const uint32_t l = blockIdx.x * 64u + threadIdx.x;
     if (l >= numLights) return;
     const RtrAreaLightInfo* L = lights + l;
-    for (uint32_t ti = 0; ti < L->numTriangles; ++ti) light_tri_record(L, vertices, indices, ti, out + (size_t)(first[l] + ti) * 4u);
+    for (uint32_t ti = 0; ti < L->numTriangles; ++ti) light_tri_record(L, vertices, indices, ti, out + (size_t)(first[l] + ti) * kLightTriRecord);
 }
 
 /* ---- launchers ------------------------------------------------------------------------------- */
@@ -838,7 +995,23 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
         hipLaunchKernelGGL(k_primary_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, blocks * kBlock);
     }
     if (ev) hipEventRecord(ev[1], s);
-    hipLaunchKernelGGL(k_shadow_gen, dim3((blocks * kBlock + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
+    /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
+    static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
+    static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);   /* 0: the 2-wide any-hit kernel on the plain queue (same results, for comparison) */
+    const uint32_t genBlocks = (blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
+    /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
+     * (k_shadow_gen -> k_shadow_trace4 over eight regions of it).  Binning pays on long queues (+2 % frame rate at 12-25 M rays:
+     * the octant forms of the slab test then run 97 % of the time instead of 36 %) and costs on short ones (its 64 short lists
+     * drain unevenly: -2 % at 3-6 M rays), hence the threshold; RTR_TRACE_BINNED=0/1 forces it off/on (the tests run both).
+     * The 16-bit per-lane counters of the binned count hold any realistic ray count per pixel. */
+    const char* binEnv = getenv("RTR_TRACE_BINNED");
+    const uint32_t binMode = (binEnv && (binEnv[0] == '0' || binEnv[0] == '1') && !binEnv[1]) ? (uint32_t)(binEnv[0] - '0') : 2u;
+    const size_t maxRaysQ = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
+    const bool binned = !stats && kWide && sc.nodes4 && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
+                        (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
+                        (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays));
+    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch);
+    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
     /* persistent waves: as many workgroups as stay resident (16 KiB of LDS stack per workgroup -> 8 per CU, the
      * 32-wave hardware maximum), each pulling batches until the queue is empty */
@@ -847,18 +1020,16 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
-    /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
-    static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 28u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
     if (stats) hipLaunchKernelGGL((k_shadow_trace_count<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 1, ws.vis, stats, kBatch, kRefill, ws.spill, kInnerMin);
     else {
-        /* the 4-wide kernel is the production path; RTR_TRACE_BVH4=0 selects the 2-wide one (same results, for comparison) */
-        static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);
         static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u);
         static const uint32_t kTop = env_u32("RTR_TRACE_TOP_NODES", kTopNodes, 0u, kTopNodes);
-        if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, kTop < sc.numNodes4 ? kTop : sc.numNodes4);
+        const uint32_t top = kTop < sc.numNodes4 ? kTop : sc.numNodes4;
+        if (binned) hipLaunchKernelGGL((k_shadow_trace4<16, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride);
+        else if (kWide && sc.nodes4) hipLaunchKernelGGL((k_shadow_trace4<16, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride);
         else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
         hipLaunchKernelGGL(k_shadow_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill);
     }

@@ -139,6 +139,8 @@ struct rtr_frame {
     DevBuf<uint8_t> vis;
     DevBuf<int32_t> spill;
     DevBuf<uint32_t> overflow;
+    DevBuf<uint2> batchLists;
+    uint32_t listStride = 0;
     DevBuf<Counters> counters;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evMega[2] = {nullptr, nullptr};
@@ -514,7 +516,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
         uint32_t total = 0;
         for (uint32_t l = 0; l < d->numLights; ++l) { first[l] = total; total += d->lights[l].numTriangles; }
         chk(s->lightTriFirst.upload(first.data(), first.size(), st));
-        chk(s->lightTris.alloc((size_t)total * 4u));
+        chk(s->lightTris.alloc((size_t)total * rtrdev::kLightTriRecord));
     }
     chk(s->xforms.upload(xforms.data(), xforms.size(), st));
     chk(s->nmats.upload(nmats.data(), nmats.size(), st));
@@ -856,12 +858,16 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     hipError_t e;
     if (wave) {
         if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); }
-        if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); HIP_TRY(f->overflow.alloc(nSlots + 1)); }
+        if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); HIP_TRY(f->overflow.alloc(nSlots + 1));
+            /* batch lists of the binned queue (octant x consumer XCD): a run's batches are dealt round-robin to the eight lists of
+             * its octant, so a list holds at most 1/8 of one batch per 64 rays (the smallest batch) + one per k_shadow_gen_oct workgroup */
+            f->listStride = (uint32_t)(nSlots / 64 / rtrdev::kQueueRegions + nPS / 256 + 16);
+            HIP_TRY(f->batchLists.alloc((size_t)f->listStride * rtrdev::kQueueLists)); }
         if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(rtrdev::kQueueCtrlWords));
         if (!f->spill.p) HIP_TRY(f->spill.alloc((size_t)48 * 2048 * 256));      /* (64 - 16) entries x the largest persistent grid */
         Workspace ws;
         ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
-        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p; ws.overflow = f->overflow.p;
+        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride;
         e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev);
     } else {
         (void)hipEventRecord(f->evMega[0], st);

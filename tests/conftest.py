@@ -32,3 +32,17 @@ def gpu_ctx():
     ctx = api.Context(0)   # raises RtrError(RTR_ERR_NO_DEVICE) without a GPU: no fallback
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(params=["plain", "binned"])
+def queue_mode(request):
+    """Runs a GPU test twice: with the shadow-ray queue in emission order and binned by direction octant (k_shadow_gen_oct +
+    per-octant batch lists).  By default the library picks by queue size, so small test frames would only ever see the plain
+    queue; RTR_TRACE_BINNED is read at every render."""
+    old = os.environ.get("RTR_TRACE_BINNED")
+    os.environ["RTR_TRACE_BINNED"] = "1" if request.param == "binned" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("RTR_TRACE_BINNED", None)
+    else:
+        os.environ["RTR_TRACE_BINNED"] = old

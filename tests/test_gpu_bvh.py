@@ -11,7 +11,7 @@ from realtimeraytracer_amd import _abi as A
 from realtimeraytracer_amd import api, scenes
 from test_oracle_bvh import _check_bvh
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("queue_mode")]
 
 
 def _with_flags(desc, flags):

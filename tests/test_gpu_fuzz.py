@@ -10,7 +10,7 @@ import pytest
 from realtimeraytracer_amd import _abi as A
 from realtimeraytracer_amd import api, scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("queue_mode")]
 
 
 def _soup(seed, directory):

@@ -7,7 +7,7 @@ import pytest
 from realtimeraytracer_amd import _abi as A
 from realtimeraytracer_amd import api, scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("queue_mode")]
 
 
 def _gpu_render(ctx, setup, params, images=A.IMAGES_FRAMEBUFFER, frame=None, scene=None, frame_no=0):
