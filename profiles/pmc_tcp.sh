@@ -20,9 +20,9 @@ for tag in ("pmc_tcp1", "pmc_tcp2", "pmc_tcp3", "pmc_sq"):
     agg = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            agg[row["Kernel_Name"][:48]][row["Counter_Name"]].append(float(row["Counter_Value"] or 0))
+            agg[row["Kernel_Name"][:72]][row["Counter_Name"]].append(float(row["Counter_Value"] or 0))
     for k in agg:
-        if "rtrdev" not in k or "true" in k: continue
+        if "rtrdev" not in k or "k_resolve<true" in k or ", true>(rtrdev::DeviceScene, rtrdev::RenderA" in k or "trace_count" in k: continue   # the counting (STATS) forms
         print(k)
         for c, v in sorted(agg[k].items()):
             print(f"   {c:40s} {sum(v)/len(v):16.0f}  (n={len(v)})")

@@ -285,7 +285,9 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, Render
     }
 }
 
-constexpr size_t kBinnedMinRays = (size_t)8 << 20;   /* queue capacity from which the binned queue is used by default */
+constexpr size_t kBinnedMinRays = (size_t)10 << 20;  /* by default the binned queue is used from this queue capacity ... */
+constexpr uint32_t kBinnedMinNodes = 1u << 16;       /* ... and this tree size: binning pays where traversal dominates (Cornell at 1080p, 14.6 M
+                                                      * cheap rays: 18.8 Grays/s plain, 14.7 binned; the 41 k-node sphere scene: -1 %) */
 constexpr uint32_t kGenOctBlock = 512;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
 /* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
  * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
@@ -1002,14 +1004,14 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
      * (k_shadow_gen -> k_shadow_trace4 over eight regions of it).  Binning pays on long queues (+2 % frame rate at 12-25 M rays:
      * the octant forms of the slab test then run 97 % of the time instead of 36 %) and costs on short ones (its 64 short lists
-     * drain unevenly: -2 % at 3-6 M rays), hence the threshold; RTR_TRACE_BINNED=0/1 forces it off/on (the tests run both).
+     * drain unevenly: -2 % at 3-6 M rays), hence the thresholds (kBinnedMinRays, kBinnedMinNodes); RTR_TRACE_BINNED=0/1 forces it off/on (the tests run both).
      * The 16-bit per-lane counters of the binned count hold any realistic ray count per pixel. */
     const char* binEnv = getenv("RTR_TRACE_BINNED");
     const uint32_t binMode = (binEnv && (binEnv[0] == '0' || binEnv[0] == '1') && !binEnv[1]) ? (uint32_t)(binEnv[0] - '0') : 2u;
     const size_t maxRaysQ = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
     const bool binned = !stats && kWide && sc.nodes4 && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
-                        (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays));
+                        (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
     if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch);
     else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
