@@ -543,8 +543,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     bool exhausted = false;                  /* wave-uniform */
     /* The queue is cut into kQueueRegions contiguous regions with one batch cursor each (64 B apart).  A workgroup starts on
      * region (blockIdx mod 8) — workgroups are dealt round-robin to the 8 XCDs — and moves on only when that region is empty.
-     * One counter sustains ~88 atomics/us, which is what forced 256-ray batches; eight counters allow batches small enough to
-     * balance the short queues of a 1/8-frame shard (launcher: kBatch shrinks with the queue). */
+     * One counter sustains ~88 atomics/us, which is what forced 256-ray batches; eight counters give headroom, but 256 stays
+     * the best batch even for the short queue of a 1/8-frame shard (profiles/r01/sweep_batch_sharded.log). */
     const uint32_t regionLen = ((n + kQueueRegions - 1) / kQueueRegions + kBatch - 1) / kBatch * kBatch;
     const uint32_t myRegion = blockIdx.x % kQueueRegions;
     uint32_t regionTry = 0;                  /* wave-uniform: regions found empty so far (cursors only grow) */
