@@ -4,7 +4,7 @@ Mrays/sec and ms/frame at 1920x1080, 1 spp, on 1/2/4/8 MI355X).
 
 A "step" is one frame: the hot path over one batch of synthetic input (the procedural Sponza-class
 atrium, ~262 k triangles, 2 area lights; BASELINE config 4), i.e. k_primary -> k_shadow_gen ->
-k_shadow_trace -> k_resolve through the C ABI, scene resident in HBM.  With N > 1 the SAME frame is
+k_shadow_trace4 -> k_resolve through the C ABI, scene resident in HBM.  With N > 1 the SAME frame is
 band-sharded over the ranks (strong scaling), gathered to rank 0 with one RCCL gather over xGMI and
 de-interleaved there; all of that is inside the timed region.
 
@@ -14,7 +14,7 @@ de-interleaved there; all of that is inside the timed region.
 
 Rank 0 prints ONE JSON line.  `value` = all rays traced per second (primary + shadow, exact count
 from the kernels' own counters in an untimed stats pass), whole job.  `roofline` is for the dominant
-kernel (k_shadow_trace): algorithmic bytes per launch / its average launch duration measured with HIP
+kernel (k_shadow_trace4): algorithmic bytes per launch / its average launch duration measured with HIP
 events on the render stream inside the timed steps.  `cpu_baseline` is the CPU oracle (a scalar C++
 port, oracle/) timed on the host cores on a bounded sample of the same workload — reported, not a target.
 """
@@ -247,7 +247,7 @@ def main():
 
     # After the timed region: the same frames ONE AT A TIME, so every kernel has the GPU to itself.  With several frames in
     # flight a launch's HIP-event bracket also contains the time it queued behind / shared CUs with the neighbouring frames'
-    # kernels (k_shadow_trace: ~6 ms bracket, 3.5 ms dispatch begin->end in rocprof, 2.93 ms alone), so the per-kernel cost
+    # kernels (k_shadow_trace4: 2.7 ms bracket, 2.1 ms dispatch begin->end in rocprof, 1.86 ms alone), so the per-kernel cost
     # and the roofline are taken from this pass; rocprofv3 of `--frames-in-flight 1` reproduces it (profiles/).
     kern_iso, iso_ms_per_frame = None, None
     if nbuf > 1 and args.isolated_frames > 0:
@@ -284,7 +284,7 @@ def main():
                     valu = tj.get(key, {}).get("k_shadow_trace_valu_wave_insts_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_shadow_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": "k_shadow_trace4 (+ k_shadow_tail; the any-hit traversal of the shadow-ray queue)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_COPY_GBS, 5),
                         "hbm_frac": round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
