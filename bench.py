@@ -54,8 +54,8 @@ def main():
     ap.add_argument("--accumulate", type=int, default=1, metavar="K",
                     help="a step = K frames (frame = 0..K-1) summed in the float HDR buffer and tonemapped once (BASELINE config 5: "
                          "--width 3840 --height 2160 --accumulate 16)")
-    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
-                    help="shortcut for a BASELINE.json config: 2 cornell 1080p, 3 bunny_class 1080p 4 spp, 4 (default) sponza_class 1080p, "
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="shortcut for a BASELINE.json config: 1 cornell 256x256 (the reference's CPU-runnable case), 2 cornell 1080p, 3 bunny_class 1080p 4 spp, 4 (default) sponza_class 1080p, "
                          "5 sponza_class 4K x16 accumulated")
     ap.add_argument("--isolated-frames", type=int, default=10,
                     help="after the timed region, render this many frames ONE AT A TIME to report per-kernel durations free of "
@@ -63,7 +63,9 @@ def main():
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
     args = ap.parse_args()
 
-    if args.config == 2:
+    if args.config == 1:
+        args.workload, args.width, args.height = "cornell", 256, 256
+    elif args.config == 2:
         args.workload = "cornell"
     elif args.config == 3:
         args.workload, args.spp = "bunny_class", 4
