@@ -1018,7 +1018,12 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     /* persistent waves: as many workgroups as stay resident (16 KiB of LDS stack per workgroup -> 8 per CU, the
      * 32-wave hardware maximum), each pulling batches until the queue is empty */
     const size_t maxRays = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
-    uint32_t tblocks = 256u * 8u;         /* leaving wave slots free for the other frames' kernels (6-7 per CU) bought no throughput */
+    /* 8 workgroups per CU fill every wave slot, which is what a long queue wants; the short queue of a 1/4 or 1/8 shard is
+     * drained in a fraction of a millisecond, and then the other frames' small kernels (which can only start where a persistent
+     * wave has retired) matter more: with 6 per CU one rank of 8 renders a frame in 0.394 instead of 0.418 ms and one rank of 4 in
+     * 0.693 instead of 0.708 (4 frames in flight, profiles/r01/sweep_wgs_per_cu.log); at N = 1, 2 it makes no difference */
+    static const uint32_t kWgsPerCu = env_u32("RTR_TRACE_WGS_PER_CU", 0u, 0u, 8u);
+    uint32_t tblocks = 256u * (kWgsPerCu ? kWgsPerCu : (maxRays >= kBinnedMinRays ? 8u : 6u));
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
