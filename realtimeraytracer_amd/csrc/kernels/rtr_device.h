@@ -24,7 +24,7 @@ namespace rtrdev {
 
 struct DeviceTexture { const uint8_t* pixels; uint32_t width, height, channels, _pad; };
 
-constexpr uint32_t kLightTriRecord = 6;     /* float4s per light-triangle record */
+constexpr uint32_t kLightTriRecord = 4;     /* float4s per light-triangle record */
 
 struct DeviceScene {
     const uint4* nodes;              /* RtrBvhNode (layout version 3) as 2 x uint4 */
@@ -36,7 +36,7 @@ struct DeviceScene {
     const uint32_t* indices;
     const RtrObjectInfo* objects;
     const RtrAreaLightInfo* lights;
-    const float4* lightTris;         /* per light triangle, kLightTriRecord x float4: {P0, area} {P1, pdf} {P2, -} {unit normal, -} {min corner, -} {max corner, -} in world space (k_light_tris) */
+    const float4* lightTris;         /* per light triangle, kLightTriRecord x float4: {P0, area} {P1, pdf} {P2, -} {unit normal, -} in world space (k_light_tris) */
     const uint32_t* lightTriFirst;   /* first record of light l */
     const float* xforms;             /* 12 floats (3x4 row-major object->world) per customIndex */
     const float* nmats;              /* 12 floats (9 used: transpose(inverse(mat3))) per customIndex */
@@ -537,21 +537,6 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
             if (!twoSided) {
                 if (rtr_dot(lightNormal, rtr_sub(hitPoint, P[0])) < 0.0f) continue;
             }
-            if constexpr (Policy::kOctantOnly) {
-                /* counting pass of the octant-binned queue: a surface point that lies clear of the light triangle's bounding box on
-                 * every axis sees all its samples in one octant — no need to draw them.  The margin is far above the rounding
-                 * of the sample position, so this never disagrees with the per-sample signs the emission pass takes. */
-                const float4 bmn = rec[4], bmx = rec[5];
-                const float mx = rtr_max(rtr_max(bmx.x - bmn.x, bmx.y - bmn.y), bmx.z - bmn.z) * 1.0e-3f +
-                                 (rtr_abs(bmn.x) + rtr_abs(bmx.x) + rtr_abs(bmn.y) + rtr_abs(bmx.y) + rtr_abs(bmn.z) + rtr_abs(bmx.z)) * 1.0e-5f;
-                const bool px_ = hitPoint.x < bmn.x - mx, nx_ = hitPoint.x > bmx.x + mx;
-                const bool py_ = hitPoint.y < bmn.y - mx, ny_ = hitPoint.y > bmx.y + mx;
-                const bool pz_ = hitPoint.z < bmn.z - mx, nz_ = hitPoint.z > bmx.z + mx;
-                if ((px_ || nx_) && (py_ || ny_) && (pz_ || nz_)) {
-                    pol.add((nx_ ? 1u : 0u) | (ny_ ? 2u : 0u) | (nz_ ? 4u : 0u), ra.numShadowRays);
-                    continue;
-                }
-            }
             rtr_v3 shadowedSample = rtr_mk(0, 0, 0), unshadowedSample = rtr_mk(0, 0, 0);
             for (uint32_t s = 0; s < ra.numShadowRays; ++s) {                             /* :206 */
                 const uint32_t seed = s + px * 733u + py * 1933u + ra.info.frame;
@@ -654,8 +639,6 @@ __device__ __forceinline__ void light_tri_record(const RtrAreaLightInfo* L, cons
     rec[1] = make_float4(P[1].x, P[1].y, P[1].z, pdf);
     rec[2] = make_float4(P[2].x, P[2].y, P[2].z, 0.f);
     rec[3] = make_float4(lightNormal.x, lightNormal.y, lightNormal.z, 0.f);
-    rec[4] = make_float4(rtr_min(rtr_min(P[0].x, P[1].x), P[2].x), rtr_min(rtr_min(P[0].y, P[1].y), P[2].y), rtr_min(rtr_min(P[0].z, P[1].z), P[2].z), 0.f);
-    rec[5] = make_float4(rtr_max(rtr_max(P[0].x, P[1].x), P[2].x), rtr_max(rtr_max(P[0].y, P[1].y), P[2].y), rtr_max(rtr_max(P[0].z, P[1].z), P[2].z), 0.f);
 }
 
 /* One primary sample's contribution: reference raygen.rgen:110-338 (+ closesthit.rchit:45-110, miss.rmiss:15-27). */

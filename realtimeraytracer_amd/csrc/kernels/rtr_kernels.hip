@@ -28,7 +28,7 @@ constexpr int kBlock = 256;
 
 template <bool STATS, int STACK>
 struct InlinePolicy {
-    static constexpr bool kShade = true, kOctantOnly = false;
+    static constexpr bool kShade = true;
     const DeviceScene& sc; int32_t* stack; LocalStats& st;
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
         HitRec h;
@@ -48,13 +48,13 @@ struct InlinePolicy {
  * Entries of one emission step are contiguous, so k_shadow_trace's waves get rays of neighbouring
  * pixels aimed at the same light triangle / sample index. */
 struct CountPolicy {
-    static constexpr bool kShade = false, kOctantOnly = false;
+    static constexpr bool kShade = false;
     uint32_t n;
     __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { ++n; return false; }
 };
 
 struct EmitPolicy {
-    static constexpr bool kShade = false, kOctantOnly = false;
+    static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;     /* keeps the access a ds_read/ds_write, not a flat_load */
     float4* queue; lds_word waveOffset; uint32_t base; uint32_t slot;
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
@@ -71,7 +71,7 @@ struct EmitPolicy {
 };
 
 struct LookupPolicy {
-    static constexpr bool kShade = true, kOctantOnly = false;
+    static constexpr bool kShade = true;
     const uint8_t* vis; uint32_t slot;
     __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { return vis[slot++] != 0; }
 };
@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t raw_octant(rtr_v3 r) {
 }
 
 struct CountOctPolicy {
-    static constexpr bool kShade = false, kOctantOnly = true;     /* kOctantOnly: light_loops may count a whole light triangle at once */
+    static constexpr bool kShade = false;
     unsigned long long lo, hi;                 /* eight 16-bit counters: octants 0-3, 4-7 */
     __device__ __forceinline__ void add(uint32_t oct, uint32_t n) {
         const unsigned long long v = (unsigned long long)n << ((oct & 3u) * 16u);
@@ -96,7 +96,7 @@ struct CountOctPolicy {
 };
 
 struct EmitOctPolicy {
-    static constexpr bool kShade = false, kOctantOnly = false;
+    static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;
     float4* queue; lds_word run; uint32_t slot;         /* run[o]: next queue index of this wave's part of the octant-o run */
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw) {
