@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 1
+#define RTR_ABI_VERSION 2
 
 typedef enum rtr_status {
     RTR_OK = 0,
@@ -122,6 +122,9 @@ typedef struct rtr_scene_stats {
     float    boxPad;
     float    _pad;
     RtrBvhGrid grid;          /* the 16-bit planes of the exported nodes live on this grid (rewritten by a refit) */
+    uint32_t numWideNodes;    /* RtrWideNode records of the wide view (rtr_scene_export_wide); 0 from rtr_host_build_bvh */
+    uint32_t wideLayoutVersion;
+    uint32_t _pad2[2];
 } rtr_scene_stats;
 
 /* Per-dispatch arguments: what the reference passes as the traceRaysKHR extent + the two
@@ -158,7 +161,7 @@ typedef struct rtr_frame_stats {
     /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
     uint64_t numShadowNodeVisits;
     uint64_t numShadowTriTests;
-    uint64_t shadowTraceBytes; /* 32 N_node_shadow + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
+    uint64_t shadowTraceBytes; /* 64 N_node_shadow (RTR_WIDE_NODE_BYTES: visits of wide nodes) + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
     /* timings of the last render (HIP events on the render stream), milliseconds */
     float    totalMs;
     float    primaryMs;        /* k_primary (wavefront) or the whole megakernel */
@@ -168,6 +171,13 @@ typedef struct rtr_frame_stats {
     uint32_t localRows;        /* rows this shard rendered */
     uint32_t localPixels;
     uint32_t pipelineUsed;     /* 1 megakernel, 2 wavefront */
+    float    shadowTraceClockMHz; /* shader clock the any-hit launch ran at: s_memtime ticks / s_memrealtime (100 MHz) ticks, median of one wave per XCD */
+    /* scheduling of the any-hit kernel, from its counting form (collectStats = 1): loop trips of its node and triangle phases,
+     * summed over waves, and the lanes that had work in those trips (lane utilisation = lanes / (64 trips)) */
+    uint64_t shadowInnerIterations, shadowInnerActiveLanes;
+    uint64_t shadowTriIterations, shadowTriActiveLanes;
+    uint64_t shadowRefills;
+    uint64_t shadowTailRays;   /* rays that outgrew the 16-entry LDS stack and were finished by k_shadow_tail (their work is not in the counters) */
 } rtr_frame_stats;
 
 /* ---- context -------------------------------------------------------------------------- */
@@ -189,6 +199,10 @@ int  rtr_scene_get_stats(const rtr_scene* scene, rtr_scene_stats* out);
 /* Copy out the device BVH arrays (test / oracle hook; sizes and the plane grid from rtr_scene_get_stats). */
 int  rtr_scene_export_bvh(const rtr_scene* scene, RtrBvhNode* nodes, size_t nodeBytes,
                           RtrBvhTri* tris, size_t triBytes);
+/* Copy out the wide view (layout RTR_WIDE_LAYOUT_VERSION): numWideNodes records and their sparse triangle array
+ * (16 places per node; places whose triMask bit is clear are zero).  Test / oracle hook: the oracle restates the any-hit
+ * kernel's walk over these arrays to check its work counters. */
+int  rtr_scene_export_wide(const rtr_scene* scene, RtrWideNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes);
 /* Host-only BVH build (no device needed): validates `desc`, flattens and builds exactly as
  * rtr_scene_create does and copies the result out.  Call with nodes == tris == NULL to get the counts
  * in `stats`.  Used by the CPU-side tests (BVH invariants, oracle BVH-vs-brute-force). */

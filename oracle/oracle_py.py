@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 class oracle_scene(C.Structure):
     _fields_ = [("desc", A.rtr_scene_desc), ("nodes", C.POINTER(A.RtrBvhNode)), ("numNodes", A.u32),
-                ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid)]
+                ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid),
+                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("wideTris", C.POINTER(A.RtrBvhTri))]
 
 
 class oracle_out(C.Structure):
@@ -72,6 +73,11 @@ def make_scene(desc, bvh=None):
     s.desc = desc
     if bvh is not None:
         nodes, tris, grid = bvh
+        wide = getattr(bvh, "wide", None)
+        if wide is not None:
+            s.wide = C.cast(wide[0], C.POINTER(A.RtrWideNode))
+            s.numWide = len(wide[0])
+            s.wideTris = C.cast(wide[1], C.POINTER(A.RtrBvhTri))
         s.grid = grid
         s.nodes = C.cast(nodes, C.POINTER(A.RtrBvhNode))
         s.numNodes = len(nodes)

@@ -59,6 +59,13 @@ class RtrBvhTri(C.Structure):
     _fields_ = [("v0", f32 * 3), ("customIndex", u32), ("e1", f32 * 3), ("primitiveId", u32), ("e2", f32 * 3), ("flags", u32)]
 
 
+class RtrWideNode(C.Structure):
+    _fields_ = [("plane", (u32 * 3) * 4), ("origin", C.c_uint16 * 3), ("_reserved", C.c_uint16), ("link", u32), ("triMask", u32)]
+
+
+WIDE_TRI_PLACES = 32
+
+
 class rtr_texture(C.Structure):
     _fields_ = [("pixels", C.POINTER(C.c_uint8)), ("width", u32), ("height", u32), ("channels", u32), ("_pad", u32)]
 
@@ -79,7 +86,8 @@ class rtr_scene_desc(C.Structure):
 class rtr_scene_stats(C.Structure):
     _fields_ = [("numTriangles", u32), ("numNodes", u32), ("maxDepth", u32), ("maxLeafSize", u32),
                 ("bvhLayoutVersion", u32), ("stackEntries", u32), ("buildMs", f32), ("sahCost", f32),
-                ("boundsMin", f32 * 3), ("boundsMax", f32 * 3), ("boxPad", f32), ("_pad", f32), ("grid", RtrBvhGrid)]
+                ("boundsMin", f32 * 3), ("boundsMax", f32 * 3), ("boxPad", f32), ("_pad", f32), ("grid", RtrBvhGrid),
+                ("numWideNodes", u32), ("wideLayoutVersion", u32), ("_pad2", u32 * 2)]
 
 
 class rtr_render_params(C.Structure):
@@ -93,12 +101,14 @@ class rtr_frame_stats(C.Structure):
                 ("numTriTests", u64), ("numHits", u64), ("numLightFetches", u64), ("numLightTriFetches", u64),
                 ("numTexFetches", u64), ("numAlphaTests", u64), ("algorithmicBytes", u64), ("numShadowNodeVisits", u64), ("numShadowTriTests", u64), ("shadowTraceBytes", u64),
                 ("totalMs", f32), ("primaryMs", f32), ("shadowGenMs", f32), ("shadowTraceMs", f32), ("resolveMs", f32),
-                ("localRows", u32), ("localPixels", u32), ("pipelineUsed", u32)]
+                ("localRows", u32), ("localPixels", u32), ("pipelineUsed", u32), ("shadowTraceClockMHz", f32),
+                ("shadowInnerIterations", u64), ("shadowInnerActiveLanes", u64), ("shadowTriIterations", u64), ("shadowTriActiveLanes", u64),
+                ("shadowRefills", u64), ("shadowTailRays", u64)]
 
 
 assert C.sizeof(RtrVertex) == 48 and C.sizeof(RtrCameraData) == 64 and C.sizeof(RtrSceneInfo) == 32
 assert C.sizeof(RtrObjectInfo) == 80 and C.sizeof(RtrAreaLightInfo) == 96
-assert C.sizeof(RtrBvhNode) == 32 and C.sizeof(RtrBvhGrid) == 32 and C.sizeof(RtrBvhTri) == 48
+assert C.sizeof(RtrBvhNode) == 32 and C.sizeof(RtrBvhGrid) == 32 and C.sizeof(RtrBvhTri) == 48 and C.sizeof(RtrWideNode) == 64
 
 # enum rtr_image
 IMAGE_ANALYTIC, IMAGE_SHADOWED, IMAGE_UNSHADOWED = 0, 1, 2
@@ -128,6 +138,7 @@ RTR_SYMBOLS = {
     "rtr_scene_destroy": (None, [VP]),
     "rtr_scene_get_stats": (C.c_int, [VP, P(rtr_scene_stats)]),
     "rtr_scene_export_bvh": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
+    "rtr_scene_export_wide": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_host_build_bvh": (C.c_int, [P(rtr_scene_desc), P(rtr_scene_stats), VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_scene_update_lights": (C.c_int, [VP, P(RtrAreaLightInfo), u32]),
     "rtr_scene_update_instances": (C.c_int, [VP, P(RtrInstance), u32, P(RtrAreaLightInfo), u32]),

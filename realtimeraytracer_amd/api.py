@@ -47,6 +47,11 @@ class Context:
             pass
 
 
+class BvhExport(tuple):
+    """(nodes, tris, grid) of rtr_scene_export_bvh, with the wide view of rtr_scene_export_wide as .wide = (wnodes, wtris)"""
+    wide = None
+
+
 class Scene:
     def __init__(self, ctx, desc):
         self.ctx, self.lib = ctx, ctx.lib
@@ -65,7 +70,13 @@ class Scene:
         ntri = max(s.numTriangles, 1)
         tris = (A.RtrBvhTri * ntri)()
         _check(self.lib.rtr_scene_export_bvh(self.h, nodes, C.sizeof(nodes), tris, C.sizeof(tris)), "rtr_scene_export_bvh")
-        return nodes, tris, s.grid      # the nodes' 16-bit planes live on s.grid
+        out = BvhExport((nodes, tris, s.grid))      # the nodes' 16-bit planes live on s.grid
+        if s.numWideNodes:
+            wn = (A.RtrWideNode * s.numWideNodes)()
+            wt = (A.RtrBvhTri * (A.WIDE_TRI_PLACES * s.numWideNodes))()
+            _check(self.lib.rtr_scene_export_wide(self.h, wn, C.sizeof(wn), wt, C.sizeof(wt)), "rtr_scene_export_wide")
+            out.wide = (wn, wt)
+        return out
 
     def update_instances(self, instances, lights=None):
         """rtr_scene_update_instances: new transforms (+ optional light infos) -> device-side re-flatten + BVH refit."""

@@ -9,7 +9,7 @@ constexpr uint32_t kQueueRegions = 8;                       /* one batch cursor 
 constexpr uint32_t kQueueLists = kQueueRegions * kQueueRegions;        /* batch lists of the binned queue: (direction octant, consumer XCD) */
 constexpr uint32_t kQueueListLens = 16 + 16 * kQueueLists;            /* first word of the list lengths (read-only while the queue drains) */
 constexpr uint32_t kQueueCtrlWords = kQueueListLens + kQueueLists;
-static_assert(kQueueLists == 64, "k_shadow_trace4 snapshots the list cursors with one lane per list");
+static_assert(kQueueLists == 64, "k_shadow_gen_oct reserves the batch lists with one lane per list");
 
 /* Scratch of the wavefront (staged) pipeline, owned by an rtr_frame. */
 struct Workspace {
@@ -21,6 +21,7 @@ struct Workspace {
     uint2*    batchLists = nullptr;  /* kQueueLists lists of listStride batches {first queue index, rays}: the queue binned by direction octant */
     uint32_t  listStride = 0;
     uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail (capacity: one per slot) */
+    unsigned long long* clk = nullptr;   /* 2 x kQueueRegions words: {shader-clock ticks, 100-MHz ticks} of the any-hit launch, one wave per XCD */
     int32_t*  spill = nullptr;       /* traversal-stack overflow of k_shadow_trace: 48 entries x (2048 workgroups x 256 lanes) */
     size_t    capPixelSamples = 0;
     size_t    capRays = 0;
@@ -33,7 +34,7 @@ hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const 
 /* Staged pipeline: primary trace -> shadow-ray generation (ballot-compacted queue) -> any-hit trace
  * -> resolve.  `ev` (5 events, may be null) are recorded between stages for per-stage timing. */
 hipError_t launch_wavefront(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, const Workspace& ws,
-                            int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev);
+                            int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev, uint32_t numCus);
 
 /* fills DeviceScene::lightTris (4 x float4 per light triangle, light l from first[l]); after create and after light transforms change */
 hipError_t launch_light_tris(const RtrAreaLightInfo* lights, const RtrVertex* vertices, const uint32_t* indices, const uint32_t* first,

@@ -72,6 +72,7 @@ struct rtr_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     hipDeviceProp_t prop;
+    int numXccs = 0;                     /* hipDeviceAttributeNumberOfXccs: the kernels cut their queues into kQueueRegions = 8 parts, one per XCD of an MI355X in SPX mode; with another count the mapping is merely less local, never wrong */
     /* scenes and frames keep a pointer to their context: a context destroyed while it still has children lives on,
      * unusable, until the last child is gone (garbage-collected bindings destroy objects in any order) */
     int children = 0;
@@ -95,7 +96,9 @@ struct rtr_scene {
     DevBuf<uint4> nodes4tmp;             /* the 4-wide entries in BVH2-id order, before the breadth-first permutation */
     DevBuf<uint32_t> wideRemap;
     uint32_t wideReached = 0;            /* entries the 4-wide tree reaches (they come first in nodes4) */
-    DevBuf<uint4> nodes4;                /* 4-wide view of the tree for the any-hit kernel, 4 x uint4 per BVH2 node id (kernels/rtr_bvh.hip) */
+    DevBuf<uint4> wnodes;                /* RtrWideNode x wideReached: the wide view of the tree the any-hit kernel walks (kernels/rtr_bvh.hip) */
+    DevBuf<float4> wtris;                /* its sparse triangle array: 16 places of 3 x float4 per wide node */
+    DevBuf<uint32_t> wideFail;
     DevBuf<float4> tris;
     DevBuf<RtrVertex> vertices;
     DevBuf<uint32_t> indices;
@@ -140,6 +143,7 @@ struct rtr_frame {
     DevBuf<int32_t> spill;
     DevBuf<uint32_t> overflow;
     DevBuf<uint2> batchLists;
+    DevBuf<unsigned long long> clk;
     uint32_t listStride = 0;
     DevBuf<Counters> counters;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -193,6 +197,7 @@ int rtr_ctx_create(int ordinal, rtr_ctx** out) {
     c->device = ordinal;
     e = hipGetDeviceProperties(&c->prop, ordinal);
     if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    if (hipDeviceGetAttribute(&c->numXccs, hipDeviceAttributeNumberOfXccs, ordinal) != hipSuccess) c->numXccs = 0;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->ownStream = true;
@@ -382,12 +387,13 @@ static int make_light_tris(rtr_scene* s) {
 
 static int make_wide_nodes(rtr_scene* s) {
     const uint32_t n = (uint32_t)s->hostNodes.size();
-    if (!s->nodes4.p) { HIP_TRY(s->nodes4.alloc((size_t)n * 4)); HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); }
+    if (!s->nodes4tmp.p) { HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); HIP_TRY(s->wideFail.alloc(1)); }
     hipStream_t st = s->ctx->stream;
     hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4tmp.p, st);
-    if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node build: %s", hipGetErrorString(e));
-    /* breadth-first order of the 4-wide tree (child codes = the 4th 16 bytes of every entry), so its top levels are the first
-     * entries: k_shadow_trace4 keeps those in LDS.  Entries the 4-wide tree does not reach keep the ids after them. */
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "wide node build: %s", hipGetErrorString(e));
+    /* breadth-first order of the wide tree (child codes = the 4th 16 bytes of every entry): the inner children of a node get
+     * consecutive numbers in slot order (RtrWideNode::link needs that) and the top levels are the first entries, which
+     * k_shadow_trace_w keeps in LDS.  Entries the wide tree does not reach are dropped. */
     std::vector<uint32_t> codes((size_t)n * 4), remap(n, 0xffffffffu), order;
     HIP_TRY(hipMemcpy2DAsync(codes.data(), 16, reinterpret_cast<const char*>(s->nodes4tmp.p) + 48, 64, 16, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -398,13 +404,24 @@ static int make_wide_nodes(rtr_scene* s) {
             const int32_t c = (int32_t)codes[(size_t)order[head] * 4 + k];
             if (c >= 0 && (uint32_t)c < n && remap[c] == 0xffffffffu) { remap[c] = (uint32_t)order.size(); order.push_back((uint32_t)c); }
         }
-    uint32_t next = (uint32_t)order.size();
-    for (uint32_t i = 0; i < n; ++i) if (remap[i] == 0xffffffffu) remap[i] = next++;
+    const uint32_t reached = (uint32_t)order.size();
+    if (reached >= RTR_WIDE_MAX_NODES) return fail(RTR_ERR_UNSUPPORTED, "scene too large: %u wide nodes (limit 2^24)", reached);
+    if (s->wnodes.n != (size_t)reached * 4) {
+        HIP_TRY(s->wnodes.alloc((size_t)reached * 4));
+        HIP_TRY(s->wtris.alloc((size_t)reached * RTR_WIDE_TRI_PLACES * 3));
+        HIP_TRY(hipMemsetAsync(s->wtris.p, 0, (size_t)reached * RTR_WIDE_TRI_PLACES * 3 * sizeof(float4), st));     /* unused places: never read (triMask) */
+    }
+    HIP_TRY(hipMemsetAsync(s->wideFail.p, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemcpyAsync(s->wideRemap.p, remap.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    e = rtrdev::bvh_permute_wide(s->nodes4tmp.p, n, s->wideRemap.p, s->nodes4.p, st);
-    if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node order: %s", hipGetErrorString(e));
+    e = rtrdev::bvh_encode_wide(s->nodes4tmp.p, n, reached, s->wideRemap.p, s->tris.p, s->wnodes.p, s->wtris.p, s->wideFail.p, st);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "wide node encode: %s", hipGetErrorString(e));
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, s->wideFail.p, sizeof bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    s->wideReached = (uint32_t)order.size();
+    if (bad) return fail(RTR_ERR_UNSUPPORTED, "wide node encode: %s", (bad & 1u) ? "a leaf holds more than 8 triangles" : "more than 2^24 wide nodes");
+    s->wideReached = reached;
+    s->stats.numWideNodes = reached; s->stats.wideLayoutVersion = RTR_WIDE_LAYOUT_VERSION;
+    s->dev.wnodes = s->wnodes.p; s->dev.wtris = s->wtris.p; s->dev.numWide = reached;
     return RTR_OK;
 }
 
@@ -563,7 +580,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     if (rc == RTR_OK) rc = make_light_tris(s);
     if (rc != RTR_OK) { delete s; ctx_release_child(ctx); return rc; }
     DeviceScene& dv = s->dev;
-    dv.nodes = s->nodes.p; dv.nodes4 = s->nodes4.p; dv.numNodes4 = (uint32_t)s->hostNodes.size(); dv.grid = s->grid.p; dv.tris = s->tris.p;
+    dv.nodes = s->nodes.p; dv.wnodes = s->wnodes.p; dv.wtris = s->wtris.p; dv.numWide = s->wideReached; dv.grid = s->grid.p; dv.tris = s->tris.p;
     dv.vertices = s->vertices.p; dv.indices = s->indices.p;
     dv.objects = s->objects.p; dv.lights = s->lights.p;
     dv.lightTris = s->lightTris.p; dv.lightTriFirst = s->lightTriFirst.p;
@@ -693,6 +710,20 @@ int rtr_scene_export_bvh(const rtr_scene* s, RtrBvhNode* nodes, size_t nodeBytes
     if (tris) {
         if (triBytes != s->hostTris.size() * sizeof(RtrBvhTri)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_bvh: triBytes %zu != %zu", triBytes, s->hostTris.size() * sizeof(RtrBvhTri));
         memcpy(tris, s->hostTris.data(), triBytes);
+    }
+    return RTR_OK;
+}
+
+int rtr_scene_export_wide(const rtr_scene* s, RtrWideNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes) {
+    if (!s) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: null scene");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    if (nodes) {
+        if (nodeBytes != (size_t)s->wideReached * sizeof(RtrWideNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: nodeBytes %zu != %zu", nodeBytes, (size_t)s->wideReached * sizeof(RtrWideNode));
+        HIP_TRY(hipMemcpy(nodes, s->wnodes.p, nodeBytes, hipMemcpyDeviceToHost));
+    }
+    if (tris) {
+        if (triBytes != (size_t)s->wideReached * RTR_WIDE_TRI_PLACES * sizeof(RtrBvhTri)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: triBytes %zu != %zu", triBytes, (size_t)s->wideReached * RTR_WIDE_TRI_PLACES * sizeof(RtrBvhTri));
+        HIP_TRY(hipMemcpy(tris, s->wtris.p, triBytes, hipMemcpyDeviceToHost));
     }
     return RTR_OK;
 }
@@ -864,11 +895,12 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
             f->listStride = (uint32_t)(nSlots / 64 / rtrdev::kQueueRegions + nPS / 256 + 16);
             HIP_TRY(f->batchLists.alloc((size_t)f->listStride * rtrdev::kQueueLists)); }
         if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(rtrdev::kQueueCtrlWords));
+        if (!f->clk.p) { HIP_TRY(f->clk.alloc(2 * rtrdev::kQueueRegions)); HIP_TRY(hipMemsetAsync(f->clk.p, 0, 2 * rtrdev::kQueueRegions * sizeof(unsigned long long), st)); }
         if (!f->spill.p) HIP_TRY(f->spill.alloc((size_t)48 * 2048 * 256));      /* (64 - 16) entries x the largest persistent grid */
         Workspace ws;
         ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
-        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride;
-        e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev);
+        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride; ws.clk = f->clk.p;
+        e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
     } else {
         (void)hipEventRecord(f->evMega[0], st);
         e = rtrdev::launch_megakernel(s->dev, ra, fo, (int)s->stats.stackEntries, dstats, st);
@@ -894,6 +926,14 @@ int rtr_frame_wait(rtr_frame* f) {
         (void)hipEventElapsedTime(&d, f->ev[3], f->ev[4]);
         s.primaryMs = a; s.shadowGenMs = b; s.shadowTraceMs = c; s.resolveMs = d; s.totalMs = a + b + c + d;
         s.pipelineUsed = 2;
+        if (f->clk.p) {      /* shader clock held during the any-hit launch: s_memtime ticks over 100-MHz ticks, median of one wave per XCD */
+            unsigned long long h[2 * rtrdev::kQueueRegions];
+            HIP_TRY(hipMemcpy(h, f->clk.p, sizeof h, hipMemcpyDeviceToHost));
+            float mhz[rtrdev::kQueueRegions]; int nv = 0;
+            for (uint32_t r = 0; r < rtrdev::kQueueRegions; ++r) if (h[2 * r + 1]) mhz[nv++] = (float)((double)h[2 * r] / (double)h[2 * r + 1] * 100.0);
+            for (int i = 1; i < nv; ++i) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; --j) { const float t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }
+            s.shadowTraceClockMHz = nv ? mhz[nv / 2] : 0.f;
+        }
     } else {
         float a = 0;
         (void)hipEventElapsedTime(&a, f->evMega[0], f->evMega[1]);
@@ -908,8 +948,12 @@ int rtr_frame_wait(rtr_frame* f) {
         s.numLightFetches = h.lightFetch; s.numLightTriFetches = h.lightTriFetch;
         s.numShadowNodeVisits = h.shadowNodes; s.numShadowTriTests = h.shadowTris;
         s.numTexFetches = h.texFetch; s.numAlphaTests = h.alphaTests;
-        s.shadowTraceBytes = (uint64_t)RTR_BVH_NODE_BYTES * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
-        s.algorithmicBytes = (uint64_t)RTR_BVH_NODE_BYTES * h.nodes + 48ull * h.tris + 236ull * (h.hits + h.alphaTests) + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
+        const uint64_t shadowNodeBytes = f->pendingWave ? RTR_WIDE_NODE_BYTES : RTR_BVH_NODE_BYTES;     /* the megakernel walks the BVH2 for its shadow rays too */
+        s.shadowTraceBytes = shadowNodeBytes * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
+        s.shadowInnerIterations = h.innerIters; s.shadowInnerActiveLanes = h.innerLanes;
+        s.shadowTriIterations = h.triIters; s.shadowTriActiveLanes = h.triLanes; s.shadowRefills = h.refills;
+        if (f->overflow.p) { uint32_t ov = 0; HIP_TRY(hipMemcpy(&ov, f->overflow.p, sizeof ov, hipMemcpyDeviceToHost)); s.shadowTailRays = ov; }
+        s.algorithmicBytes = (uint64_t)RTR_BVH_NODE_BYTES * (h.nodes - h.shadowNodes) + shadowNodeBytes * h.shadowNodes + 48ull * h.tris + 236ull * (h.hits + h.alphaTests) + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
                              16ull * h.texFetch +
                              4ull * f->pendingImagesK * s.localPixels + (f->pendingHdr ? (f->pendingAccum ? 32ull : 16ull) * s.localPixels : 0ull);
     }

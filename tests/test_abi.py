@@ -53,7 +53,7 @@ def test_pod_layouts_match_reference():
 
 def test_abi_version_and_status_strings():
     lib = A.hip_lib()
-    assert lib.rtr_abi_version() == 1
+    assert lib.rtr_abi_version() == 2
     assert lib.rtr_status_string(0) == b"RTR_OK"
     assert lib.rtr_status_string(-3) == b"RTR_ERR_NO_DEVICE"
     assert lib.rtr_status_string(-6) == b"RTR_ERR_BVH_TOO_DEEP"
