@@ -161,7 +161,7 @@ typedef struct rtr_frame_stats {
     /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
     uint64_t numShadowNodeVisits;
     uint64_t numShadowTriTests;
-    uint64_t shadowTraceBytes; /* 64 N_node_shadow (RTR_WIDE_NODE_BYTES: visits of wide nodes) + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
+    uint64_t shadowTraceBytes; /* 64 N_node_shadow (RTR_WIDE_NODE_BYTES: 4-wide records visited; 32 in the megakernel, which walks the BVH2) + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
     /* timings of the last render (HIP events on the render stream), milliseconds */
     float    totalMs;
     float    primaryMs;        /* k_primary (wavefront) or the whole megakernel */
@@ -177,7 +177,7 @@ typedef struct rtr_frame_stats {
     uint64_t shadowInnerIterations, shadowInnerActiveLanes;
     uint64_t shadowTriIterations, shadowTriActiveLanes;
     uint64_t shadowRefills;
-    uint64_t shadowTailRays;   /* rays that outgrew the 16-entry LDS stack and were finished by k_shadow_tail (their work is not in the counters) */
+    uint64_t shadowTailRays;   /* rays that outgrew the 16-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
 } rtr_frame_stats;
 
 /* ---- context -------------------------------------------------------------------------- */
@@ -199,10 +199,10 @@ int  rtr_scene_get_stats(const rtr_scene* scene, rtr_scene_stats* out);
 /* Copy out the device BVH arrays (test / oracle hook; sizes and the plane grid from rtr_scene_get_stats). */
 int  rtr_scene_export_bvh(const rtr_scene* scene, RtrBvhNode* nodes, size_t nodeBytes,
                           RtrBvhTri* tris, size_t triBytes);
-/* Copy out the wide view (layout RTR_WIDE_LAYOUT_VERSION): numWideNodes records and their sparse triangle array
- * (16 places per node; places whose triMask bit is clear are zero).  Test / oracle hook: the oracle restates the any-hit
- * kernel's walk over these arrays to check its work counters. */
-int  rtr_scene_export_wide(const rtr_scene* scene, RtrWideNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes);
+/* Copy out the 4-wide view the any-hit kernel walks (RtrWideNode, layout RTR_WIDE_LAYOUT_VERSION): numWideNodes records; their
+ * leaf codes index the triangle array of rtr_scene_export_bvh.  Test / oracle hook: the oracle restates the kernel's walk over
+ * it to check the kernel's work counters. */
+int  rtr_scene_export_wide(const rtr_scene* scene, RtrWideNode* nodes, size_t nodeBytes);
 /* Host-only BVH build (no device needed): validates `desc`, flattens and builds exactly as
  * rtr_scene_create does and copies the result out.  Call with nodes == tris == NULL to get the counts
  * in `stats`.  Used by the CPU-side tests (BVH invariants, oracle BVH-vs-brute-force). */

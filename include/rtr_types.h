@@ -114,12 +114,12 @@ typedef struct RtrInstance {
  *   i.e. as 32-bit words: (lminx|lminy<<16) (lmaxx|lmaxy<<16) (rminx|rminy<<16) (rmaxx|rmaxy<<16) (lminz|lmaxz<<16)
  *   (rminz|rmaxz<<16) — the pairing lets one packed FMA decode-and-slab two planes.
  *   child[0], child[1]: >= 0 -> index of an inner node;
- *                       <  0 -> leaf: code = ~child; first = code >> 3; count = (code & 7) + 1 (<= RTR_BVH_MAX_LEAF)
+ *                       <  0 -> leaf: code = ~child; first = code >> 3; count = (code & 7) + 1
  *   The root is always an inner node: a scene with a single leaf stores that leaf as BOTH children (testing a
  *   triangle twice cannot change the (t, id)-minimal hit); an empty scene holds one degenerate triangle.
  */
 #define RTR_BVH_LAYOUT_VERSION 3
-#define RTR_BVH_MAX_LEAF 8      /* triangles per leaf: a leaf is one slot of an RtrWideNode, whose triangle block has 8 places per slot */
+#define RTR_BVH_MAX_LEAF 8
 #define RTR_BVH_NODE_BYTES 32   /* bytes a node visit fetches (the N_node coefficient of the algorithmic-byte formulas) */
 typedef struct RtrBvhNode {
     uint16_t q[12];
@@ -133,34 +133,22 @@ typedef struct RtrBvhGrid {
     float scale[3];  float _pad1;
 } RtrBvhGrid;
 
-/* ---- wide view of the same tree, layout W4.1: what the any-hit kernel walks (k_shadow_trace_w) -------------------------
- * A 64-B record holds up to four children of a collapsed subtree of the BVH2 (greedy: open the inner child with the largest
- * box while a slot is free).  Planes are HALF-FLOATS: the offset of the plane from the node's own origin, in steps of the
- * scene grid, rounded outward (min planes down, max planes up) to the 11 significant bits of an f16 — exact up to 2048
- * steps from the origin and to 2^-11 of the offset beyond, i.e. finer than the 16-bit grid wherever the node is small.
- * So a plane's parameter on a ray is ONE instruction, t = fma(f16 plane, ga, gbN) with v_fma_mix_f32 (no conversion), after
- * gbN = fma(origin, ga, gb) per axis per visit (ga, gb: rtr_ray_grid).  Boxes only have to be conservative.
- *   plane[k][axis]   : slot k (0..3), axis 0..2: low half = min plane, high half = max plane.
- *                      An empty slot holds min = 65504, max = 0: no ray can hit it.
- *   origin[3]        : 16-bit scene-grid coordinates of the node's min corner
- *   triMask          : bit 8 k + j set <=> triangle j of slot k exists (slot k is a leaf with more than j triangles);
- *                      its record is wtris[32 * nodeIndex + 8 k + j] (a sparse array: every node owns 32 places)
- *   link             : firstInnerChild << 8 | innerMask << 4.  innerMask bit k <=> slot k is an inner node; the inner children
- *                      of a node are consecutive, in slot order, from firstInnerChild (breadth-first numbering).  `link | hits`
- *                      (hits = the inner slots a ray still has to enter, bits 0..3) is one traversal-stack entry.
- * Node 0 is the root; indices < 2^24.
+/* ---- 4-wide view of the same tree (layout W4.0): what the any-hit kernel walks (k_shadow_trace4) ---------------------------
+ * One 64-B record = a collapsed subtree of the BVH2 (greedy: open the inner child with the largest box while a slot is free):
+ * up to four child boxes on the same 16-bit scene grid and their four child codes, so a ray makes about half as many DEPENDENT
+ * visits.  Records are in breadth-first order (the first ones are the top levels, which the kernel keeps in LDS); record 0 is
+ * the root.  Built on the device after every build / refit (kernels/rtr_bvh.hip: k_wide_nodes, k_permute_wide).
+ *   plane[k] : slot k: (xmin | ymin << 16) (xmax | ymax << 16) (zmin | zmax << 16)
+ *   child[k] : >= 0 index of a record of this array; < 0 leaf code as in RtrBvhNode (triangles in the same leaf-ordered array);
+ *              0x80000000 = empty slot (slots 0 and 1 are never empty)
  */
-#define RTR_WIDE_LAYOUT_VERSION 42
+#define RTR_WIDE_LAYOUT_VERSION 40
 #define RTR_WIDE_NODE_BYTES 64
-#define RTR_WIDE_MAX_NODES (1u << 24)
+#define RTR_WIDE_EMPTY ((int32_t)0x80000000)
 typedef struct RtrWideNode {
     uint32_t plane[4][3];
-    uint16_t origin[3];
-    uint16_t _reserved;
-    uint32_t link;
-    uint32_t triMask;
+    int32_t  child[4];
 } RtrWideNode;
-#define RTR_WIDE_TRI_PLACES 32  /* places of the sparse triangle array per wide node */
 
 /* 48-B world-space Moeller-Trumbore record, in BVH leaf order.
  * v0 / e1 = v1-v0 / e2 = v2-v0 in world space; the three w slots carry the ids the

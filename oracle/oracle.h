@@ -29,13 +29,12 @@ typedef struct oracle_scene {
     const RtrBvhNode* nodes;  uint32_t numNodes;
     const RtrBvhTri*  tris;   uint32_t numTris;
     RtrBvhGrid grid;              /* the grid the nodes' 16-bit planes live on (rtr_scene_stats.grid) */
-    /* Optional wide view exported by the product (rtr_scene_export_wide).  When given (and params.pipeline != 1: the megakernel
-     * walks the BVH2 for its shadow rays too), shadow rays are walked over it exactly as k_shadow_trace_w does — slot order, one
-     * stack entry per node, triangles of the hit leaf slots in place order — so that the any-hit work counters
-     * (numShadowNodeVisits = 64-B wide-node visits, numShadowTriTests) can be held equal to the kernel's.  The visibility of a
-     * ray does not depend on which structure is walked (tests compare all of them with the brute-force mode). */
+    /* Optional 4-wide view exported by the product (rtr_scene_export_wide).  When given (and params.pipeline != 1: the megakernel
+     * walks the BVH2 for its shadow rays too), shadow rays are walked over it exactly as k_shadow_trace4 does — nearest hit child
+     * first, ties to the lower slot, the others stacked in slot order, a leaf's triangles in storage order — so that the any-hit
+     * work counters (numShadowNodeVisits = 64-B records visited, numShadowTriTests) can be held equal to the kernel's.  The
+     * visibility of a ray does not depend on which structure is walked (tests compare all of them with the brute-force mode). */
     const RtrWideNode* wide;  uint32_t numWide;
-    const RtrBvhTri*  wideTris;   /* RTR_WIDE_TRI_PLACES places per wide node */
 } oracle_scene;
 
 typedef struct oracle_out {

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 class oracle_scene(C.Structure):
     _fields_ = [("desc", A.rtr_scene_desc), ("nodes", C.POINTER(A.RtrBvhNode)), ("numNodes", A.u32),
                 ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid),
-                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("wideTris", C.POINTER(A.RtrBvhTri))]
+                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32)]
 
 
 class oracle_out(C.Structure):
@@ -75,9 +75,8 @@ def make_scene(desc, bvh=None):
         nodes, tris, grid = bvh
         wide = getattr(bvh, "wide", None)
         if wide is not None:
-            s.wide = C.cast(wide[0], C.POINTER(A.RtrWideNode))
-            s.numWide = len(wide[0])
-            s.wideTris = C.cast(wide[1], C.POINTER(A.RtrBvhTri))
+            s.wide = C.cast(wide, C.POINTER(A.RtrWideNode))
+            s.numWide = len(wide)
         s.grid = grid
         s.nodes = C.cast(nodes, C.POINTER(A.RtrBvhNode))
         s.numNodes = len(nodes)

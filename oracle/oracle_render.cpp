@@ -176,77 +176,62 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
     return best;
 }
 
-/* IEEE binary16 -> binary32 (exact), no compiler support needed */
-inline float half_bits_to_float(uint32_t h) {
-    const uint32_t e = (h >> 10) & 31u, m = h & 1023u, sgn = (h & 0x8000u) << 16;
-    uint32_t u;
-    if (e == 0) {
-        if (m == 0) u = sgn;
-        else { int sh = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; ++sh; } u = sgn | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13); }
-    } else if (e == 31) u = sgn | 0x7f800000u | (m << 13);
-    else u = sgn | ((e + 112u) << 23) | (m << 13);
-    return rtr_u2f(u);
-}
-
-/* Any-hit walk over the wide view, restating k_shadow_trace_w (realtimeraytracer_amd/csrc/kernels/rtr_kernels.hip): per visit the
- * node frame gbn = fma(origin, ga, gb), per slot the slab test on fma(f16 plane, ga, gbn) (min / max form: equal to the kernel's
- * per-octant forms because the fma is monotone in the plane), hit slots -> one stack entry for the inner ones (link | hits) and a
- * triangle mask for the leaf ones; children entered in slot order, triangles tested in place order before the next visit. */
+/* Any-hit walk over the 4-wide view, restating k_shadow_trace4 / inner_nodes4 (realtimeraytracer_amd/csrc/kernels/rtr_kernels.hip):
+ * per visit the four slab tests on the scene grid (rtr_slab_q: the kernel's per-octant forms give the same bits), descend into
+ * the nearest child that is hit (strict <, so ties go to the lower slot), push the other hit children in slot order (skipping a
+ * code equal to the one entered, as the kernel's `c != next` does), test a leaf's triangles in storage order until one hits;
+ * 16 stack entries, beyond which the ray is redone over the BVH2 as k_shadow_tail does. */
 Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Counters& c) {
     const RtrWideNode* nodes = sc.s->wide;
-    const RtrBvhTri* tris = sc.s->wideTris;
+    const RtrBvhTri* tris = sc.s->tris;
     Hit best{}; best.hit = false; best.t = tmax;
     rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
     rtr_v3 ga, gb;
     rtr_ray_grid(o, idir, sc.s->grid.origin, sc.s->grid.scale, &ga, &gb);
-    uint32_t stack[256];
-    int sp = 0;
-    stack[0] = 0u;
-    int64_t cur = 0;
-    while (cur >= 0) {
-        const RtrWideNode& n = nodes[cur];
-        c.nodes++; c.shadowNodes++;
-        const rtr_v3 gbn = rtr_mk(rtr_fma((float)n.origin[0], ga.x, gb.x), rtr_fma((float)n.origin[1], ga.y, gb.y), rtr_fma((float)n.origin[2], ga.z, gb.z));
-        uint32_t hm = 0;
-        for (int k = 0; k < 4; ++k) {
-            const float gak[3] = {ga.x, ga.y, ga.z}, gbk[3] = {gbn.x, gbn.y, gbn.z};
-            float lo = tmin, hi = tmax, nr[3], fr[3];
-            for (int a = 0; a < 3; ++a) {
-                const float t0 = rtr_fma(half_bits_to_float(n.plane[k][a] & 0xffffu), gak[a], gbk[a]);
-                const float t1 = rtr_fma(half_bits_to_float(n.plane[k][a] >> 16), gak[a], gbk[a]);
-                nr[a] = rtr_hwmin(t0, t1); fr[a] = rtr_hwmax(t0, t1);
+    std::vector<int32_t> stack;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const RtrWideNode& n = nodes[cur];
+            c.nodes++; c.shadowNodes++;
+            int hit[4]; float te[4];
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t wmin = n.plane[k][0], wmax = n.plane[k][1], wz = n.plane[k][2];
+                hit[k] = rtr_slab_q(wmin & 0xffffu, wmin >> 16, wz & 0xffffu, wmax & 0xffffu, wmax >> 16, wz >> 16, ga, gb, tmin, tmax, &te[k]);
+                if (k >= 2 && n.child[k] == RTR_WIDE_EMPTY) hit[k] = 0;
             }
-            lo = rtr_hwmax(rtr_hwmax(nr[0], nr[1]), rtr_hwmax(nr[2], tmin));
-            hi = rtr_hwmin(rtr_hwmin(fr[0], fr[1]), rtr_hwmin(fr[2], tmax));
-            if (lo <= hi) hm |= 1u << k;
-        }
-        const uint32_t imask = (n.link >> 4) & 15u;
-        const uint32_t I = hm & imask, L = hm & ~imask & 15u;
-        const uint32_t T = (((L * 0x204081u) & 0x01010101u) * 255u) & n.triMask;
-        const uint32_t X = I ? (n.link | I) : stack[sp];
-        const uint32_t hits = X & 15u, low = hits & (0u - hits);
-        const uint32_t child = (uint32_t)__builtin_popcount((X >> 4) & (low - 1u)) + (X >> 8);
-        const uint32_t X2 = X ^ low;
-        const bool more = (X2 & 15u) != 0u;
-        const int spw = sp + (I ? 1 : 0);
-        if (more) { if (spw >= 256) return best; stack[spw] = X2; }
-        sp = more ? spw : (spw > 0 ? spw - 1 : 0);
-        const int64_t next = X == 0u ? -1 : (int64_t)child;
-        for (uint32_t rem = T; rem; rem &= rem - 1u) {
-            const uint32_t j = (uint32_t)__builtin_ctz(rem);
-            const RtrBvhTri& tr = tris[(size_t)cur * RTR_WIDE_TRI_PLACES + j];
-            float t, u, v;
-            c.tris++; c.shadowTris++;
-            if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
-                if (!(t < tmax)) continue;
-                if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
-                best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = tr.customIndex; best.prim = tr.primitiveId;
-                return best;
+            int32_t next = RTR_WIDE_EMPTY;
+            float tn = 3.0e38f;
+            if (hit[0]) { tn = te[0]; next = n.child[0]; }
+            for (int k = 1; k < 4; ++k) if (hit[k] && te[k] < tn) { tn = te[k]; next = n.child[k]; }
+            bool overflow = false;
+            for (int k = 0; k < 4; ++k) if (hit[k] && n.child[k] != next) { if (stack.size() < 16) stack.push_back(n.child[k]); else overflow = true; }
+            /* the kernel keeps 16 stack entries in LDS; a ray that needs a 17th is abandoned there and re-traced from scratch
+             * over the BVH2 by k_shadow_tail (counting form: both parts are counted) */
+            if (overflow) return trace_bvh(sc, o, d, tmin, tmax, true, c);
+            if (next == RTR_WIDE_EMPTY) {
+                if (stack.empty()) return best;
+                next = stack.back(); stack.pop_back();
             }
+            cur = next;
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const RtrBvhTri& tr = tris[first + i];
+                float t, u, v;
+                c.tris++; c.shadowTris++;
+                if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
+                    if (!(t < tmax)) continue;
+                    if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
+                    best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = tr.customIndex; best.prim = tr.primitiveId;
+                    return best;
+                }
+            }
+            if (stack.empty()) return best;
+            cur = stack.back(); stack.pop_back();
         }
-        cur = next;
     }
-    return best;
 }
 
 inline Hit trace(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
@@ -653,7 +638,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     if (wantAnalytic && (!s->desc.ltc1 || !s->desc.ltc2)) return -4;
     Scene sc;
     if (!prepare(s, sc)) return -1;
-    sc.useWide = s->wide != nullptr && s->wideTris != nullptr && s->numWide > 0 && prm.pipeline != 1;
+    sc.useWide = s->wide != nullptr && s->nodes != nullptr && s->numWide > 0 && prm.pipeline != 1;
     const uint32_t rows = shard_rows(prm.height, prm.bandRows, prm.shardCount);
     const uint32_t W = prm.width;
     BandMap bm{prm.bandRows, prm.shardIndex, prm.shardCount, prm.height};

@@ -19,9 +19,9 @@ api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, spp=spp, coll
 t0 = frame.stats()
 api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, spp=spp, collect_stats=1), frame)
 st = frame.stats()
-print(f"{name} {W}x{H} {spp}spp: {ss.numTriangles} triangles, {ss.numNodes} BVH2 nodes, {ss.numWideNodes} wide nodes (layout {ss.wideLayoutVersion})")
-print("rays", st.numRays, "shadow", st.numShadowRays, "wide visits", st.numShadowNodeVisits, "shadow tri tests", st.numShadowTriTests, "tail rays", st.shadowTailRays)
-print("per shadow ray: wide visits %.2f  tri tests %.2f ; per primary ray: BVH2 visits %.2f  tri tests %.2f" % (
+print(f"{name} {W}x{H} {spp}spp: {ss.numTriangles} triangles, {ss.numNodes} BVH2 nodes, {ss.numWideNodes} 4-wide records (layout {ss.wideLayoutVersion})")
+print("rays", st.numRays, "shadow", st.numShadowRays, "4-wide visits", st.numShadowNodeVisits, "shadow tri tests", st.numShadowTriTests, "tail rays", st.shadowTailRays)
+print("per shadow ray: 4-wide visits %.2f  tri tests %.2f ; per primary ray: BVH2 visits %.2f  tri tests %.2f" % (
     st.numShadowNodeVisits / st.numShadowRays, st.numShadowTriTests / st.numShadowRays,
     (st.numNodeVisits - st.numShadowNodeVisits) / st.numPrimaryRays, (st.numTriTests - st.numShadowTriTests) / st.numPrimaryRays))
 ii, il, ti, tl = st.shadowInnerIterations, st.shadowInnerActiveLanes, st.shadowTriIterations, st.shadowTriActiveLanes

@@ -60,10 +60,7 @@ class RtrBvhTri(C.Structure):
 
 
 class RtrWideNode(C.Structure):
-    _fields_ = [("plane", (u32 * 3) * 4), ("origin", C.c_uint16 * 3), ("_reserved", C.c_uint16), ("link", u32), ("triMask", u32)]
-
-
-WIDE_TRI_PLACES = 32
+    _fields_ = [("plane", (u32 * 3) * 4), ("child", i32 * 4)]
 
 
 class rtr_texture(C.Structure):
@@ -138,7 +135,7 @@ RTR_SYMBOLS = {
     "rtr_scene_destroy": (None, [VP]),
     "rtr_scene_get_stats": (C.c_int, [VP, P(rtr_scene_stats)]),
     "rtr_scene_export_bvh": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
-    "rtr_scene_export_wide": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
+    "rtr_scene_export_wide": (C.c_int, [VP, VP, C.c_size_t]),
     "rtr_host_build_bvh": (C.c_int, [P(rtr_scene_desc), P(rtr_scene_stats), VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_scene_update_lights": (C.c_int, [VP, P(RtrAreaLightInfo), u32]),
     "rtr_scene_update_instances": (C.c_int, [VP, P(RtrInstance), u32, P(RtrAreaLightInfo), u32]),

@@ -48,7 +48,7 @@ class Context:
 
 
 class BvhExport(tuple):
-    """(nodes, tris, grid) of rtr_scene_export_bvh, with the wide view of rtr_scene_export_wide as .wide = (wnodes, wtris)"""
+    """(nodes, tris, grid) of rtr_scene_export_bvh, with the 4-wide view of rtr_scene_export_wide as .wide"""
     wide = None
 
 
@@ -73,9 +73,8 @@ class Scene:
         out = BvhExport((nodes, tris, s.grid))      # the nodes' 16-bit planes live on s.grid
         if s.numWideNodes:
             wn = (A.RtrWideNode * s.numWideNodes)()
-            wt = (A.RtrBvhTri * (A.WIDE_TRI_PLACES * s.numWideNodes))()
-            _check(self.lib.rtr_scene_export_wide(self.h, wn, C.sizeof(wn), wt, C.sizeof(wt)), "rtr_scene_export_wide")
-            out.wide = (wn, wt)
+            _check(self.lib.rtr_scene_export_wide(self.h, wn, C.sizeof(wn)), "rtr_scene_export_wide")
+            out.wide = wn
         return out
 
     def update_instances(self, instances, lights=None):

@@ -33,7 +33,7 @@ struct Box {
 struct Prim { Box box; float c[3]; uint32_t index; };
 
 constexpr int kBins = 32;
-constexpr uint32_t kLeafTarget = RTR_BVH_MAX_LEAF < 4 ? RTR_BVH_MAX_LEAF : 4;        /* SAH may stop at <= this many */
+constexpr uint32_t kLeafTarget = 4;        /* SAH may stop at <= this many */
 constexpr uint32_t kMedianDepth = 48;      /* beyond this depth fall back to median splits: bounds the stack */
 constexpr float kCostTraverse = 1.0f;
 constexpr float kCostIntersect = 1.0f;

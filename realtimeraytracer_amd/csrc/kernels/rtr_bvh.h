@@ -45,10 +45,7 @@ hipError_t bvh_refit(const BvhInputs& in, uint32_t numPrims, uint32_t numNodes, 
 /* The 4-wide view of a finished (quantised) tree that the any-hit kernel walks: numNodes x 4 uint4, see k_wide_nodes.
  * parentOrNull: the refit parent array (entries outside the tree are skipped) or null. */
 hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, const RtrBvhGrid* grid, uint4* wide, hipStream_t s);
-/* Final RtrWideNode records (breadth-first numbering through remap; only entries with remap[i] < reached are part of the tree)
- * and the sparse triangle array (RTR_WIDE_TRI_PLACES places per node).  *fail != 0 afterwards: a leaf with more than 8 triangles (bit 0) or more
- * than 2^24 nodes (bit 1). */
-hipError_t bvh_encode_wide(const uint4* in, uint32_t numNodes, uint32_t reached, const uint32_t* remap, const float4* tris, uint4* wnodes,
-                           float4* wtris, uint32_t* fail, hipStream_t stream);
+/* out[remap[i]] = in[i] with inner child codes renumbered through remap (a permutation of 0..numNodes-1, remap[0] == 0) */
+hipError_t bvh_permute_wide(const uint4* in, uint32_t numNodes, const uint32_t* remap, uint4* out, hipStream_t stream);
 
 }  // namespace rtrdev

@@ -30,7 +30,7 @@
 namespace rtrdev {
 
 constexpr int kB = 256;
-constexpr uint32_t kLeafMax = RTR_BVH_MAX_LEAF;
+constexpr uint32_t kLeafMax = 4;
 
 __device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __host__ __device__ inline float ord2f(uint32_t u) {
@@ -328,71 +328,20 @@ __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint
     for (int q = 0; q < 4; ++q) wide[(size_t)i * 4 + q] = make_uint4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);
 }
 
-/* f16 bits of a plane offset d (scene-grid steps from the node origin, 0..65535), rounded DOWN / UP to 11 significant bits.
- * Integer arithmetic, so host (oracle-side restatement) and device agree bit for bit; an offset that rounds up past 65504
- * becomes +inf, which the slab test handles (ga is never 0, so inf * ga + gbN is +-inf, not NaN). */
-__host__ __device__ inline uint32_t f16_bits_of_int(uint32_t v) {        /* v has at most 11 significant bits, v <= 65536 */
-    if (v == 0) return 0u;
-    if (v > 65504u) return 0x7c00u;                                       /* +inf */
-    const int e = 31 - __builtin_clz(v);                                   /* v = 1.m * 2^e, e <= 15 */
-    const uint32_t m = (e >= 10) ? (v >> (e - 10)) : (v << (10 - e));      /* 11 bits, leading one at bit 10 */
-    return ((uint32_t)(e + 15) << 10) | (m & 0x3ffu);
-}
-__host__ __device__ inline uint32_t f16_floor_bits(uint32_t d) {
-    if (d <= 2048u) return f16_bits_of_int(d);
-    const int sh = (31 - __builtin_clz(d)) - 10;
-    return f16_bits_of_int((d >> sh) << sh);
-}
-__host__ __device__ inline uint32_t f16_ceil_bits(uint32_t d) {
-    if (d <= 2048u) return f16_bits_of_int(d);
-    const int sh = (31 - __builtin_clz(d)) - 10;
-    return f16_bits_of_int(((d + (1u << sh) - 1u) >> sh) << sh);
-}
-
-/* Final form of the wide tree (RtrWideNode, include/rtr_types.h), in the order the host chose (breadth-first from the root:
- * rtr_api.cpp, make_wide_nodes): entry i of `in` (the scene-grid form k_wide_nodes wrote, BVH2 numbering) becomes node
- * remap[i] when that is < reached.  Planes become f16 offsets from the node's min corner; the inner children of a node are
- * consecutive in the new numbering (breadth-first order appends them in slot order), so only the first index is stored; the
- * triangles of leaf slot k are copied to places 8 k .. 8 k + 7 of the node's block of the sparse array wtris. */
-__global__ __launch_bounds__(kB) void k_encode_wide(uint32_t numNodes, uint32_t reached, const uint4* __restrict__ in, const uint32_t* __restrict__ remap,
-                                                    const float4* __restrict__ tris, uint4* __restrict__ wnodes, float4* __restrict__ wtris,
-                                                    uint32_t* __restrict__ fail) {
+/* Moves the 4-wide entries into the order the host chose (breadth-first from the root: rtr_api.cpp, make_wide_nodes), so the
+ * top of the tree is entries 0..K-1 — the part k_shadow_trace4 keeps in LDS.  Inner child codes are renumbered with it. */
+__global__ __launch_bounds__(kB) void k_permute_wide(uint32_t numNodes, const uint4* __restrict__ in, const uint32_t* __restrict__ remap,
+                                                     uint4* __restrict__ out) {
     const uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i >= numNodes) return;
-    const uint32_t r = remap[i];
-    if (r >= reached) return;
-    uint32_t w[16];
-    for (int q = 0; q < 4; ++q) { const uint4 v = in[(size_t)i * 4 + q]; w[q * 4] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w; }
-    uint32_t org[3] = {65535u, 65535u, 65535u};
-    for (int k = 0; k < 4; ++k) {
-        if (w[12 + k] == 0x80000000u) continue;
-        org[0] = min(org[0], w[k * 3] & 0xffffu); org[1] = min(org[1], w[k * 3] >> 16); org[2] = min(org[2], w[k * 3 + 2] & 0xffffu);
-    }
-    uint32_t o[16];
-    uint32_t imask = 0, first = 0xffffffffu, vmask = 0;
-    for (int k = 0; k < 4; ++k) {
-        const int32_t code = (int32_t)w[12 + k];
-        if (w[12 + k] == 0x80000000u) { o[k * 3] = o[k * 3 + 1] = o[k * 3 + 2] = 0x00007bffu; continue; }    /* min 65504, max 0 */
-        const uint32_t mn[3] = {w[k * 3] & 0xffffu, w[k * 3] >> 16, w[k * 3 + 2] & 0xffffu};
-        const uint32_t mx[3] = {w[k * 3 + 1] & 0xffffu, w[k * 3 + 1] >> 16, w[k * 3 + 2] >> 16};
-        for (int a = 0; a < 3; ++a) o[k * 3 + a] = f16_floor_bits(mn[a] - org[a]) | (f16_ceil_bits(mx[a] - org[a]) << 16);
-        if (code >= 0) {
-            imask |= 1u << k;
-            if (first == 0xffffffffu) first = remap[code];
-        } else {
-            const uint32_t c = (uint32_t)~code, t0 = c >> 3, cnt = (c & 7u) + 1u;
-            if (cnt > 8u) { atomicOr(fail, 1u); continue; }
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const size_t dst = ((size_t)r * RTR_WIDE_TRI_PLACES + (size_t)k * 8 + j) * 3, src = (size_t)(t0 + j) * 3;
-                wtris[dst] = tris[src]; wtris[dst + 1] = tris[src + 1]; wtris[dst + 2] = tris[src + 2];
-                vmask |= 1u << (k * 8 + j);
-            }
-        }
-    }
-    if (first == 0xffffffffu) first = 0;
-    if (first >= (1u << 24)) atomicOr(fail, 2u);
-    o[12] = org[0] | (org[1] << 16); o[13] = org[2]; o[14] = (first << 8) | (imask << 4); o[15] = vmask;
-    for (int q = 0; q < 4; ++q) wnodes[(size_t)r * 4 + q] = make_uint4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);
+    const size_t dst = (size_t)remap[i] * 4;
+    for (int q = 0; q < 3; ++q) out[dst + q] = in[(size_t)i * 4 + q];
+    uint4 c = in[(size_t)i * 4 + 3];
+    if ((int32_t)c.x >= 0) c.x = remap[c.x];
+    if ((int32_t)c.y >= 0) c.y = remap[c.y];
+    if ((int32_t)c.z >= 0) c.z = remap[c.z];
+    if ((int32_t)c.w >= 0) c.w = remap[c.w];
+    out[dst + 3] = c;
 }
 
 /* ---- host-side drivers ------------------------------------------------------------------------------ */
@@ -436,9 +385,8 @@ hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* p
     return hipGetLastError();
 }
 
-hipError_t bvh_encode_wide(const uint4* in, uint32_t numNodes, uint32_t reached, const uint32_t* remap, const float4* tris, uint4* wnodes,
-                           float4* wtris, uint32_t* fail, hipStream_t s) {
-    hipLaunchKernelGGL(k_encode_wide, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, reached, in, remap, tris, wnodes, wtris, fail);
+hipError_t bvh_permute_wide(const uint4* in, uint32_t numNodes, const uint32_t* remap, uint4* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_permute_wide, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, in, remap, out);
     return hipGetLastError();
 }
 

@@ -29,9 +29,8 @@ constexpr uint32_t kLightTriRecord = 4;     /* float4s per light-triangle record
 struct DeviceScene {
     const uint4* nodes;              /* RtrBvhNode (layout version 3) as 2 x uint4 */
     const RtrBvhGrid* grid;          /* the grid the 16-bit planes live on; device memory so a refit can rewrite it */
-    const uint4* wnodes;             /* RtrWideNode (layout W4.1) as 4 x uint4, breadth-first order: the wide view the any-hit kernel walks */
-    const float4* wtris;             /* its sparse triangle array: 16 places of 3 x float4 per wide node */
-    uint32_t numWide;                /* entries in wnodes */
+    const uint4* nodes4;             /* RtrWideNode (layout W4.0): 4-wide view for the any-hit kernel (4 x uint4 per entry, breadth-first order), or null */
+    uint32_t numNodes4;              /* entries in nodes4 (the first wideReached of them are the tree) */
     const float4* tris;              /* RtrBvhTri  as 3 x float4 */
     const RtrVertex* vertices;
     const uint32_t* indices;

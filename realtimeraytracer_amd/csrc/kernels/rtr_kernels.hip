@@ -78,7 +78,7 @@ struct LookupPolicy {
 
 /* The same two phases with the queue binned by direction octant (k_shadow_gen_oct): a workgroup's chunk of the queue is laid
  * out octant by octant, and every run of one octant is cut into batches that are appended to that octant's batch list, from
- * which k_shadow_trace_w's waves draw — so the rays a wave holds share their direction signs and the inner-node loop runs in its
+ * which k_shadow_trace4's waves draw — so the rays a wave holds share their direction signs and the inner-node loop runs in its
  * octant form (slab_oct) nearly always instead of a third of the time.  The octant is taken from the un-normalised direction in
  * both phases (a component that underflows in the normalisation must not move a ray between the count and the emission). */
 __device__ __forceinline__ uint32_t raw_octant(rtr_v3 r) {
@@ -387,6 +387,10 @@ constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first
 constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
 constexpr uint32_t kRefillDefault = 20;    /* idle lanes that trigger a refill (re-swept for the 4-wide kernel: profiles/r01/sweep_trace_wide.log) */
 
+/* Stack policy of the persistent kernels.  Ordered traversal rarely holds more than ~10 entries, so every lane gets 16 LDS
+ * entries (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum).  The rare ray that needs a 17th entry is
+ * abandoned — its queue index goes to an overflow list and k_shadow_tail finishes it from scratch with a full-depth stack — so the
+ * hot loop is pure LDS with no spill branch (an LDS/global select made the compiler emit flat_load for EVERY pop). */
 /* Production form (no counters).  Same scheduling — persistent waves, ballot refill, early-exit
  * while-while, described above — with the hot loop stripped of everything that is not a node visit:
  *   * a ray's result (0 visible, 1 occluded, 2 "needs a deeper stack") stays in a register and is written when the lane
@@ -394,9 +398,9 @@ constexpr uint32_t kRefillDefault = 20;    /* idle lanes that trigger a refill (
  *   * the slot below stack entry 0 holds the "ray finished" code, so a pop needs no empty-stack test and the speculative
  *     read of the top needs no index clamp;
  *   * node and triangle addresses are 32-bit offsets from a scalar base (global_load ... saddr), not 64-bit lane math.
- * (This is the 2-wide form, RTR_TRACE_BVH4=0: kept as a second implementation the tests hold against the wide kernel.) */
+ * (This is the 2-wide form, RTR_TRACE_BVH4=0: kept as a second implementation the tests hold against the 4-wide kernel.) */
 constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
-constexpr uint32_t kTopNodes = 85;         /* wide nodes k_shadow_trace_w keeps in LDS: the first four levels, 5.3 KiB next to the 13-KiB stack = 8 workgroups per CU */
+constexpr uint32_t kTopNodes = 40;         /* four-wide entries k_shadow_trace4 keeps in LDS: 2.5 KiB next to the 17-KiB stack = 8 workgroups per CU */
 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
@@ -479,8 +483,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
             if (exhausted) break;                /* every lane is idle and was retired above (nIdle == 64) */
             continue;
         }
-        /* ---- inner nodes ("while-while" with an early exit: keep descending while more than kInnerMin lanes are on inner nodes or
-         * nobody has a leaf to test; then test the leaves that are waiting) ---- */
+        /* ---- inner nodes ("while-while" with an early exit: keep descending while more than kInnerMin lanes are on inner nodes, or
+         * while nobody has a leaf to test; then test the leaves that are waiting.  Waiting for EVERY lane to reach a leaf left the
+         * early lanes idle for the stragglers: 3.64 -> 3.0 ms at kInnerMin = 20, profiles/r01/sweep_inner.log.  Every pass of the
+         * outer loop visits a node or tests a leaf for at least one lane, or exits, so all waves drain) ---- */
         for (;;) {
             const unsigned long long innerMask = __ballot(cur >= 0);
             if (innerMask == 0ull) break;
@@ -533,60 +539,45 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
     }
 }
 
-/* ---- the any-hit kernel over the wide view of the tree (RtrWideNode, layout W4.1) ------------------------------------------
- * One visit = one 64-B record: up to four child boxes as f16 plane offsets from the node's own origin, so a plane's parameter
- * is one v_fma_mix_f32 (no conversion; round 1 spent 6 conversions + 3 packed fmas per box, 63 clocks against 46 measured in
- * profiles/microbench/valu_rates2.hip), hit slots come out as a 4-bit mask, the inner ones of which are ONE stack entry
- * (link | hits: the children of a node are consecutive) and the leaf ones a 16-bit mask of triangles in the node's block of
- * the sparse triangle array — no child codes to select, order or push one by one.  Children are entered in slot order:
- * for these rays nearest-first buys nothing (profiles/experiments/wide_sim.cpp: 15.9 against 16.2 visits per ray), and a
- * ray's sequence of visits and triangle tests then depends on nothing but the ray and the tree, so the counting form's
- * numbers are exactly those of the timed form, whatever the scheduling (and the oracle restates them). */
-struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
-
-/* Slab test of one slot: dx / dy / dz = (min | max << 16) f16 plane offsets of an axis.  OCT 0..7: the direction signs of every
- * lane that calls are known (bit a = ga.a < 0), so near / far planes are picked at compile time; 8 = any signs. */
-template <int OCT>
-__device__ __forceinline__ bool slab_w(uint32_t dx, uint32_t dy, uint32_t dz, rtr_v3 ga, rtr_v3 gbn, float tmin, float tmax) {
-    typedef _Float16 rtr_h2 __attribute__((ext_vector_type(2)));
-    const rtr_h2 px = __builtin_bit_cast(rtr_h2, dx), py = __builtin_bit_cast(rtr_h2, dy), pz = __builtin_bit_cast(rtr_h2, dz);
-    const float x0 = rtr_fma((float)px.x, ga.x, gbn.x), x1 = rtr_fma((float)px.y, ga.x, gbn.x);
-    const float y0 = rtr_fma((float)py.x, ga.y, gbn.y), y1 = rtr_fma((float)py.y, ga.y, gbn.y);
-    const float z0 = rtr_fma((float)pz.x, ga.z, gbn.z), z1 = rtr_fma((float)pz.y, ga.z, gbn.z);
-    float nx, fx, ny, fy, nz, fz;
-    if (OCT < 8) {
-        nx = (OCT & 1) ? x1 : x0; fx = (OCT & 1) ? x0 : x1;
-        ny = (OCT & 2) ? y1 : y0; fy = (OCT & 2) ? y0 : y1;
-        nz = (OCT & 4) ? z1 : z0; fz = (OCT & 4) ? z0 : z1;
-    } else {
-        nx = rtr_hwmin(x0, x1); fx = rtr_hwmax(x0, x1);
-        ny = rtr_hwmin(y0, y1); fy = rtr_hwmax(y0, y1);
-        nz = rtr_hwmin(z0, z1); fz = rtr_hwmax(z0, z1);
-    }
-    const float lo = rtr_hwmax(rtr_hwmax(nx, ny), rtr_hwmax(nz, tmin));
-    const float hi = rtr_hwmin(rtr_hwmin(fx, fy), rtr_hwmin(fz, tmax));
-    return lo <= hi;
+/* The inner-node loop of k_shadow_trace4, compiled per direction octant (OCT 0..7; 8 = any signs, see slab_oct). */
+/* One any-hit triangle test of the persistent 4-wide kernel: 48-B record through the buffer resource, Moeller-Trumbore, t < tmax,
+ * and opacity.rahit on alpha-tested geometry. */
+template <bool STATS>
+__device__ __forceinline__ bool tri_any(const DeviceScene& sc, const __amdgpu_buffer_rsrc_t triBuf, const uint32_t tri, const rtr_v3 o, const rtr_v3 d,
+                                        const float tmin, const float tmax, LocalStats& st) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int32_t triOff = (int32_t)(tri * 48u);
+    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff, 0, 0);
+    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 16, 0, 0);
+    const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 32, 0, 0);
+    const float4 q0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+    const float4 q1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+    const float4 q2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+    float t, u, v;
+    if (!(rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v) && t < tmax)) return false;
+    if (__float_as_uint(q2.w) & 1u) return alpha_pass<STATS>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
+    return true;
 }
 
-/* The node phase.  A lane works here while it has a node to enter (cur >= 0) and no triangles waiting (T == 0); the phase ends
- * when at most kInnerMin lanes can work and somebody has triangles to test (or nobody can work).  Stack: lds[sp * kBlock] is
- * the top entry, slot 0 holds 0 = "nothing left".  An entry is link | hits: firstInnerChild << 8 | innerMask << 4 | slots still
- * to enter; taking the lowest slot either rewrites the entry (slots left) or removes it. */
+struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
+
 template <int STACK, int OCT, bool STATS>
-__device__ __forceinline__ void inner_wide(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
-                                           int32_t* lds, int32_t& cur, int& sp, uint32_t& res, uint32_t& T, uint32_t& TB,
-                                           const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
-                                           WaveStats& ws, LocalStats& st) {
+__device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
+                                             int32_t* lds, int32_t& cur, int& sp, uint32_t& res,
+                                             const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
+                                             WaveStats& ws, LocalStats& st) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     for (;;) {
-        const bool act = cur >= 0 && T == 0u;
-        const unsigned long long actMask = __ballot(act);
-        if (actMask == 0ull) break;
-        if ((uint32_t)__popcll(actMask) <= kInnerMin && __ballot(T != 0u) != 0ull) break;
-        if (STATS) { ws.innerIters++; ws.innerLanes += (uint32_t)__popcll(actMask); }
-        if (act) {
+        const unsigned long long innerMask = __ballot(cur >= 0);
+        if (innerMask == 0ull) break;
+        if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
+        if (STATS) { ws.innerIters++; ws.innerLanes += (uint32_t)__popcll(innerMask); }
+        if (cur >= 0) {
+            if (STATS) { st.nodes++; st.shadowNodes++; }
+            /* one 64-B four-wide node = the whole visit; the first topCount entries (the top levels: breadth-first order) are in
+             * LDS, which takes those visits — 35-40 % of all — off the L1's tag look-ups, the busiest unit of this kernel */
             u32x4 q0, q1, q2, q3;
-            if ((uint32_t)cur < topCount) {                   /* the top levels (breadth-first order) live in LDS */
+            if ((uint32_t)cur < topCount) {
                 const uint4* t = ldsTop + cur * 4;
                 const uint4 a0 = t[0], a1 = t[1], a2 = t[2], a3 = t[3];
                 q0 = u32x4{a0.x, a0.y, a0.z, a0.w}; q1 = u32x4{a1.x, a1.y, a1.z, a1.w};
@@ -598,98 +589,61 @@ __device__ __forceinline__ void inner_wide(const __amdgpu_buffer_rsrc_t nodeBuf,
                 q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, 0);
                 q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, 0);
             }
-            const uint32_t top = (uint32_t)lds[sp * kBlock];  /* speculative: hides the pop's LDS latency under the node loads */
-            if (STATS) { st.nodes++; st.shadowNodes++; }
-            /* the node's frame: planes are offsets from its origin, so only gb moves */
-            const rtr_v3 gbn = rtr_mk(rtr_fma((float)(q3.x & 0xffffu), ga.x, gb.x), rtr_fma((float)(q3.x >> 16), ga.y, gb.y),
-                                      rtr_fma((float)(q3.y & 0xffffu), ga.z, gb.z));
-            const uint32_t hm = (slab_w<OCT>(q0.x, q0.y, q0.z, ga, gbn, tmin, tmax) ? 1u : 0u) |
-                                (slab_w<OCT>(q0.w, q1.x, q1.y, ga, gbn, tmin, tmax) ? 2u : 0u) |
-                                (slab_w<OCT>(q1.z, q1.w, q2.x, ga, gbn, tmin, tmax) ? 4u : 0u) |
-                                (slab_w<OCT>(q2.y, q2.z, q2.w, ga, gbn, tmin, tmax) ? 8u : 0u);
-            const uint32_t link = q3.z;
-            const uint32_t I = hm & (link >> 4);              /* link has nothing in bits 0-3, hm nothing above them: the inner slots that are hit */
-            const uint32_t L = hm & ~(link >> 4);             /* the leaf slots that are hit */
-            /* their triangles: every hit leaf slot -> its byte of the node's triangle mask */
-            T = (((L * 0x204081u) & 0x01010101u) * 255u) & q3.w;
-            TB = (uint32_t)cur << 5;
-            /* one entry for all inner hits, or the top of the stack when there is none; enter its lowest slot */
-            const bool down = I != 0u;
-            const uint32_t X = down ? (link | I) : top;
-            const uint32_t hits = X & 15u;
-            const uint32_t low = hits & (0u - hits);
-            const uint32_t child = (uint32_t)__popc((X >> 4) & (low - 1u)) + (X >> 8);
-            const uint32_t X2 = X ^ low;
-            const bool more = (X2 & 15u) != 0u;
-            const int spw = sp + (down ? 1 : 0);
-            int32_t next = X == 0u ? kDone : (int32_t)child;    /* 0: slot 0 of the stack, nothing left to enter */
-            if (more) {
-                if (spw <= STACK) lds[spw * kBlock] = (int32_t)X2;
-                else { res = 2u; next = kDone; T = 0u; }         /* needs more than the LDS stack: the tail kernel redoes this ray */
-            }
-            sp = more ? spw : (spw > 0 ? spw - 1 : 0);
+            const int32_t top = lds[sp * kBlock];              /* speculative: hides the pop's LDS latency under the node loads */
+            const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
+            float t0, t1, t2, t3;
+            const bool h0 = slab_oct<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);            /* slot 0 is never empty */
+            const bool h1 = slab_oct<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmax, t1);
+            const bool h2 = slab_oct<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmax, t2) && c2 != kDone;
+            const bool h3 = slab_oct<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmax, t3) && c3 != kDone;
+            /* descend into the nearest child that is hit; the others go on the stack in slot order.  (Taking the first hit slot
+             * instead of the nearest saves eight instructions and costs 2 % more time; ordering the others too —
+             * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
+             * 2.15 / 2.22 ms against 2.05.) */
+            int32_t next = kDone;
+            bool ovf = false;
+            float tn = 3.0e38f;
+            if (h0) { tn = t0; next = c0; }
+            if (h1 && t1 < tn) { tn = t1; next = c1; }
+            if (h2 && t2 < tn) { tn = t2; next = c2; }
+            if (h3 && t3 < tn) { tn = t3; next = c3; }
+            if (h0 && c0 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c0; } else ovf = true; }
+            if (h1 && c1 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c1; } else ovf = true; }
+            if (h2 && c2 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c2; } else ovf = true; }
+            if (h3 && c3 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c3; } else ovf = true; }
+            if (ovf) { res = 2u; next = kDone; }                 /* needs more than the LDS stack: the tail kernel redoes this ray */
+            if (next == kDone && !ovf) { next = top; --sp; }    /* nothing hit: pop (slot 0 holds kDone) */
             cur = next;
         }
     }
 }
 
-/* The triangle phase: every lane with waiting triangles tests one per trip (lowest bit of T first = slot order, storage order
- * inside a slot).  It ends when no lane has any left — or, past the first trip, when fewer than kTriMin have and some lane
- * could do node work instead. */
-template <bool STATS>
-__device__ __forceinline__ void tris_wide(const DeviceScene& sc, const __amdgpu_buffer_rsrc_t triBuf, int32_t& cur, uint32_t& res,
-                                          uint32_t& T, const uint32_t TB, const rtr_v3 o, const rtr_v3 d, const float tmin, const float tmax,
-                                          const uint32_t kTriMin, WaveStats& ws, LocalStats& st) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    bool first = true;
-    for (;;) {
-        const unsigned long long m = __ballot(T != 0u);
-        if (m == 0ull) break;
-        if (!first && (uint32_t)__popcll(m) < kTriMin && __ballot(cur >= 0 && T == 0u) != 0ull) break;
-        first = false;
-        if (STATS) { ws.triIters++; ws.triLanes += (uint32_t)__popcll(m); }
-        if (T != 0u) {
-            const uint32_t j = (uint32_t)__ffs((int)T) - 1u;
-            T &= T - 1u;
-            const int32_t triOff = (int32_t)((TB + j) * 48u);
-            const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff, 0, 0);
-            const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 16, 0, 0);
-            const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 32, 0, 0);
-            const float4 q0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-            const float4 q1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-            const float4 q2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-            if (STATS) { st.tris++; st.shadowTris++; }
-            float t, u, v;
-            if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v) && t < tmax) {
-                bool hit = true;
-                if (__float_as_uint(q2.w) & 1u)            /* opacity.rahit on alpha-tested geometry */
-                    hit = alpha_pass<STATS>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
-                if (hit) { res = 1u; cur = kDone; T = 0u; }      /* occluded: whatever is still on the stack is dropped */
-            }
-        }
-    }
-}
-
-/* Persistent waves over the shadow-ray queue (see the scheduling notes at the top of this stage).  STATS: the same kernel with
- * per-ray work counters, per-trip lane counts and a shader-clock stamp pair per wave — the counting form the bench's roofline
- * and the tests' counter checks use; its visibility bytes and its per-ray counts are those of the timed form. */
+/* The same kernel over the 4-wide view of the tree (DeviceScene::nodes4, built by k_wide_nodes): a visit is one 64-B record
+ * (four loads issued together) holding up to four child boxes, so a ray makes about half as many DEPENDENT visits; the
+ * instruction and look-up totals stay about the same.  2.17 -> 2.05 ms on the bench frame; identical visibility bits. */
+/* STATS: the same kernel with per-ray work counters (a ray's sequence of visits and triangle tests depends only on the ray and the
+ * tree: nearest hit child first, ties to the lower slot, the others stacked in slot order — whatever the scheduling, the octant
+ * form or the queue mode, so the counting form's numbers are the timed form's, and the oracle restates them), per-trip lane counts
+ * of the two phases, and a shader-clock stamp pair per wave. */
 template <int STACK, bool LISTS, bool STATS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace_w(DeviceScene sc, const float4* __restrict__ queue,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
-                                                              uint32_t kInnerMin, uint32_t kTriMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
+                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
                                                               const uint2* __restrict__ lists, uint32_t listStride, Counters* stats,
                                                               unsigned long long* __restrict__ clk) {
-    __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds 0 = "nothing left" for good */
-    __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) wide nodes */
+    __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
+    __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
     int32_t* lds = s_stack + threadIdx.x;
-    lds[0] = 0;
-    for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kBlock) s_top[i] = sc.wnodes[i];
+    lds[0] = kDone;
+    for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kBlock) s_top[i] = sc.nodes4[i];
     __syncthreads();
-    /* clock of this launch: shader-clock ticks over 100-MHz ticks, one wave per XCD's first workgroup (bench.py: roofline.clock_mhz) */
+    /* clock of this launch: shader-clock ticks over 100-MHz ticks, lane 0 of the first workgroup of each XCD (bench.py: roofline.clock_mhz) */
     const bool stamp = clk != nullptr && blockIdx.x < kQueueRegions && threadIdx.x == 0;
     unsigned long long c0 = 0, r0 = 0;
     if (stamp || STATS) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    LocalStats st;
+    WaveStats ws;
     uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
     bool exhausted = false;                  /* wave-uniform */
     /* LISTS == false: the plain queue, cut into kQueueRegions contiguous regions with one batch cursor each (64 B apart).  A
@@ -699,7 +653,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
      * {first, count} (length lens[r], cursor nextBatch[16 r]).  A workgroup starts on the octant its share of the launch falls
      * into — octants get workgroups in proportion to their batches — and there on the list of its own XCD, then takes the other
      * XCDs' lists of that octant, then the next octant: the rays in a wave share their direction signs except around such a move.
-     * (With one list per octant, shared by all XCDs, the same scheduling took 3.8 ms instead of 1.9.) */
+     * (With one list per octant, shared by all XCDs, the same kernel took 3.8 ms instead of 1.9.) */
     const uint32_t* __restrict__ lens = nextBatch - 16 + kQueueListLens;
     const uint32_t n = LISTS ? 0u : *count;
     const uint32_t regionLen = ((n + kQueueRegions - 1) / kQueueRegions + kBatch - 1) / kBatch * kBatch;
@@ -714,27 +668,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         for (uint32_t r = 0; r < kQueueLists; ++r) { upTo += lens[r]; if (target < upTo) { myRegion = r / kQueueRegions; break; } }
     }
     uint32_t regionTry = 0;                  /* wave-uniform: regions / lists found empty so far (cursors only grow) */
-    int32_t cur = kDone;                     /* node to enter next, or kDone */
+    int32_t cur = kDone;
     int sp = 0;                              /* entries held; the top is lds[sp * kBlock] */
-    uint32_t T = 0u, TB = 0u;                /* triangles waiting: bit j = place TB + j of the sparse triangle array */
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
     float tmax = 0.f;
     uint32_t slot = 0, rayIndex = 0, res = kResNone;
     const float tmin = 0.001f;
-    LocalStats st;
-    WaveStats ws;
-    /* nodes and triangles through buffer resources: the address of a visit is one 32-bit shift, not 64-bit lane arithmetic */
-    const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.wnodes, 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.wtris, 0, 0xffffffff, 0x00020000);
+    /* nodes and triangles through buffer resources: the address of a visit is one 32-bit shift, not 64-bit lane arithmetic
+     * (2.28 -> 2.17 ms, and 62 -> 47 VGPRs) */
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes4, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, 0, 0xffffffff, 0x00020000);
 
     for (;;) {
         /* ---- retire finished rays, refill idle lanes from the wave's batch ---- */
-        const unsigned long long idle = __ballot(cur == kDone && T == 0u);
+        const unsigned long long idle = __ballot(cur == kDone);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (nIdle >= kRefill || nIdle == 64u) {
-            const bool mine = cur == kDone && T == 0u;
             if (STATS) ws.refills++;
-            if (mine && res != kResNone) {
+            if (cur == kDone && res != kResNone) {
                 if (res == 2u) overflow[1u + atomicAdd(overflow, 1u)] = rayIndex;      /* finished by k_shadow_tail */
                 else vis[slot] = (uint8_t)res;
                 res = kResNone;
@@ -775,7 +727,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 if (!exhausted) {
                     const uint32_t avail = batchEnd - batchPos;
                     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    if (mine && prefix < avail) {
+                    if (cur == kDone && prefix < avail) {
                         rayIndex = batchPos + prefix;
                         const float4 a = queue[rayIndex * 2u], b = queue[rayIndex * 2u + 1u];
                         o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
@@ -792,33 +744,57 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 }
             }
         }
-        if (__ballot(cur >= 0 || T != 0u) == 0ull) {
+        if (__ballot(cur != kDone) == 0ull) {
             if (exhausted) break;                /* every lane is idle and was retired above (nIdle == 64) */
             continue;
         }
-        /* ---- node phase.  When every lane that can work has the same direction signs (usual: the queue is binned by octant), it
-         * runs in the form compiled for that octant, without the per-axis min / max. */
+        /* ---- inner nodes ("while-while" with an early exit, see k_shadow_trace) ----
+         * When every lane that is at an inner node has the same direction signs (usual: a wave's rays are neighbouring pixels
+         * aimed at the same light triangle), the loop runs in the form compiled for that octant, without the per-axis min/max. */
         {
-            const unsigned long long actNow = __ballot(cur >= 0 && T == 0u);
-            if (actNow != 0ull) {
+            const unsigned long long innerNow = __ballot(cur >= 0);
+            if (innerNow != 0ull) {
                 const uint32_t oct = (ga.x < 0.f ? 1u : 0u) | (ga.y < 0.f ? 2u : 0u) | (ga.z < 0.f ? 4u : 0u);
-                const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)actNow) - 1);
-                const bool mixed = __ballot(cur >= 0 && T == 0u && oct != woct) != 0ull;
+                const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
+                const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
                 switch ((mixed || octForms == 0u) ? 8u : woct) {
-                    case 0: inner_wide<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 1: inner_wide<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 2: inner_wide<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 3: inner_wide<STACK, 3, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 4: inner_wide<STACK, 4, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 5: inner_wide<STACK, 5, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 6: inner_wide<STACK, 6, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 7: inner_wide<STACK, 7, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    default: inner_wide<STACK, 8, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, T, TB, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
                 }
             }
         }
-        /* ---- triangle phase ---- */
-        tris_wide<STATS>(sc, triBuf, cur, res, T, TB, o, d, tmin, tmax, kTriMin, ws, st);
+        /* ---- leaves ---- */
+        if (STATS) {          /* the same per-lane tests, as a wave-uniform loop so that its trips and the lanes working in them can be counted */
+            const bool atLeaf = cur < 0 && cur != kDone;
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            bool hit = false;
+            for (uint32_t i = 0;; ++i) {
+                const bool go = atLeaf && i < cnt && !hit;
+                const unsigned long long m = __ballot(go);
+                if (m == 0ull) break;
+                ws.triIters++; ws.triLanes += (uint32_t)__popcll(m);
+                if (go) { st.tris++; st.shadowTris++; hit = tri_any<true>(sc, triBuf, first + i, o, d, tmin, tmax, st); }
+            }
+            if (atLeaf) {
+                if (hit) { res = 1u; cur = kDone; }
+                else { cur = lds[sp * kBlock]; --sp; }
+            }
+        } else if (cur < 0 && cur != kDone) {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            bool hit = false;
+            for (uint32_t i = 0; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
+            if (hit) { res = 1u; cur = kDone; }
+            else { cur = lds[sp * kBlock]; --sp; }                   /* slot 0 holds kDone: an empty stack ends the ray (visible) */
+        }
     }
     if (stamp || STATS) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -837,8 +813,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
  * trace<true>() with a full-depth 64-entry stack.  Usually zero rays.  The stack lives in GLOBAL memory (the frame's spill
  * area): a 64-KiB LDS stack could not become resident next to another frame's persistent traversal kernel, so with frames
  * in flight this small launch used to wait for that kernel to drain and held up its own frame's resolve behind it. */
+template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const float4* __restrict__ queue, const uint32_t* __restrict__ overflow,
-                                                        uint8_t* __restrict__ vis, int32_t* __restrict__ spill) {
+                                                        uint8_t* __restrict__ vis, int32_t* __restrict__ spill, Counters* stats) {
     const uint32_t n = overflow[0];
     if (n == 0) return;
     int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;          /* depth stride = every lane of the grid */
@@ -847,9 +824,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const fl
         const uint32_t r = overflow[1u + i];
         const float4 a = queue[(size_t)r * 2], b = queue[(size_t)r * 2 + 1];
         HitRec h;
-        const bool occ = trace<true, false, kTailBlocks * kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
+        const bool occ = trace<true, STATS, kTailBlocks * kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
+        if (STATS) { st.rays--; st.shadow--; }              /* the ray itself was counted when the persistent kernel took it from the queue */
         vis[__float_as_uint(b.w)] = occ ? 1 : 0;
     }
+    if (STATS) st.flush(stats);
 }
 
 /* ---- wavefront stage 4: resolve (shade with looked-up visibility, tonemap, store) ------------- */
@@ -948,19 +927,19 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
     static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);   /* 0: the 2-wide any-hit kernel on the plain queue (same results, for comparison) */
     const uint32_t genBlocks = (blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
-    /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace_w), or the plain queue
-     * (k_shadow_gen -> k_shadow_trace_w over eight regions of it).  Binning pays on long queues (the octant forms of the slab test
-     * then run 97 % of the time instead of 36 %) and costs on short ones (its 64 short lists drain unevenly: -2 % at 3-6 M rays),
-     * hence the thresholds (kBinnedMinRays, kBinnedMinNodes); RTR_TRACE_BINNED=0/1 forces it off/on (the tests run both).
+    /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
+     * (k_shadow_gen -> k_shadow_trace4 over eight regions of it).  Binning pays on long queues (+2 % frame rate at 12-25 M rays:
+     * the octant forms of the slab test then run 97 % of the time instead of 36 %) and costs on short ones (its 64 short lists
+     * drain unevenly: -2 % at 3-6 M rays), hence the thresholds (kBinnedMinRays, kBinnedMinNodes); RTR_TRACE_BINNED=0/1 forces it off/on (the tests run both).
      * The 16-bit per-lane counters of the binned count hold any realistic ray count per pixel.  The counting form (stats) takes
-     * the same path as the timed one. */
+     * the same path as the timed one: same queue, same kernel template. */
     const char* binEnv = getenv("RTR_TRACE_BINNED");
     const uint32_t binMode = (binEnv && (binEnv[0] == '0' || binEnv[0] == '1') && !binEnv[1]) ? (uint32_t)(binEnv[0] - '0') : 2u;
     const size_t maxRaysQ = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
-    const bool wide = (kWide || stats) && sc.wnodes;
+    const bool wide = (kWide || stats) && sc.nodes4;
     const bool binned = wide && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
-                        (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numWide >= kBinnedMinNodes / 2u));
+                        (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
     if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch);
     else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
@@ -969,7 +948,9 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const size_t maxRays = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
     /* 8 workgroups per CU fill every wave slot, which is what a long queue wants; the short queue of a 1/4 or 1/8 shard is
      * drained in a fraction of a millisecond, and then the other frames' small kernels (which can only start where a persistent
-     * wave has retired) matter more: 6 per CU there (profiles/r01/sweep_wgs_per_cu.log) */
+     * wave has retired) matter more: with 6 per CU one rank of 8 renders a frame in 0.394 instead of 0.418 ms and one rank of 4 in
+     * 0.693 instead of 0.708 (4 frames in flight, profiles/r01/sweep_wgs_per_cu.log); at N = 1, 2 it makes no difference.
+     * numCus comes from hipDeviceProp_t::multiProcessorCount (256 on an MI355X in SPX mode). */
     static const uint32_t kWgsPerCu = env_u32("RTR_TRACE_WGS_PER_CU", 0u, 0u, 8u);
     uint32_t tblocks = numCus * (kWgsPerCu ? kWgsPerCu : (maxRays >= kBinnedMinRays ? 8u : 6u));
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
@@ -977,21 +958,21 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (tblocks == 0) tblocks = 1;
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 28u, 0u, 63u);
-    static const uint32_t kTriMin = env_u32("RTR_TRACE_TRI_MIN", 0u, 0u, 64u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
     static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u);
     static const uint32_t kTop = env_u32("RTR_TRACE_TOP_NODES", kTopNodes, 0u, kTopNodes);
-    const uint32_t top = kTop < sc.numWide ? kTop : sc.numWide;
+    const uint32_t top = kTop < sc.numNodes4 ? kTop : sc.numNodes4;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace_w<12, true, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, kTriMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace_w<12, false, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, kTriMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<16, true, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<16, false, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace_w<12, true, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, kTriMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace_w<12, false, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, kTriMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<16, true, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<16, false, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
     } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
-    hipLaunchKernelGGL(k_shadow_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill);
+    if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
+    else hipLaunchKernelGGL((k_shadow_tail<false>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
     if (ev) hipEventRecord(ev[3], s);
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);

@@ -96,9 +96,7 @@ struct rtr_scene {
     DevBuf<uint4> nodes4tmp;             /* the 4-wide entries in BVH2-id order, before the breadth-first permutation */
     DevBuf<uint32_t> wideRemap;
     uint32_t wideReached = 0;            /* entries the 4-wide tree reaches (they come first in nodes4) */
-    DevBuf<uint4> wnodes;                /* RtrWideNode x wideReached: the wide view of the tree the any-hit kernel walks (kernels/rtr_bvh.hip) */
-    DevBuf<float4> wtris;                /* its sparse triangle array: 16 places of 3 x float4 per wide node */
-    DevBuf<uint32_t> wideFail;
+    DevBuf<uint4> nodes4;                /* RtrWideNode: 4-wide view of the tree for the any-hit kernel, breadth-first order (kernels/rtr_bvh.hip) */
     DevBuf<float4> tris;
     DevBuf<RtrVertex> vertices;
     DevBuf<uint32_t> indices;
@@ -387,13 +385,12 @@ static int make_light_tris(rtr_scene* s) {
 
 static int make_wide_nodes(rtr_scene* s) {
     const uint32_t n = (uint32_t)s->hostNodes.size();
-    if (!s->nodes4tmp.p) { HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); HIP_TRY(s->wideFail.alloc(1)); }
+    if (!s->nodes4.p) { HIP_TRY(s->nodes4.alloc((size_t)n * 4)); HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); }
     hipStream_t st = s->ctx->stream;
     hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4tmp.p, st);
-    if (e != hipSuccess) return fail(RTR_ERR_HIP, "wide node build: %s", hipGetErrorString(e));
-    /* breadth-first order of the wide tree (child codes = the 4th 16 bytes of every entry): the inner children of a node get
-     * consecutive numbers in slot order (RtrWideNode::link needs that) and the top levels are the first entries, which
-     * k_shadow_trace_w keeps in LDS.  Entries the wide tree does not reach are dropped. */
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node build: %s", hipGetErrorString(e));
+    /* breadth-first order of the 4-wide tree (child codes = the 4th 16 bytes of every entry), so its top levels are the first
+     * entries: k_shadow_trace4 keeps those in LDS.  Entries the 4-wide tree does not reach keep the ids after them. */
     std::vector<uint32_t> codes((size_t)n * 4), remap(n, 0xffffffffu), order;
     HIP_TRY(hipMemcpy2DAsync(codes.data(), 16, reinterpret_cast<const char*>(s->nodes4tmp.p) + 48, 64, 16, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -404,24 +401,14 @@ static int make_wide_nodes(rtr_scene* s) {
             const int32_t c = (int32_t)codes[(size_t)order[head] * 4 + k];
             if (c >= 0 && (uint32_t)c < n && remap[c] == 0xffffffffu) { remap[c] = (uint32_t)order.size(); order.push_back((uint32_t)c); }
         }
-    const uint32_t reached = (uint32_t)order.size();
-    if (reached >= RTR_WIDE_MAX_NODES) return fail(RTR_ERR_UNSUPPORTED, "scene too large: %u wide nodes (limit 2^24)", reached);
-    if (s->wnodes.n != (size_t)reached * 4) {
-        HIP_TRY(s->wnodes.alloc((size_t)reached * 4));
-        HIP_TRY(s->wtris.alloc((size_t)reached * RTR_WIDE_TRI_PLACES * 3));
-        HIP_TRY(hipMemsetAsync(s->wtris.p, 0, (size_t)reached * RTR_WIDE_TRI_PLACES * 3 * sizeof(float4), st));     /* unused places: never read (triMask) */
-    }
-    HIP_TRY(hipMemsetAsync(s->wideFail.p, 0, sizeof(uint32_t), st));
+    uint32_t next = (uint32_t)order.size();
+    for (uint32_t i = 0; i < n; ++i) if (remap[i] == 0xffffffffu) remap[i] = next++;
     HIP_TRY(hipMemcpyAsync(s->wideRemap.p, remap.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    e = rtrdev::bvh_encode_wide(s->nodes4tmp.p, n, reached, s->wideRemap.p, s->tris.p, s->wnodes.p, s->wtris.p, s->wideFail.p, st);
-    if (e != hipSuccess) return fail(RTR_ERR_HIP, "wide node encode: %s", hipGetErrorString(e));
-    uint32_t bad = 0;
-    HIP_TRY(hipMemcpyAsync(&bad, s->wideFail.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    e = rtrdev::bvh_permute_wide(s->nodes4tmp.p, n, s->wideRemap.p, s->nodes4.p, st);
+    if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node order: %s", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(st));
-    if (bad) return fail(RTR_ERR_UNSUPPORTED, "wide node encode: %s", (bad & 1u) ? "a leaf holds more than 8 triangles" : "more than 2^24 wide nodes");
-    s->wideReached = reached;
-    s->stats.numWideNodes = reached; s->stats.wideLayoutVersion = RTR_WIDE_LAYOUT_VERSION;
-    s->dev.wnodes = s->wnodes.p; s->dev.wtris = s->wtris.p; s->dev.numWide = reached;
+    s->wideReached = (uint32_t)order.size();
+    s->stats.numWideNodes = s->wideReached; s->stats.wideLayoutVersion = RTR_WIDE_LAYOUT_VERSION;
     return RTR_OK;
 }
 
@@ -580,7 +567,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     if (rc == RTR_OK) rc = make_light_tris(s);
     if (rc != RTR_OK) { delete s; ctx_release_child(ctx); return rc; }
     DeviceScene& dv = s->dev;
-    dv.nodes = s->nodes.p; dv.wnodes = s->wnodes.p; dv.wtris = s->wtris.p; dv.numWide = s->wideReached; dv.grid = s->grid.p; dv.tris = s->tris.p;
+    dv.nodes = s->nodes.p; dv.nodes4 = s->nodes4.p; dv.numNodes4 = (uint32_t)s->hostNodes.size(); dv.grid = s->grid.p; dv.tris = s->tris.p;
     dv.vertices = s->vertices.p; dv.indices = s->indices.p;
     dv.objects = s->objects.p; dv.lights = s->lights.p;
     dv.lightTris = s->lightTris.p; dv.lightTriFirst = s->lightTriFirst.p;
@@ -714,17 +701,11 @@ int rtr_scene_export_bvh(const rtr_scene* s, RtrBvhNode* nodes, size_t nodeBytes
     return RTR_OK;
 }
 
-int rtr_scene_export_wide(const rtr_scene* s, RtrWideNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes) {
-    if (!s) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: null scene");
+int rtr_scene_export_wide(const rtr_scene* s, RtrWideNode* nodes, size_t nodeBytes) {
+    if (!s || !nodes) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: null argument");
+    if (nodeBytes != (size_t)s->wideReached * sizeof(RtrWideNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: nodeBytes %zu != %zu", nodeBytes, (size_t)s->wideReached * sizeof(RtrWideNode));
     HIP_TRY(hipSetDevice(s->ctx->device));
-    if (nodes) {
-        if (nodeBytes != (size_t)s->wideReached * sizeof(RtrWideNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: nodeBytes %zu != %zu", nodeBytes, (size_t)s->wideReached * sizeof(RtrWideNode));
-        HIP_TRY(hipMemcpy(nodes, s->wnodes.p, nodeBytes, hipMemcpyDeviceToHost));
-    }
-    if (tris) {
-        if (triBytes != (size_t)s->wideReached * RTR_WIDE_TRI_PLACES * sizeof(RtrBvhTri)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_export_wide: triBytes %zu != %zu", triBytes, (size_t)s->wideReached * RTR_WIDE_TRI_PLACES * sizeof(RtrBvhTri));
-        HIP_TRY(hipMemcpy(tris, s->wtris.p, triBytes, hipMemcpyDeviceToHost));
-    }
+    HIP_TRY(hipMemcpy(nodes, s->nodes4.p, nodeBytes, hipMemcpyDeviceToHost));      /* the records the tree reaches come first */
     return RTR_OK;
 }
 

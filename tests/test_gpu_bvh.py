@@ -39,12 +39,13 @@ def test_device_lbvh_build(gpu_ctx, oracle, scene_cache, which):
     if st.numTriangles >= 16:                        # tiny scenes (the 14-triangle room) fall back to the host builder
         assert st.numNodes == st.numTriangles - 1
     assert st.maxLeafSize <= 4 and st.maxDepth <= 64 and st.stackEntries >= st.maxDepth
-    nodes, tris, grid = lbvh.export_bvh()
+    exported = lbvh.export_bvh()             # (nodes, tris, grid) + the 4-wide view as .wide
+    nodes, tris, grid = exported
     _check_bvh(s.desc, st, nodes, tris, grid)
     p = api.make_params(W, H, spp=2, collect_stats=1)
     f_sah, f_lbvh = _render(gpu_ctx, sah, s, p), _render(gpu_ctx, lbvh, s, p)
     assert np.array_equal(f_sah.download(), f_lbvh.download()), "image must not depend on which builder made the tree"
-    ref = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=(nodes, tris, grid), threads=16)
+    ref = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=exported, threads=16)
     assert np.array_equal(f_lbvh.download(), ref.images[A.IMAGE_SHADOWED])
     g = f_lbvh.stats()
     assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits)
@@ -96,9 +97,10 @@ def test_refit_matches_fresh_build(gpu_ctx, oracle, scene_cache, flags):
     fresh = api.Scene(gpu_ctx, d2)
     assert np.array_equal(_render(gpu_ctx, fresh, s, p).download(), img), "refit image != image of a fresh build"
     # oracle on the refitted tree (exported from the device) and by brute force
-    nodes, tris, grid = scene.export_bvh()
+    exported = scene.export_bvh()
+    nodes, tris, grid = exported
     _check_bvh(d2, scene.stats(), nodes, tris, grid)
-    ref = oracle.render(d2, s.camera, s.scene_info(0), p, bvh=(nodes, tris, grid), threads=8)
+    ref = oracle.render(d2, s.camera, s.scene_info(0), p, bvh=exported, threads=8)
     assert np.array_equal(img, ref.images[A.IMAGE_SHADOWED])
     assert after.stats().numNodeVisits == ref.stats.numNodeVisits
     brute = oracle.render(d2, s.camera, s.scene_info(0), p, bvh=None, threads=8)
