@@ -14,9 +14,15 @@ de-interleaved there; all of that is inside the timed region.
 
 Rank 0 prints ONE JSON line.  `value` = all rays traced per second (primary + shadow, exact count
 from the kernels' own counters in an untimed stats pass), whole job.  `roofline` is for the dominant
-kernel (k_shadow_trace4): algorithmic bytes per launch / its average launch duration measured with HIP
-events on the render stream inside the timed steps.  `cpu_baseline` is the CPU oracle (a scalar C++
-port, oracle/) timed on the host cores on a bounded sample of the same workload — reported, not a target.
+kernel (k_shadow_trace4, the any-hit traversal of the shadow-ray queue).  The kernel is bound by
+vector-instruction ISSUE, not by HBM (its 17 MB tree is cache-resident: 6 % of its algorithmic bytes
+reach the fabric), so the block reports the ceiling that binds — SIMD issue cycles busy / SIMD cycles
+of the launch, with the launch duration (HIP events on the launch stream) and the shader clock (s_memtime
+over s_memrealtime stamps inside the launch) measured live, lane utilisation from the kernel's counting
+form run in this process, and the counter totals of the committed rocprofv3 passes of the same command
+(profiles/r02/pmc_roofline.json, tagged with the kernel revision) — and, beside it, the HBM and L2
+fractions and the algorithmic byte rate.  `cpu_baseline` is the CPU oracle (a scalar C++ port, oracle/)
+timed on the host cores on a bounded sample of the same workload — reported, not a target.
 """
 import argparse
 import json
@@ -30,13 +36,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0   # same guide: measured streaming copy (SURVEY 8d asks for the fraction of this as well)
+L2_PEAK_GBS = 34500.0    # same guide: L2 aggregate, 8 XCDs
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="sponza_class", choices=["sponza_class", "cornell", "bunny_class"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -61,6 +68,11 @@ def main():
                     help="after the timed region, render this many frames ONE AT A TIME to report per-kernel durations free of "
                          "cross-frame overlap (0 = skip; profiles/run_rocprof.sh skips it so rocprof's averages cover the timed launches only)")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
+    ap.add_argument("--obj", default=None, metavar="PATH",
+                    help="render a real asset instead of the procedural stand-in (SURVEY 8d: 'real bunny.obj / sponza.obj accepted if present'): "
+                         "an OBJ file with its MTL / textures beside it; the camera looks at the centre of its bounds from --obj-view, one area light "
+                         "hangs under the top of the bounds")
+    ap.add_argument("--obj-view", default="-0.45,0.15,0.05", help="camera position as fractions of the bounds' extent from the centre (x,y,z)")
     args = ap.parse_args()
 
     if args.config == 1:
@@ -106,7 +118,20 @@ def main():
             dist.init_process_group(backend="gloo")
 
     W, H, S = args.width, args.height, args.spp
-    setup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
+    if args.obj:
+        vs = np.array([[float(t) for t in ln.split()[1:4]] for ln in open(args.obj, errors="replace") if ln.startswith("v ")], dtype=np.float64)
+        if len(vs) == 0:
+            raise SystemExit(f"bench.py: {args.obj} has no vertices")
+        lo, hi = vs.min(0), vs.max(0)
+        c, e = (lo + hi) / 2, np.maximum(hi - lo, 1e-6)
+        view = np.array([float(t) for t in args.obj_view.split(",")])
+        cam = tuple(float(x) for x in (c + view * e))
+        side = float(0.25 * max(e[0], e[2]))
+        light = (12.0, (1.0, 0.95, 0.9), (float(c[0]), float(hi[1] - 0.02 * e[1]), float(c[2])), (side, side, 1.0), (90.0, 0.0, 0.0))
+        setup = scenes.custom_obj(args.obj, os.path.dirname(os.path.abspath(args.obj)), cam, tuple(float(x) for x in c), fov_y=60.0, width=W, height=H, lights=[light])
+        args.workload = "obj:" + os.path.basename(args.obj)
+    else:
+        setup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
     emu = args.emulate_rank_of if (world == 1 and args.emulate_rank_of > 1) else 0
     nshards = emu if emu else world
     # Several frames are kept in flight on separate streams (one context each, ONE shared scene): the tails of one
@@ -155,9 +180,14 @@ def main():
     # (every hit issues numLights x light-triangles x shadow-rays rays; only the sample positions change)
     rays_per_frame, primary_per_frame = int(counts[0].item()) * K, int(counts[1].item()) * K
     pipeline_used = fs.pipelineUsed
+    sched = {"node_loop_trips": int(fs.shadowInnerIterations), "node_loop_lanes": int(fs.shadowInnerActiveLanes),
+             "triangle_loop_trips": int(fs.shadowTriIterations), "triangle_loop_lanes": int(fs.shadowTriActiveLanes),
+             "refill_passes": int(fs.shadowRefills), "tail_rays": int(fs.shadowTailRays),
+             "wide_visits": int(fs.numShadowNodeVisits), "triangle_tests": int(fs.numShadowTriTests), "shadow_rays": int(fs.numShadowRays)}
 
     p_run = [params(0, j=j) for j in range(K)]
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0}
+    clocks = []
 
     works = [None] * nbuf
 
@@ -203,6 +233,8 @@ def main():
         st = frames[buf].stats()
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
         kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
+        if st.shadowTraceClockMHz > 0:
+            clocks.append(st.shadowTraceClockMHz)
 
     def step(i):
         b = i % nbuf
@@ -251,9 +283,10 @@ def main():
     # flight a launch's HIP-event bracket also contains the time it queued behind / shared CUs with the neighbouring frames'
     # kernels (k_shadow_trace4: 2.7 ms bracket, 2.1 ms dispatch begin->end in rocprof, 1.86 ms alone), so the per-kernel cost
     # and the roofline are taken from this pass; rocprofv3 of `--frames-in-flight 1` reproduces it (profiles/).
-    kern_iso, iso_ms_per_frame = None, None
+    kern_iso, iso_ms_per_frame, clocks_iso = None, None, []
     if nbuf > 1 and args.isolated_frames > 0:
         kern_iso = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0}
+        clocks_iso = []
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for j in range(args.isolated_frames):
@@ -261,6 +294,8 @@ def main():
             st = frames[0].stats()
             kern_iso["primary"] += st.primaryMs / args.isolated_frames; kern_iso["shadow_gen"] += st.shadowGenMs / args.isolated_frames
             kern_iso["shadow_trace"] += st.shadowTraceMs / args.isolated_frames; kern_iso["resolve"] += st.resolveMs / args.isolated_frames
+            if st.shadowTraceClockMHz > 0:
+                clocks_iso.append(st.shadowTraceClockMHz)
         iso_ms_per_frame = (time.perf_counter() - t1) * 1e3 / args.isolated_frames
 
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
@@ -274,35 +309,62 @@ def main():
         trace_bytes = fs.shadowTraceBytes                         # rank 0's launch
         roofline = None
         if pipeline_used == 2 and trace_ms > 0:
-            achieved = trace_bytes / (trace_ms * 1e-3) / 1e9
-            traffic = lookups = valu = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
-                    traffic = tj.get(key, {}).get("k_shadow_trace_hbm_bytes_per_launch")
-                    lookups = tj.get(key, {}).get("k_shadow_trace_l1_tag_lookups_per_launch")
-                    valu = tj.get(key, {}).get("k_shadow_trace_valu_wave_insts_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_shadow_trace4 (+ k_shadow_tail; the any-hit traversal of the shadow-ray queue)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_COPY_GBS, 5),
-                        "hbm_frac": round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                        "algorithmic_bytes_per_launch": int(trace_bytes), "avg_launch_ms": round(trace_ms, 4),
-                        "avg_launch_ms_source": (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
-                                                 if kern_iso else "HIP events on the launch stream over the timed region"),
-                        "in_flight_event_bracket_ms": round(bracket_ms, 4) if kern_iso else None,
-                        # what actually limits the kernel (HBM is not it: the BVH is cache-resident), from committed PMC passes of this
-                        # workload and the launch time measured here; 256 L1s (one tag look-up per clock) and 1024 SIMDs (a wave
-                        # instruction occupies one for 4 clocks) at the 2.4 GHz engine clock
-                        "limits": {"l1_tag_lookup_frac": round(lookups / (256 * 2.4e9 * trace_ms * 1e-3), 4) if lookups else None,
-                                   "valu_busy_frac": round(valu * 4 / (1024 * 2.4e9 * trace_ms * 1e-3), 4) if valu else None,
-                                   # with the 4.2 clocks per instruction the issue-rate microbenchmark measures for this mix
-                                   "valu_issue_frac_at_4p2_clk": round(valu * 4.2 / (1024 * 2.4e9 * trace_ms * 1e-3), 4) if valu else None,
-                                   "source": "profiles/pmc_traffic.json"},
-                        "bvh_layout_version": int(sstats.bvhLayoutVersion)}
+            rev = A.hip_lib().rtr_kernel_revision().decode()
+            pmc, pmc_note = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02", "pmc_roofline.json")
+            key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
+            try:
+                pmc = json.load(open(tpath)).get(key)
+                if pmc is None:
+                    pmc_note = f"no committed counter passes for {key}"
+                elif pmc.get("kernel_revision") != rev:
+                    pmc, pmc_note = None, f"committed counters are of kernel revision {pmc.get('kernel_revision')}, this library is {rev}"
+            except Exception as e:      # noqa: BLE001
+                pmc_note = f"{tpath}: {e}"
+            ck = clocks_iso if (kern_iso and clocks_iso) else clocks
+            clock_mhz = sorted(ck)[len(ck) // 2] if ck else None
+            num_simds = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+            launch_cycles = trace_ms * 1e-3 * clock_mhz * 1e6 if clock_mhz else None
+            busy = pmc["SQ_ACTIVE_INST_VALU_quad"] * 4 / num_simds if pmc else None
+            traffic = pmc["hbm_bytes_per_launch"] if pmc else None
+            roofline = {
+                # the ceiling that binds: one SIMD issues one vector instruction at a time; SQ_ACTIVE_INST_VALU counts, in units of 4
+                # cycles, the time SIMDs spent issuing them
+                "bound": "valu_issue",
+                "kernel": "k_shadow_trace4<16, true, false> (+ k_shadow_tail): any-hit traversal of the shadow-ray queue, revision " + rev,
+                "achieved": round(busy, 1) if busy else None, "peak": round(launch_cycles, 1) if launch_cycles else None,
+                "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch)",
+                "frac": round(busy / launch_cycles, 4) if (busy and launch_cycles) else None,
+                "avg_launch_ms": round(trace_ms, 4),
+                "avg_launch_ms_source": (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
+                                         if kern_iso else "HIP events on the launch stream over the timed region"),
+                "in_flight_event_bracket_ms": round(bracket_ms, 4) if kern_iso else None,
+                "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
+                "clock_source": "s_memtime / s_memrealtime stamps around the launch's persistent loop (lane 0 of the first workgroup of each XCD, median), same launches as avg_launch_ms",
+                "simds": num_simds,
+                "valu_wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]) if pmc else None,
+                "valu_wave_insts_per_ray": round(pmc["SQ_INSTS_VALU"] / sched["shadow_rays"], 2) if pmc else None,
+                # dead lanes: what fraction of the lanes did work in the trips of the kernel's two loops (counting form of the same kernel,
+                # run in this process), and what the hardware says for all vector instructions (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))
+                "lane_util": {"node_loop": round(sched["node_loop_lanes"] / max(64 * sched["node_loop_trips"], 1), 4),
+                              "triangle_loop": round(sched["triangle_loop_lanes"] / max(64 * sched["triangle_loop_trips"], 1), 4),
+                              "all_vector_instructions": round(pmc["derived"]["valu_lane_utilisation"], 4) if pmc else None},
+                "per_ray": {"wide_node_visits": round(sched["wide_visits"] / max(sched["shadow_rays"], 1), 3),
+                            "triangle_tests": round(sched["triangle_tests"] / max(sched["shadow_rays"], 1), 3)},
+                "schedule": sched,
+                # the memory side, for the record: HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (gfx950 corrections in the json),
+                # L1 -> L2 read requests x 64 B, L1 tag look-ups per L1 per clock
+                "traffic": traffic,
+                "hbm_frac": round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "l2_frac": round(pmc["TCP_TCC_READ_REQ"] * 64 / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if pmc else None,
+                "l1_tag_lookups_per_l1_clock": round(pmc["TCP_TOTAL_CACHE_ACCESSES"] / (num_simds / 4 * launch_cycles), 4) if (pmc and launch_cycles) else None,
+                # algorithmic bytes of the same kernel (its counting form): 64 B per 4-wide record visited + 48 B per triangle test + 33 B per
+                # ray.  Served by LDS / L1 / L2 / Infinity Cache: this rate is NOT a fraction of any ceiling and is not the roofline
+                "algorithmic_bytes_per_launch": int(trace_bytes),
+                "algorithmic_gbps": round(trace_bytes / (trace_ms * 1e-3) / 1e9, 1),
+                "algorithmic_over_hbm_peak": round(trace_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pmc_source": "profiles/r02/pmc_roofline.json" if pmc else None, "pmc_note": pmc_note,
+                "layout": {"bvh": int(sstats.bvhLayoutVersion), "wide": int(sstats.wideLayoutVersion)}}
         elif trace_ms == 0 and kern["primary"] > 0:
             mk_ms = kern["primary"] / n
             achieved = fs.algorithmicBytes / (mk_ms * 1e-3) / 1e9
@@ -314,7 +376,7 @@ def main():
             "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S, K) == (1920, 1080, 1, 1) else f"Mrays/sec at {W}x{H} {S}spp" + (f" x{K} frames accumulated in HDR" if K > 1 else ""),
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / K, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("file " + args.obj) if args.obj else "synthetic",
             "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
                                    f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{world}",
                        "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame,

@@ -265,6 +265,8 @@ int  rtr_deinterleave_bands(rtr_ctx* ctx, const void* gathered, void* dst, uint3
 const char* rtr_last_error(void);
 const char* rtr_status_string(int status);
 int         rtr_abi_version(void);
+/* Revision tag of the any-hit kernel + the tree layout it walks (bumped when either changes); measurement files carry it. */
+const char* rtr_kernel_revision(void);
 
 #ifdef __cplusplus
 }

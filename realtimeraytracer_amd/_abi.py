@@ -155,6 +155,7 @@ RTR_SYMBOLS = {
     "rtr_last_error": (C.c_char_p, []),
     "rtr_status_string": (C.c_char_p, [C.c_int]),
     "rtr_abi_version": (C.c_int, []),
+    "rtr_kernel_revision": (C.c_char_p, []),
 }
 
 RTRH_SYMBOLS = {

@@ -172,6 +172,8 @@ const char* rtr_status_string(int s) {
 
 int rtr_abi_version(void) { return RTR_ABI_VERSION; }
 
+const char* rtr_kernel_revision(void) { return RTR_ANYHIT_KERNEL_REVISION; }
+
 uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount) {
     if (bandRows == 0) bandRows = 8;
     if (shardCount <= 1) return height;               /* unsharded: no padding rows */
