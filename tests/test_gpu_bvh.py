@@ -49,6 +49,9 @@ def test_device_lbvh_build(gpu_ctx, oracle, scene_cache, which):
     assert np.array_equal(f_lbvh.download(), ref.images[A.IMAGE_SHADOWED])
     g = f_lbvh.stats()
     assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits)
+    # the timed kernels (no counters) on the device-built tree, against the oracle directly
+    p0 = api.make_params(W, H, spp=2, collect_stats=0)
+    assert np.array_equal(_render(gpu_ctx, lbvh, s, p0).download(), ref.images[A.IMAGE_SHADOWED]), "timed kernels on the LBVH tree vs oracle"
     # deterministic: a second device build gives the same bytes
     n2, t2, g2 = api.Scene(gpu_ctx, _with_flags(s.desc, A.BUILD_DEVICE_LBVH)).export_bvh()
     assert bytes(n2) == bytes(nodes) and bytes(t2) == bytes(tris) and bytes(g2) == bytes(grid)

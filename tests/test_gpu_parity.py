@@ -160,32 +160,44 @@ def test_hdr_accumulation_matches_oracle(gpu_ctx, oracle, scene_cache):
     assert not frame.download(A.IMAGE_HDR).any()
 
 
+@pytest.mark.parametrize("collect", [0, 1])
 @pytest.mark.parametrize("pipeline", [1, 2])
-def test_bunny_class_parity(gpu_ctx, oracle, scene_cache, pipeline):
-    """BASELINE config 3 geometry (81,920-triangle displaced icosphere, smooth normals), 4 spp, reduced extent."""
+def test_bunny_class_parity(gpu_ctx, oracle, scene_cache, pipeline, collect):
+    """BASELINE config 3 geometry (81,920-triangle displaced icosphere, smooth normals), 4 spp, reduced extent.  collect = 0: the
+    kernels the bench times (k_primary with its 16-entry LDS stack + redo tail, the spp > 1 branch of k_shadow_gen, the timed form
+    of k_shadow_trace4), compared with the oracle directly; collect = 1: their counting forms, counters included."""
     W, H = 480, 272
     s = scenes.bunny_class(W, H)
-    p = api.make_params(W, H, spp=4, collect_stats=1, pipeline=pipeline)
+    p = api.make_params(W, H, spp=4, collect_stats=collect, pipeline=pipeline)
     scene, frame = _gpu_render(gpu_ctx, s, p)
     assert scene.stats().numTriangles == 81920 + 512 + 2
     ref = oracle.render(s.desc, s.camera, s.scene_info(0), p, bvh=scene.export_bvh(), threads=16)
-    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"bunny-class pipeline{pipeline}")
-    g = frame.stats()
-    assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits)
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"bunny-class pipeline{pipeline} collect{collect}")
+    if collect:
+        g = frame.stats()
+        assert (g.numRays, g.numNodeVisits, g.numTriTests, g.numHits) == (ref.stats.numRays, ref.stats.numNodeVisits, ref.stats.numTriTests, ref.stats.numHits)
 
 
+@pytest.mark.parametrize("collect", [0, 1])
 @pytest.mark.parametrize("pipeline", [1, 2])
-def test_sponza_class_parity(gpu_ctx, oracle, scene_cache, pipeline):
-    """BASELINE config 4 geometry (262 k triangles, 2 area lights), 1 spp, reduced extent, full oracle compare."""
+def test_sponza_class_parity(gpu_ctx, oracle, scene_cache, pipeline, collect):
+    """BASELINE config 4 geometry (262 k triangles, 2 area lights), 1 spp, reduced extent, full oracle compare — the timed kernels
+    (collect = 0) and their counting forms (collect = 1), each against the oracle directly."""
     W, H = 640, 360
     s = scenes.sponza_class(W, H)
-    p = api.make_params(W, H, spp=1, collect_stats=1, pipeline=pipeline)
+    p = api.make_params(W, H, spp=1, collect_stats=collect, pipeline=pipeline)
     scene, frame = _gpu_render(gpu_ctx, s, p, frame_no=5)
     ref = oracle.render(s.desc, s.camera, s.scene_info(5), p, bvh=scene.export_bvh(), threads=16)
-    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"sponza-class pipeline{pipeline}")
-    g = frame.stats()
-    for f in ("numRays", "numShadowRays", "numNodeVisits", "numTriTests", "numShadowNodeVisits", "numShadowTriTests", "numHits", "shadowTraceBytes"):
-        assert getattr(g, f) == getattr(ref.stats, f), f
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"sponza-class pipeline{pipeline} collect{collect}")
+    if collect:
+        g = frame.stats()
+        for f in ("numRays", "numShadowRays", "numNodeVisits", "numTriTests", "numShadowNodeVisits", "numShadowTriTests", "numHits", "shadowTraceBytes"):
+            assert getattr(g, f) == getattr(ref.stats, f), f
+        if pipeline == 2:
+            # every lane counted in a trip of the node loop visited one 4-wide record there (tail rays walk the BVH2 elsewhere)
+            assert g.shadowInnerIterations > 0 and (g.shadowInnerActiveLanes == g.numShadowNodeVisits or g.shadowTailRays > 0)
+            assert g.shadowTriIterations > 0 and (g.shadowTriActiveLanes == g.numShadowTriTests or g.shadowTailRays > 0)
+            assert g.shadowTraceClockMHz > 500.0
 
 
 def test_sponza_1080p_properties_and_sampled_oracle(gpu_ctx, oracle, scene_cache):
@@ -216,6 +228,31 @@ def test_sponza_1080p_properties_and_sampled_oracle(gpu_ctx, oracle, scene_cache
     p8 = api.make_params(W, H, shard_index=0, shard_count=8)
     ref = oracle.render(s.desc, s.camera, s.scene_info(0), p8, bvh=scene.export_bvh(), threads=16)
     _assert_same(gathered[0], ref.images[A.IMAGE_SHADOWED], "shard 0 of 8 vs oracle at 1080p")
+
+
+def test_bunny_1080p_4spp_properties_and_sampled_oracle(gpu_ctx, oracle, scene_cache):
+    """BASELINE.json config 3 at its own size (bunny-class, 1920x1080, 4 spp = the reference's NUM_PRIMARY_RAYS, raygen.rgen:8) on the
+    timed kernels: megakernel == wavefront, idempotence, 8-shard reassembly == unsharded, and the oracle on every 8th band (shard
+    0 of 8).  The fixture runs it with the plain and with the octant-binned queue."""
+    from realtimeraytracer_amd import mgpu
+    W, H = 1920, 1080
+    s = scenes.bunny_class(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    _, fw = _gpu_render(gpu_ctx, s, api.make_params(W, H, spp=4, pipeline=2), scene=scene)
+    wave = fw.download()
+    _, fm = _gpu_render(gpu_ctx, s, api.make_params(W, H, spp=4, pipeline=1), scene=scene)
+    _assert_same(fm.download(), wave, "bunny 1080p 4 spp: megakernel vs wavefront")
+    api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, spp=4, pipeline=2), fw)
+    _assert_same(fw.download(), wave, "bunny 1080p 4 spp: idempotence")
+    rows = api.shard_rows(H, 8, 8)
+    gathered = np.zeros((8, rows, W), np.uint32)
+    for r in range(8):
+        _, fr = _gpu_render(gpu_ctx, s, api.make_params(W, H, spp=4, shard_index=r, shard_count=8), scene=scene)
+        gathered[r] = fr.download()
+    _assert_same(mgpu.assemble_numpy(gathered, H, 8), wave, "bunny 1080p 4 spp: 8-shard reassembly")
+    p8 = api.make_params(W, H, spp=4, shard_index=0, shard_count=8)
+    ref = oracle.render(s.desc, s.camera, s.scene_info(0), p8, bvh=scene.export_bvh(), threads=16)
+    _assert_same(gathered[0], ref.images[A.IMAGE_SHADOWED], "bunny 1080p 4 spp: shard 0 of 8 vs oracle")
 
 
 def test_4k_accumulated_sample(gpu_ctx, oracle, scene_cache):
@@ -351,21 +388,24 @@ def test_denoise_combine_matches_oracle(gpu_ctx, oracle, scene_cache, size):
         small.denoise_combine(4)
 
 
+@pytest.mark.parametrize("collect", [0, 1])
 @pytest.mark.parametrize("pipeline", [1, 2])
-def test_textured_room_parity(gpu_ctx, oracle, scene_cache, pipeline):
+def test_textured_room_parity(gpu_ctx, oracle, scene_cache, pipeline, collect):
     """texture maps (colour / specular / metallic), alpha-tested any-hit on both closest-hit and
-    shadow rays, repeat addressing with tiled and negative uvs, equirect HDRI miss — all five images, bit-exact."""
+    shadow rays, repeat addressing with tiled and negative uvs, equirect HDRI miss — all five images, bit-exact, from the timed
+    kernels (collect = 0) and from their counting forms (collect = 1)."""
     W, H = 400, 248
     s = scenes.textured_room(W, H, ltc=scenes.synthetic_ltc())
-    p = api.make_params(W, H, spp=2, images=A.IMAGES_RAYGEN5, collect_stats=1, pipeline=pipeline)
+    p = api.make_params(W, H, spp=2, images=A.IMAGES_RAYGEN5, collect_stats=collect, pipeline=pipeline)
     scene, frame = _gpu_render(gpu_ctx, s, p, images=A.IMAGES_RAYGEN5, frame_no=3)
     ref = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=scene.export_bvh(), images=A.IMAGES_RAYGEN5, threads=16)
     for which, name in NAMES.items():
-        _assert_same(frame.download(which), ref.images[which], f"textured room {name} pipeline{pipeline}")
-    g = frame.stats()
-    for f in ("numRays", "numNodeVisits", "numTriTests", "numHits", "numTexFetches", "numAlphaTests", "algorithmicBytes"):
-        assert getattr(g, f) == getattr(ref.stats, f), f
-    assert g.numAlphaTests > 10000 and g.numTexFetches > g.numHits
+        _assert_same(frame.download(which), ref.images[which], f"textured room {name} pipeline{pipeline} collect{collect}")
+    if collect:
+        g = frame.stats()
+        for f in ("numRays", "numNodeVisits", "numTriTests", "numHits", "numTexFetches", "numAlphaTests", "algorithmicBytes"):
+            assert getattr(g, f) == getattr(ref.stats, f), f
+        assert g.numAlphaTests > 10000 and g.numTexFetches > g.numHits
 
 
 def test_missing_texture_is_refused_on_device_path(gpu_ctx, scene_cache):
