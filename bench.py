@@ -224,6 +224,19 @@ def main():
 
     inflight = [False] * nbuf
 
+    # N > 1 over RCCL: the sharded frame comes from librtr_mgpu.so (include/rtr_mgpu.h) — the same C entry points a C++ caller of the
+    # library would use: one rank per process (rtr_mgpu_create_rank; the communicator id travels through torch.distributed), nbuf
+    # frame slots with a render stream each, a communication stream with grouped ncclSend / ncclRecv to rank 0, k_deinterleave
+    use_lib = dist_on and args.backend == "nccl"
+    mg = None
+    if use_lib:
+        uid = torch.zeros(A.MGPU_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(mgpu.MultiGpu.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        mg = mgpu.MultiGpu.rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), frames_in_flight=nbuf)
+        mg.scene_create(setup.desc)
+
     def collect(buf):
         """host-side join of the frame that used `buf` (the other frames stay in flight) + its per-launch HIP-event times"""
         if not inflight[buf]:
@@ -236,9 +249,26 @@ def main():
         if st.shadowTraceClockMHz > 0:
             clocks.append(st.shadowTraceClockMHz)
 
+    def lib_collect(b):
+        if not inflight[b]:
+            return
+        mg.wait(b)
+        inflight[b] = False
+        st = mg.frame_stats(b, 0)
+        kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
+        kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
+        if st.shadowTraceClockMHz > 0:
+            clocks.append(st.shadowTraceClockMHz)
+
     def step(i):
         b = i % nbuf
         last_buf[0] = b
+        if use_lib:
+            lib_collect(b)                              # frame i-nbuf: done long ago unless the host runs ahead
+            for j in range(K):
+                mg.render_async(b, setup.camera, setup.scene_info(j if K > 1 else i), p_run[j], exchange=(j == K - 1))
+            inflight[b] = True
+            return
         with torch.cuda.stream(streams[b]):
             collect(b)                                  # frame i-nbuf: done long ago unless the host runs ahead
             finish(b)                                   # its gather (stream-level wait) + de-interleave on rank 0
@@ -248,6 +278,10 @@ def main():
                 works[b] = gather_async(b)              # RCCL gather to rank 0; runs under the other streams' kernels
 
     def drain():
+        if use_lib:
+            for b in range(nbuf):
+                lib_collect(b)
+            return
         for b in range(nbuf):
             with torch.cuda.stream(streams[b]):
                 collect(b)
@@ -262,6 +296,9 @@ def main():
     # fewer warm-up steps than frames in flight that first render — a few synchronous hipMallocs — would land in the timed region
     for b in range(nbuf):
         render_step(frames[b], 0, p_run, False)
+        if use_lib:
+            step(b)                                     # the library's slots allocate on their first render too
+    drain()
     for i in range(args.warmup):
         step(i)
     drain()
@@ -437,11 +474,15 @@ def main():
         whole = api.Frame(ctx, W, H, images)
         render_step(whole, last_i, [params(0, 0, 1, j=j) for j in range(K)], False)
         torch.cuda.synchronize()
-        bad = int((fulls[last_i % nbuf].cpu().numpy().view(np.uint32) != whole.download()).sum())
-        out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i}
+        assembled = mg.download(last_i % nbuf) if use_lib else fulls[last_i % nbuf].cpu().numpy().view(np.uint32)
+        bad = int((assembled != whole.download()).sum())
+        out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i,
+                         "gather": "librtr_mgpu.so: grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave" if use_lib else "torch.distributed gather (rehearsal backend)"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if mg is not None:
+        mg.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

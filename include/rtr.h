@@ -188,6 +188,8 @@ int  rtr_ctx_create(int deviceOrdinal, rtr_ctx** out);
 void rtr_ctx_destroy(rtr_ctx* ctx);
 /* Use an existing HIP stream (e.g. torch's current stream) for all work of this ctx; NULL -> own stream. */
 int  rtr_ctx_set_stream(rtr_ctx* ctx, void* hipStream);
+/* The HIP stream (hipStream_t) this context's work is enqueued on, for callers that order their own work against it with events. */
+int  rtr_ctx_get_stream(rtr_ctx* ctx, void** hipStream);
 int  rtr_ctx_device_name(rtr_ctx* ctx, char* buf, size_t bytes);
 
 /* ---- scene ---------------------------------------------------------------------------- */

@@ -1,0 +1,85 @@
+/* rtr_mgpu.h — C ABI of librtr_mgpu.so: the frame tile-sharded over the GPUs of one node, assembled on rank 0 with ONE exchange
+ * step over xGMI (RCCL grouped send / recv), SURVEY.md §8b "Threading" row and §8e.
+ *
+ * The reference renders on one GPU (one vkCmdTraceRaysKHR per frame, src/app/application.cppm:362-389); this is the part of
+ * the north star that has no counterpart there.  librtr_mgpu.so is a pure client of include/rtr.h (librtr_hip.so) plus RCCL and
+ * the HIP runtime: it owns one rtr_ctx + one replicated rtr_scene per rank, the RCCL communicator, one host thread per local
+ * rank (enqueueing a shard costs ~25 us of host time, which eight ranks must not pay one after the other), one render stream per
+ * frame slot and one communication stream per rank, ordered against each other with events — so that the kernels of several
+ * frames overlap on a GPU (a 1/8-frame shard cannot fill it) and the gather of frame n runs under the rendering of frame n+1.
+ *
+ * Partitioning (same as rtr_render_params::shardIndex / shardCount): interleaved bands of 8 rows, band b -> rank b mod N; every
+ * rank renders rtr_shard_rows() rows into a compact image; rank 0 receives the N-1 other shards next to its own (it renders
+ * straight into slot 0 of the gather buffer) and de-interleaves them into the full frame (k_deinterleave).  Pixels are
+ * independent and the PCG seeds depend only on (x, y, sample, frame), so the assembled frame is bit-identical to the one-GPU frame.
+ *
+ * Two ways to make the ranks:
+ *   rtr_mgpu_create       one process drives n devices (ncclCommInitAll); what a C++ application like the reference's would use;
+ *   rtr_mgpu_create_rank  one process per GPU (ncclCommInitRank with an id made by rtr_mgpu_unique_id on rank 0 and handed to the
+ *                         others by the launcher's own means); what bench.py does under torch.distributed.run.
+ * Handles are not thread-safe; calls return an rtr_status (include/rtr.h) and rtr_mgpu_last_error() has the message.
+ */
+#ifndef RTR_MGPU_H
+#define RTR_MGPU_H
+
+#include "rtr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtr_mgpu rtr_mgpu;
+
+#define RTR_MGPU_ID_BYTES 128          /* sizeof(ncclUniqueId) */
+#define RTR_MGPU_MAX_SLOTS 8
+
+/* Fills `id` (RTR_MGPU_ID_BYTES bytes) with a fresh communicator id: call on one rank, distribute to all. */
+int  rtr_mgpu_unique_id(void* id);
+
+/* One process, n devices (ordinals in `devices`, rank r = devices[r]).  framesInFlight frame slots (1..RTR_MGPU_MAX_SLOTS). */
+int  rtr_mgpu_create(const int* devices, int n, int framesInFlight, rtr_mgpu** out);
+/* This process is rank `rank` of `nranks`, on HIP device `device`. */
+int  rtr_mgpu_create_rank(int device, int rank, int nranks, const void* id, int framesInFlight, rtr_mgpu** out);
+void rtr_mgpu_destroy(rtr_mgpu* m);
+
+/* Replicates the scene on every local rank (rtr_scene_create per device; the caller keeps its arrays). */
+int  rtr_mgpu_scene_create(rtr_mgpu* m, const rtr_scene_desc* desc);
+
+/* Renders the frame into slot `slot`: every local rank enqueues its shard (rtr_render_async), then the exchange on its
+ * communication stream (rank 0: grouped ncclRecv x (N-1) + k_deinterleave; others: ncclSend).  params->shardIndex / shardCount
+ * are set by the library; width, height, spp, numShadowRays, bandRows are the caller's; images is RTR_IMAGES_FRAMEBUFFER, plus
+ * RTR_IMG_BIT(RTR_IMAGE_HDR) when frames are summed (accumulate / accumulatedFrames as in rtr_render; each shard keeps its own
+ * float accumulator and tonemaps it, the RGBA8 result is what travels).  flags: RTR_MGPU_NO_EXCHANGE renders without the
+ * exchange — the frames of a sum before its last.  Returns when everything is enqueued; rtr_mgpu_wait joins.  Calls on one slot
+ * are ordered; a slot's previous exchange is waited for (on the GPU, by an event) before its buffers are overwritten. */
+#define RTR_MGPU_NO_EXCHANGE 1
+int  rtr_mgpu_render_async(rtr_mgpu* m, int slot, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo, const rtr_render_params* params, int flags);
+int  rtr_mgpu_wait(rtr_mgpu* m, int slot);
+/* rtr_mgpu_render_async + rtr_mgpu_wait on slot 0. */
+int  rtr_mgpu_render(rtr_mgpu* m, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo, const rtr_render_params* params);
+
+/* The assembled frame (height x width RGBA8, bytes B,G,R,255) of a waited-for slot; only where rank 0 is local
+ * (RTR_ERR_INVALID_ARGUMENT elsewhere). */
+int  rtr_mgpu_frame_download(rtr_mgpu* m, int slot, void* dst, size_t bytes);
+int  rtr_mgpu_frame_device_ptr(rtr_mgpu* m, int slot, void** devicePtr, size_t* bytes);
+/* Per-kernel times of a local rank's shard render of a waited-for slot (rtr_frame_get_stats of its frame). */
+int  rtr_mgpu_frame_stats(rtr_mgpu* m, int slot, int localRank, rtr_frame_stats* out);
+/* This rank's own shard (rtr_shard_rows x width) of a waited-for slot: localRank indexes the ranks of this process. */
+int  rtr_mgpu_shard_download(rtr_mgpu* m, int slot, int localRank, void* dst, size_t bytes);
+
+typedef struct rtr_mgpu_info {
+    int nranks;          /* size of the communicator */
+    int nlocal;          /* ranks driven by this process */
+    int firstRank;       /* rank of local rank 0 */
+    int framesInFlight;
+    int selfExchange;    /* 1: a one-rank communicator still sends its shard to itself through RCCL (RTR_MGPU_SELF_EXCHANGE=1; test hook) */
+    int _pad[3];
+} rtr_mgpu_info;
+int  rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out);
+
+const char* rtr_mgpu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTR_MGPU_H */

@@ -130,6 +130,7 @@ RTR_SYMBOLS = {
     "rtr_ctx_create": (C.c_int, [C.c_int, P(VP)]),
     "rtr_ctx_destroy": (None, [VP]),
     "rtr_ctx_set_stream": (C.c_int, [VP, VP]),
+    "rtr_ctx_get_stream": (C.c_int, [VP, P(VP)]),
     "rtr_ctx_device_name": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
     "rtr_scene_create": (C.c_int, [VP, P(rtr_scene_desc), P(VP)]),
     "rtr_scene_destroy": (None, [VP]),
@@ -198,6 +199,34 @@ RTRH_SYMBOLS = {
 }
 
 
+class rtr_mgpu_info(C.Structure):
+    _fields_ = [("nranks", C.c_int), ("nlocal", C.c_int), ("firstRank", C.c_int), ("framesInFlight", C.c_int),
+                ("selfExchange", C.c_int), ("_pad", C.c_int * 3)]
+
+
+MGPU_ID_BYTES = 128
+MGPU_MAX_SLOTS = 8
+MGPU_NO_EXCHANGE = 1
+
+# every entry point include/rtr_mgpu.h declares
+MGPU_SYMBOLS = {
+    "rtr_mgpu_unique_id": (C.c_int, [VP]),
+    "rtr_mgpu_create": (C.c_int, [P(C.c_int), C.c_int, C.c_int, P(VP)]),
+    "rtr_mgpu_create_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, VP, C.c_int, P(VP)]),
+    "rtr_mgpu_destroy": (None, [VP]),
+    "rtr_mgpu_scene_create": (C.c_int, [VP, P(rtr_scene_desc)]),
+    "rtr_mgpu_render_async": (C.c_int, [VP, C.c_int, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), C.c_int]),
+    "rtr_mgpu_wait": (C.c_int, [VP, C.c_int]),
+    "rtr_mgpu_render": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params)]),
+    "rtr_mgpu_frame_download": (C.c_int, [VP, C.c_int, VP, C.c_size_t]),
+    "rtr_mgpu_frame_device_ptr": (C.c_int, [VP, C.c_int, P(VP), P(C.c_size_t)]),
+    "rtr_mgpu_shard_download": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_size_t]),
+    "rtr_mgpu_frame_stats": (C.c_int, [VP, C.c_int, C.c_int, P(rtr_frame_stats)]),
+    "rtr_mgpu_get_info": (C.c_int, [VP, P(rtr_mgpu_info)]),
+    "rtr_mgpu_last_error": (C.c_char_p, []),
+}
+
+
 def _bind(path, table, what):
     if not os.path.exists(path):
         raise ImportError(
@@ -216,6 +245,17 @@ def _bind(path, table, what):
 
 _hip = None
 _host = None
+_mgpu = None
+LIB_MGPU_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtr_mgpu.so")
+
+
+def mgpu_lib():
+    """librtr_mgpu.so (include/rtr_mgpu.h): the tile-sharded frame over several GPUs, RCCL inside.  Loaded after librtr_hip.so."""
+    global _mgpu
+    if _mgpu is None:
+        hip_lib()
+        _mgpu = _bind(LIB_MGPU_PATH, MGPU_SYMBOLS, "librtr_mgpu.so")
+    return _mgpu
 
 
 def hip_lib():

@@ -676,7 +676,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const float tmin = 0.001f;
     /* nodes and triangles through buffer resources: the address of a visit is one 32-bit shift, not 64-bit lane arithmetic
      * (2.28 -> 2.17 ms, and 62 -> 47 VGPRs) */
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes4, 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, 0, 0xffffffff, 0x00020000);
 

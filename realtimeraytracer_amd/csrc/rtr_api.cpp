@@ -220,6 +220,12 @@ int rtr_ctx_set_stream(rtr_ctx* c, void* s) {
     return RTR_OK;
 }
 
+int rtr_ctx_get_stream(rtr_ctx* c, void** out) {
+    if (!c || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_get_stream: null argument");
+    *out = (void*)c->stream;
+    return RTR_OK;
+}
+
 int rtr_ctx_device_name(rtr_ctx* c, char* buf, size_t bytes) {
     if (!c || !buf || bytes == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_device_name: bad argument");
     snprintf(buf, bytes, "%s (%s)", c->prop.name, c->prop.gcnArchName);

@@ -29,6 +29,39 @@ def test_header_symbols_are_exported_and_bound():
         assert n in names, f"{n} bound but not declared in include/rtr.h"
 
 
+def test_mgpu_header_symbols_are_exported_and_bound():
+    """include/rtr_mgpu.h <-> librtr_mgpu.so <-> _abi.MGPU_SYMBOLS (load + symbols only: no compute without a GPU)."""
+    text = open(os.path.join(ROOT, "include", "rtr_mgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rtr_mgpu_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 12
+    lib = A.mgpu_lib()
+    for n in names:
+        assert hasattr(lib, n), f"librtr_mgpu.so does not export {n}"
+        assert n in A.MGPU_SYMBOLS, f"{n} declared in include/rtr_mgpu.h but not bound in _abi.MGPU_SYMBOLS"
+    for n in A.MGPU_SYMBOLS:
+        assert n in names, f"{n} bound but not declared in include/rtr_mgpu.h"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", A.LIB_MGPU_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(names) <= exported
+    ldd = subprocess.check_output(["ldd", A.LIB_MGPU_PATH]).decode()
+    assert "librccl" in ldd and "librtr_hip" in ldd and "oracle" not in ldd
+    assert C.sizeof(A.rtr_mgpu_info) == 32
+
+
+def test_mgpu_rejects_bad_arguments_and_missing_device():
+    import torch
+    lib = A.mgpu_lib()
+    h = A.VP()
+    assert lib.rtr_mgpu_create(None, 0, 1, C.byref(h)) == -1
+    assert lib.rtr_mgpu_render(None, None, None, None) == -1
+    assert lib.rtr_mgpu_wait(None, 0) == -1
+    if not torch.cuda.is_available():
+        devs = (C.c_int * 1)(0)
+        assert lib.rtr_mgpu_create(devs, 1, 1, C.byref(h)) == -3 and not h.value     # RTR_ERR_NO_DEVICE, never a CPU path
+        assert b"no CPU fallback" in lib.rtr_mgpu_last_error()
+
+
 def test_exports_are_c_linkage():
     out = subprocess.check_output(["nm", "-D", "--defined-only", A.LIB_HIP_PATH]).decode()
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}

@@ -1,11 +1,15 @@
 """Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
 inputs.  Bar: RGBA8 images bit-exact (integer framebuffer); HDR float accumulation bit-exact as well
 (tolerance 0: both sides evaluate the same IEEE expression tree, include/rtr_math.h)."""
+import os
+
 import numpy as np
 import pytest
 
 from realtimeraytracer_amd import _abi as A
 from realtimeraytracer_amd import api, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("queue_mode")]
 
@@ -571,3 +575,50 @@ print("two-wide ok")
     env = dict(os.environ, RTR_TRACE_BVH4="0", PYTHONPATH=root, RTR_SCENE_CACHE=str(scene_cache))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "two-wide ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
+    """include/rtr_mgpu.h: the sharded frame behind the C ABI, ONE process driving every GPU of the box (1 on the test box) through a
+    real RCCL communicator.  With one rank RTR_MGPU_SELF_EXCHANGE=1 makes the shard travel through grouped ncclSend / ncclRecv
+    all the same, so communicator, communication stream, events, gather buffer and k_deinterleave are exercised; two frame slots
+    are kept in flight.  Assembled frame == unsharded frame == oracle, 0 pixels."""
+    import subprocess, sys, textwrap
+    # its own process: RCCL initialises its own state, and a failure (or a hang, hence the timeout) must not take the suite down
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, os.getcwd())
+        import numpy as np, torch
+        from realtimeraytracer_amd import _abi as A, api, mgpu, scenes
+        from oracle import oracle_py as O
+        n = torch.cuda.device_count()
+        W, H = 640, 360
+        s = scenes.cornell_box(W, H)
+        m = mgpu.MultiGpu(devices=list(range(n)), frames_in_flight=2)
+        assert m.info.nranks == n and m.info.nlocal == n and m.info.selfExchange == (1 if os.environ.get("RTR_MGPU_SELF_EXCHANGE") == "1" else 0)
+        m.scene_create(s.desc)
+        p = api.make_params(W, H, spp=2)
+        m.render_async(0, s.camera, s.scene_info(0), p)
+        m.render_async(1, s.camera, s.scene_info(1), p)          # second slot in flight behind the first
+        m.wait(0); m.wait(1)
+        got0, got1 = m.download(0), m.download(1)
+        m.render_async(0, s.camera, s.scene_info(2), p)          # slot reuse: ordered behind its previous exchange by an event
+        m.wait(0)
+        got2 = m.download(0)
+        ctx = api.Context(0)
+        scene = api.Scene(ctx, s.desc)
+        frame = api.Frame(ctx, W, H)
+        bvh = scene.export_bvh()
+        for f, got in ((0, got0), (1, got1), (2, got2)):
+            api.render(scene, s.camera, s.scene_info(f), p, frame)
+            whole = frame.download()
+            assert int((got != whole).sum()) == 0, ("assembled vs unsharded", f, int((got != whole).sum()))
+            ref = O.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, threads=8)
+            assert int((got != ref.images[A.IMAGE_SHADOWED]).sum()) == 0, ("assembled vs oracle", f)
+        shard = m.download_shard(0, 0)
+        assert shard.shape == (api.shard_rows(H, 8, n), W)
+        m.close()
+        print("MGPU_OK", n)
+    """)
+    env = dict(os.environ, RTR_MGPU_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "MGPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
