@@ -9,6 +9,7 @@
 //   scene::SceneInfo         <- reference src/scene/scene_info.cppm:10-20
 //   scene::geometry::Vertex  <- reference src/scene/geometry/vertex.cppm:11-52
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -41,49 +42,60 @@ public:
     Camera(float fovY, vm::vec3 position, vm::vec3 lookAt, vm::vec3 upVector, int pixelWidth, int pixelHeight)
         : GPUDataNeedsUpdate_(true), position_(position), lookAtPoint_(lookAt), upVector_(upVector), fovY_(fovY),
           pixelWidth_(pixelWidth), pixelHeight_(pixelHeight) {
-        // initial yaw / pitch from the lookAt direction (camera.cppm:83-86)
-        vm::vec3 dir = vm::normalize(lookAtPoint_ - position_);
-        pitch_ = vm::degrees(std::asin(dir.y));
-        yaw_ = vm::degrees(std::atan2(dir.z, dir.x));
+        // the angles the camera starts from are those of the unit vector towards the look-at point (behaviour of camera.cppm:83-86)
+        const vm::vec3 towards = vm::normalize(lookAtPoint_ - position_);
+        yaw_ = vm::degrees(std::atan2(towards.z, towards.x));
+        pitch_ = vm::degrees(std::asin(towards.y));
         updateGPUData();
     }
 
-    void processMouseMovement(float xoffset, float yoffset) {   // camera.cppm:136-148
-        constexpr float sensitivity = 0.1f;
-        yaw_ += xoffset * sensitivity;
-        pitch_ += yoffset * sensitivity;
-        if (pitch_ > 89.0f) pitch_ = 89.0f;
-        if (pitch_ < -89.0f) pitch_ = -89.0f;
+    // Mouse look (behaviour of camera.cppm:136-148): a tenth of a degree per unit of mouse travel; pitch stops one degree short of
+    // straight up / down.
+    void processMouseMovement(float xoffset, float yoffset) {
+        const float degreesPerUnit = 0.1f, pitchLimit = 89.0f;
+        yaw_ += xoffset * degreesPerUnit;
+        pitch_ = std::min(pitchLimit, std::max(-pitchLimit, pitch_ + yoffset * degreesPerUnit));
         GPUDataNeedsUpdate_ = true;
     }
 
-    void updateGPUData() {                                       // camera.cppm:98-134
+    // Behaviour of camera.cppm:98-134: the view direction follows from yaw / pitch (degrees), the look-at point is re-derived from
+    // it, and the 64-B record holds the eye, the world-space step per pixel along the image's right (+x) and down (+y) axes, and the
+    // world-space position of the image's top-left corner on the plane one unit in front of the eye.  The float operations and
+    // their order are the reference's (the known answers of SURVEY Appendix B pin them); the code is organised around a small
+    // orthonormal frame instead.
+    struct ViewFrame { vm::vec3 back, right, up; };           // back = away from what is looked at
+
+    static vm::vec3 directionFromAngles(float yawDegrees, float pitchDegrees) {
+        const float yaw = vm::radians(yawDegrees), pitch = vm::radians(pitchDegrees);
+        vm::vec3 d;
+        d.x = std::cos(pitch) * std::cos(yaw);
+        d.y = std::sin(pitch);
+        d.z = std::cos(pitch) * std::sin(yaw);
+        return vm::normalize(d);
+    }
+
+    ViewFrame frameTowards(vm::vec3 target) const {
+        ViewFrame f;
+        f.back = vm::normalize(position_ - target);
+        f.right = vm::normalize(vm::cross(upVector_, f.back));
+        f.up = vm::cross(f.back, f.right);
+        return f;
+    }
+
+    void updateGPUData() {
         if (!GPUDataNeedsUpdate_) return;
-        float aspect = float(pixelWidth_) / float(pixelHeight_);
-        float theta = vm::radians(fovY_);
-        float halfHeight = std::tan(theta * 0.5f);
-        float halfWidth = aspect * halfHeight;
-        float yawRadians = vm::radians(yaw_);
-        float pitchRadians = vm::radians(pitch_);
-        vm::vec3 direction;
-        direction.x = std::cos(pitchRadians) * std::cos(yawRadians);
-        direction.y = std::sin(pitchRadians);
-        direction.z = std::cos(pitchRadians) * std::sin(yawRadians);
-        direction = vm::normalize(direction);
-        lookAtPoint_ = position_ + direction;
-        vm::vec3 w = vm::normalize(position_ - lookAtPoint_);
-        vm::vec3 u = vm::normalize(vm::cross(upVector_, w));
-        vm::vec3 v = vm::cross(w, u);
-        forward_ = -w;
-        right_ = u;
-        vm::vec3 hd = (2.0f * halfWidth * u) / float(pixelWidth_);
-        vm::vec3 vd = -((2.0f * halfHeight * v) / float(pixelHeight_));
-        vm::vec3 tl = position_ - (halfWidth * u) + (halfHeight * v) - w;
+        lookAtPoint_ = position_ + directionFromAngles(yaw_, pitch_);
+        const ViewFrame f = frameTowards(lookAtPoint_);
+        forward_ = -f.back;
+        right_ = f.right;
+        // half extents of the image plane at distance 1: vertical from the field of view, horizontal through the pixel aspect
+        const float halfV = std::tan(vm::radians(fovY_) * 0.5f);
+        const float halfH = (float(pixelWidth_) / float(pixelHeight_)) * halfV;
         std::memset(&GPUData_, 0, sizeof GPUData_);
         store(GPUData_.position, position_);
-        store(GPUData_.horizontalViewportDelta, hd);
-        store(GPUData_.verticalViewportDelta, vd);
-        store(GPUData_.topLeftViewportCorner, tl);
+        store(GPUData_.horizontalViewportDelta, (2.0f * halfH * f.right) / float(pixelWidth_));
+        store(GPUData_.verticalViewportDelta, -((2.0f * halfV * f.up) / float(pixelHeight_)));
+        store(GPUData_.topLeftViewportCorner, position_ - (halfH * f.right) + (halfV * f.up) - f.back);
         GPUDataNeedsUpdate_ = false;
     }
 
@@ -109,22 +121,22 @@ private:
     float yaw_ = -90.0f, pitch_ = 0.0f;
 };
 
-// Shared by Object::rotate and AreaLight::rotate (object.cppm:171-195, area_light.cppm:110-134).
-// rotation[row][k] indexes a column-major glm::mat3 by [column][row]: the applied matrix is the
-// TRANSPOSE of rotZ*rotY*rotX (quirk Q4) — kept, because it is what callers of the API observe.
+// Object::rotate / AreaLight::rotate (behaviour of object.cppm:171-195, area_light.cppm:110-134): Euler angles in degrees, composed
+// as Z * Y * X.  What reaches the transform is the TRANSPOSE of that product (quirk Q4: the reference indexes a column-major
+// matrix as [row][k]) — the inverse rotation — applied from the left to the 3x3 linear part; the translation column is left
+// alone.  Kept because it is what callers of the API observe; here the transpose is taken explicitly.
 inline void apply_reference_rotate(vm::Transform34& t, const vm::vec3& degrees) {
-    vm::vec3 radians = vm::radians(degrees);
-    vm::mat3 rotX = vm::rotation(radians.x, vm::vec3(1, 0, 0));
-    vm::mat3 rotY = vm::rotation(radians.y, vm::vec3(0, 1, 0));
-    vm::mat3 rotZ = vm::rotation(radians.z, vm::vec3(0, 0, 1));
-    vm::mat3 rotation = rotZ * rotY * rotX;
-    float result[3][3];
-    for (int row = 0; row < 3; ++row)
-        for (int col = 0; col < 3; ++col)
-            result[row][col] = rotation[row][0] * t.matrix[0][col] + rotation[row][1] * t.matrix[1][col] +
-                               rotation[row][2] * t.matrix[2][col];
-    for (int row = 0; row < 3; ++row)
-        for (int col = 0; col < 3; ++col) t.matrix[row][col] = result[row][col];
+    const vm::vec3 a = vm::radians(degrees);
+    const vm::mat3 zyx = vm::rotation(a.z, vm::vec3(0, 0, 1)) * vm::rotation(a.y, vm::vec3(0, 1, 0)) * vm::rotation(a.x, vm::vec3(1, 0, 0));
+    float applied[3][3];                           // applied[i][k] = element (row k, column i) of zyx = transpose(zyx)[i][k]
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) applied[i][k] = zyx[i][k];        // zyx[i] is COLUMN i, so zyx[i][k] is row k of column i
+    float linear[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 3; ++c)
+            linear[i][c] = applied[i][0] * t.matrix[0][c] + applied[i][1] * t.matrix[1][c] + applied[i][2] * t.matrix[2][c];
+    for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 3; ++c) t.matrix[i][c] = linear[i][c];
 }
 
 class Object {
@@ -149,11 +161,11 @@ public:
     void setIndexOffset(uint32_t o) { indexOffset_ = o; }
     void setNumTriangles(uint32_t n) { numTriangles_ = n; }
 
-    void move(const vm::vec3& m) {                                  // object.cppm:158-162
-        transform_.matrix[0][3] += m.x; transform_.matrix[1][3] += m.y; transform_.matrix[2][3] += m.z;
+    void move(const vm::vec3& m) {                                  // adds to the translation column (object.cppm:158-162)
+        for (int axis = 0; axis < 3; ++axis) transform_.matrix[axis][3] += m[axis];
     }
-    void scale(float s) {                                           // object.cppm:163-169
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) transform_.matrix[r][c] *= s;
+    void scale(float s) {                                           // uniform, linear part only (object.cppm:163-169)
+        for (auto& row : transform_.matrix) for (int c = 0; c < 3; ++c) row[c] *= s;
     }
     void rotate(const vm::vec3& degrees) { apply_reference_rotate(transform_, degrees); }
 
@@ -207,11 +219,11 @@ public:
         : intensity_(intensity), color_(color), isTwoSided_(isTwoSided), isVisible_(isVisible), objPath_(objPath) {}
 
     std::string getOBJPath() const { return objPath_; }
-    void move(const vm::vec3& m) {                                  // area_light.cppm:98-102
-        transform_.matrix[0][3] += m.x; transform_.matrix[1][3] += m.y; transform_.matrix[2][3] += m.z;
+    void move(const vm::vec3& m) {                                  // adds to the translation column (area_light.cppm:98-102)
+        for (int axis = 0; axis < 3; ++axis) transform_.matrix[axis][3] += m[axis];
     }
-    void scale(vm::vec3 s) {                                        // area_light.cppm:104-108 (diagonal only, quirk Q5)
-        transform_.matrix[0][0] *= s.x; transform_.matrix[1][1] *= s.y; transform_.matrix[2][2] *= s.z;
+    void scale(vm::vec3 s) {                                        // the DIAGONAL only, whatever the rotation so far (quirk Q5, area_light.cppm:104-108)
+        for (int axis = 0; axis < 3; ++axis) transform_.matrix[axis][axis] *= s[axis];
     }
     void rotate(const vm::vec3& degrees) { apply_reference_rotate(transform_, degrees); }
 
