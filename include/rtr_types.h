@@ -135,14 +135,16 @@ typedef struct RtrBvhGrid {
 
 /* ---- 4-wide view of the same tree (layout W4.0): what the any-hit kernel walks (k_shadow_trace4) ---------------------------
  * One 64-B record = a collapsed subtree of the BVH2 (greedy: open the inner child with the largest box while a slot is free):
- * up to four child boxes on the same 16-bit scene grid and their four child codes, so a ray makes about half as many DEPENDENT
- * visits.  Records are in breadth-first order (the first ones are the top levels, which the kernel keeps in LDS); record 0 is
+ * up to four child boxes and their four child codes, so a ray makes about half as many DEPENDENT visits.  A plane is stored as
+ * a HALF FLOAT: its offset from the centre of the scene grid in grid steps (q - 32768), rounded outward to 11 significant bits
+ * (exact within 2048 steps of the centre, 2^-11 of the distance from it beyond), so that its parameter on a ray is ONE
+ * instruction, t = fma(f16 plane, ga, gbc) with v_fma_mix_f32, no conversion (ga, gbc: rtr_ray_grid_centre).  Records are in breadth-first order (the first ones are the top levels, which the kernel keeps in LDS); record 0 is
  * the root.  Built on the device after every build / refit (kernels/rtr_bvh.hip: k_wide_nodes, k_permute_wide).
- *   plane[k] : slot k: (xmin | ymin << 16) (xmax | ymax << 16) (zmin | zmax << 16)
+ *   plane[k] : slot k: (xmin | ymin << 16) (xmax | ymax << 16) (zmin | zmax << 16), IEEE binary16 each
  *   child[k] : >= 0 index of a record of this array; < 0 leaf code as in RtrBvhNode (triangles in the same leaf-ordered array);
  *              0x80000000 = empty slot (slots 0 and 1 are never empty)
  */
-#define RTR_WIDE_LAYOUT_VERSION 40
+#define RTR_WIDE_LAYOUT_VERSION 43
 #define RTR_WIDE_NODE_BYTES 64
 #define RTR_WIDE_EMPTY ((int32_t)0x80000000)
 typedef struct RtrWideNode {

@@ -43,7 +43,7 @@ static Box tribox(int t) {                  // on the 16-bit scene grid, outward
     return b;
 }
 
-enum Quant { Q_SCENE16, Q_LOCAL11, Q_LOCAL8, Q_FP6, Q_LOCAL6, Q_LOCAL7 };
+enum Quant { Q_SCENE16, Q_LOCAL11, Q_LOCAL8, Q_FP6, Q_LOCAL6, Q_LOCAL7, Q_F16CENTER, Q_F16CORNER };
 enum Order { O_NEAREST, O_SLOTOCT, O_SLOT, O_SATO, O_SATO_T, O_FAR, O_LEN };
 
 struct WChild { Box b; int kind; int idx; int count; };   // kind 0 inner (idx = wide node), 1 leaf (idx = first tri, count)
@@ -60,8 +60,29 @@ static float fp6_down(float x) {   // largest representable <= x (x in [-7.5, 7.
 }
 static float fp6_up(float x) { return -fp6_down(-x); }
 
+static float f16_down(float x) {      // largest f16-representable value <= x (|x| < 65504), x in scene-grid steps
+    if (x == 0) return 0;
+    float a = std::fabs(x); int e; std::frexp(a, &e);            // a = m * 2^e, m in [0.5, 1)
+    float step = std::ldexp(1.0f, e - 11);                      // 11 significant bits
+    if (a < 6.1e-5f) step = 5.96e-8f;
+    float d = std::floor(x / step) * step;
+    return d;
+}
+static float f16_up(float x) { return -f16_down(-x); }
+static float g_center[3];
+
 static void quantize(WNode& n, Quant q) {
     if (q == Q_SCENE16 || n.ch.empty()) return;
+    if (q == Q_F16CENTER || q == Q_F16CORNER) {                 // planes as f16 values on a scene-wide grid whose origin is the scene centre / min corner
+        for (int k = 0; k < 3; ++k) {
+            const float org = q == Q_F16CENTER ? g_center[k] : gorg[k];
+            for (auto& ch : n.ch) {
+                ch.b.mn[k] = org + f16_down((ch.b.mn[k] - org) / gscl[k]) * gscl[k];
+                ch.b.mx[k] = org + f16_up((ch.b.mx[k] - org) / gscl[k]) * gscl[k];
+            }
+        }
+        return;
+    }
     Box nb = n.ch[0].b; for (auto& c : n.ch) nb = unite(nb, c.b);
     for (int k = 0; k < 3; ++k) {
         if (q == Q_FP6) {
@@ -227,13 +248,14 @@ template <class T> static std::vector<T> load(const std::string& p) {
 int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : "/tmp/wsim";
     nodes2 = load<Node2>(dir + "/nodes.bin"); tris = load<Tri>(dir + "/tris.bin"); rays = load<Ray>(dir + "/rays.bin");
-    auto g = load<float>(dir + "/grid.bin"); for (int k = 0; k < 3; ++k) { gorg[k] = g[k]; gscl[k] = g[4 + k]; }
+    auto g = load<float>(dir + "/grid.bin"); for (int k = 0; k < 3; ++k) { gorg[k] = g[k]; gscl[k] = g[4 + k]; g_center[k] = gorg[k] + 32768.0f * gscl[k]; }
     const Config cfgs[] = {
-        {"W4 local11 slot leaves<=4          64B", 4, false, Q_LOCAL11, O_SLOT, 64, 4},
-        {"W4 local11 nearest                 64B", 4, false, Q_LOCAL11, O_NEAREST, 64, 4},
-        {"W4 local11 farthest                64B", 4, false, Q_LOCAL11, O_FAR, 64, 4},
-        {"W4 local11 longest overlap first   64B", 4, false, Q_LOCAL11, O_LEN, 64, 4},
+        {"W4 scene16 nearest (r01 kernel)    64B", 4, false, Q_SCENE16, O_NEAREST, 64, 8},
+        {"W4 f16 about the scene centre      64B", 4, false, Q_F16CENTER, O_NEAREST, 64, 8},
+        {"W4 f16 about the min corner        64B", 4, false, Q_F16CORNER, O_NEAREST, 64, 8},
+        {"W4 local11 nearest                 64B", 4, false, Q_LOCAL11, O_NEAREST, 64, 8},
     };
+
 
 
 

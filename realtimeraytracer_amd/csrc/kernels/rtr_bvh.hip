@@ -282,11 +282,36 @@ __global__ __launch_bounds__(kB) void k_quantize(uint32_t numNodes, const float4
     nodes[(size_t)i * 2] = w0; nodes[(size_t)i * 2 + 1] = w1;
 }
 
+/* f16 bits of a signed plane offset v (scene-grid steps from the grid's CENTRE, |v| <= 32768), rounded towards -inf / +inf to the
+ * 11 significant bits of a half float.  Integer arithmetic, so a host restatement agrees bit for bit. */
+__host__ __device__ inline uint32_t rtr_f16_bits_of_int(uint32_t a) {      /* a has at most 11 significant bits, a <= 65504 */
+    if (a == 0) return 0u;
+    const int e = 31 - __builtin_clz(a);                                   /* a = 1.m * 2^e, e <= 15 */
+    const uint32_t m = (e >= 10) ? (a >> (e - 10)) : (a << (10 - e));      /* 11 bits, leading one at bit 10 */
+    return ((uint32_t)(e + 15) << 10) | (m & 0x3ffu);
+}
+__host__ __device__ inline uint32_t rtr_f16_mag_down(uint32_t a) {          /* largest representable <= a */
+    if (a <= 2048u) return a;
+    const int sh = (31 - __builtin_clz(a)) - 10;
+    return (a >> sh) << sh;
+}
+__host__ __device__ inline uint32_t rtr_f16_mag_up(uint32_t a) {            /* smallest representable >= a */
+    if (a <= 2048u) return a;
+    const int sh = (31 - __builtin_clz(a)) - 10;
+    return ((a + (1u << sh) - 1u) >> sh) << sh;
+}
+__host__ __device__ inline uint32_t rtr_f16_floor_bits(int32_t v) {         /* towards -inf */
+    return v >= 0 ? rtr_f16_bits_of_int(rtr_f16_mag_down((uint32_t)v)) : (0x8000u | rtr_f16_bits_of_int(rtr_f16_mag_up((uint32_t)(-v))));
+}
+__host__ __device__ inline uint32_t rtr_f16_ceil_bits(int32_t v) {          /* towards +inf */
+    return v >= 0 ? rtr_f16_bits_of_int(rtr_f16_mag_up((uint32_t)v)) : (0x8000u | rtr_f16_bits_of_int(rtr_f16_mag_down((uint32_t)(-v))));
+}
+
 /* 4-wide view of the tree for the any-hit kernel (rtr_kernels.hip, k_shadow_trace4): entry n starts from the two children of
  * BVH2 node n and, while a slot is free, opens the inner entry with the largest box into its own two children; boxes are
  * copied from the BVH2 nodes that own them and child codes keep BVH2 node ids, so entry 0 roots a complete 4-wide tree.
- * Word layout (16 words): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16), then the four child codes; an empty
- * slot has the code 0x80000000. */
+ * Word layout (16 words = RtrWideNode): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16) as half floats about the grid centre,
+ * then the four child codes; an empty slot has the code 0x80000000. */
 __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
                                                    const RtrBvhGrid* __restrict__ grid, uint4* __restrict__ wide) {
     const uint32_t i = blockIdx.x * kB + threadIdx.x;
@@ -322,7 +347,16 @@ __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint
         for (int j = 0; j < k; ++j) {
             uint32_t wmin, wmax, wz; int32_t code;
             words(own[j], side[j], wmin, wmax, wz, code);
-            o[j * 3] = wmin; o[j * 3 + 1] = wmax; o[j * 3 + 2] = wz; o[12 + j] = (uint32_t)code;
+            /* planes leave here as HALF FLOATS: the offset from the centre of the scene grid (q - 32768), rounded outward to 11 significant
+             * bits, so the kernel's slab test needs no conversion (one v_fma_mix_f32 per plane).  Exact within 2048 steps of the centre,
+             * 2^-11 of the distance from it beyond: +0.7 % node visits, +6 % triangle tests on the bench frame (profiles/r02/wide_sim_f16.log)
+             * for 12 % fewer vector instructions per visit */
+            const int32_t xmin = (int32_t)(wmin & 0xffffu) - 32768, ymin = (int32_t)(wmin >> 16) - 32768, zmin = (int32_t)(wz & 0xffffu) - 32768;
+            const int32_t xmax = (int32_t)(wmax & 0xffffu) - 32768, ymax = (int32_t)(wmax >> 16) - 32768, zmax = (int32_t)(wz >> 16) - 32768;
+            o[j * 3] = rtr_f16_floor_bits(xmin) | (rtr_f16_floor_bits(ymin) << 16);
+            o[j * 3 + 1] = rtr_f16_ceil_bits(xmax) | (rtr_f16_ceil_bits(ymax) << 16);
+            o[j * 3 + 2] = rtr_f16_floor_bits(zmin) | (rtr_f16_ceil_bits(zmax) << 16);
+            o[12 + j] = (uint32_t)code;
         }
     }
     for (int q = 0; q < 4; ++q) wide[(size_t)i * 4 + q] = make_uint4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);

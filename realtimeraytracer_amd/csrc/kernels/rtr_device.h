@@ -184,6 +184,32 @@ __device__ __forceinline__ bool slab_oct<8>(uint32_t wmin, uint32_t wmax, uint32
     return slab_pair(wmin, wmax, wz, ga, gb, tmin, tmax, t_entry);       /* 8 = signs differ between the lanes of the wave */
 }
 
+/* Slab test of one slot of an RtrWideNode: the same three words, but the planes are HALF FLOATS — offsets from the centre of the scene
+ * grid in grid steps, rounded outward when the record was made — so t = fma(plane, ga, gbc) is one v_fma_mix_f32 per plane with no
+ * conversion (gbc: gb taken about the grid centre, rtr_ray_grid_centre).  OCT as in slab_oct. */
+template <int OCT>
+__device__ __forceinline__ bool slab_wide(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gbc, float tmin, float tmax, float& t_entry) {
+    typedef _Float16 rtr_h2 __attribute__((ext_vector_type(2)));
+    const rtr_h2 pmin = __builtin_bit_cast(rtr_h2, wmin), pmax = __builtin_bit_cast(rtr_h2, wmax), pz = __builtin_bit_cast(rtr_h2, wz);
+    const float x0 = rtr_fma((float)pmin.x, ga.x, gbc.x), x1 = rtr_fma((float)pmax.x, ga.x, gbc.x);
+    const float y0 = rtr_fma((float)pmin.y, ga.y, gbc.y), y1 = rtr_fma((float)pmax.y, ga.y, gbc.y);
+    const float z0 = rtr_fma((float)pz.x, ga.z, gbc.z), z1 = rtr_fma((float)pz.y, ga.z, gbc.z);
+    float nx, fx, ny, fy, nz, fz;
+    if (OCT < 8) {
+        nx = (OCT & 1) ? x1 : x0; fx = (OCT & 1) ? x0 : x1;
+        ny = (OCT & 2) ? y1 : y0; fy = (OCT & 2) ? y0 : y1;
+        nz = (OCT & 4) ? z1 : z0; fz = (OCT & 4) ? z0 : z1;
+    } else {
+        nx = rtr_hwmin(x0, x1); fx = rtr_hwmax(x0, x1);
+        ny = rtr_hwmin(y0, y1); fy = rtr_hwmax(y0, y1);
+        nz = rtr_hwmin(z0, z1); fz = rtr_hwmax(z0, z1);
+    }
+    const float lo = rtr_hwmax(rtr_hwmax(nx, ny), rtr_hwmax(nz, tmin));
+    const float hi = rtr_hwmin(rtr_hwmin(fx, fy), rtr_hwmin(fz, tmax));
+    t_entry = lo;
+    return lo <= hi * RTR_BOX_WIDEN;
+}
+
 /* Direction signs of a ray as trace() will see them (bit a = the grid-space slope of axis a is negative). */
 __device__ __forceinline__ uint32_t ray_octant(const DeviceScene& sc, rtr_v3 o, rtr_v3 d) {
     const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));

@@ -592,10 +592,10 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
             const int32_t top = lds[sp * kBlock];              /* speculative: hides the pop's LDS latency under the node loads */
             const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
             float t0, t1, t2, t3;
-            const bool h0 = slab_oct<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);            /* slot 0 is never empty */
-            const bool h1 = slab_oct<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmax, t1);
-            const bool h2 = slab_oct<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmax, t2) && c2 != kDone;
-            const bool h3 = slab_oct<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmax, t3) && c3 != kDone;
+            const bool h0 = slab_wide<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);           /* slot 0 is never empty */
+            const bool h1 = slab_wide<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmax, t1);
+            const bool h2 = slab_wide<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmax, t2) && c2 != kDone;
+            const bool h3 = slab_wide<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmax, t3) && c3 != kDone;
             /* descend into the nearest child that is hit; the others go on the stack in slot order.  (Taking the first hit slot
              * instead of the nearest saves eight instructions and costs 2 % more time; ordering the others too —
              * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                         } else {
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
-                            rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
+                            rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);      /* gb about the grid centre: the records' planes are offsets from it */
                             cur = 0; sp = 0; res = 0u;
                         }
                     }
