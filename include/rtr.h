@@ -177,7 +177,7 @@ typedef struct rtr_frame_stats {
     uint64_t shadowInnerIterations, shadowInnerActiveLanes;
     uint64_t shadowTriIterations, shadowTriActiveLanes;
     uint64_t shadowRefills;
-    uint64_t shadowTailRays;   /* rays that outgrew the 16-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
+    uint64_t shadowTailRays;   /* rays that outgrew the 13-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
 } rtr_frame_stats;
 
 /* ---- context -------------------------------------------------------------------------- */

@@ -563,7 +563,7 @@ struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLan
 
 template <int STACK, int OCT, bool STATS>
 __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
-                                             int32_t* lds, int32_t& cur, int& sp, uint32_t& res,
+                                             int32_t* lds, int32_t& cur, int32_t*& sp, uint32_t& res,
                                              const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
                                              WaveStats& ws, LocalStats& st) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -589,7 +589,7 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
                 q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, 0);
                 q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, 0);
             }
-            const int32_t top = lds[sp * kBlock];              /* speculative: hides the pop's LDS latency under the node loads */
+            const int32_t top = *sp;                           /* speculative: hides the pop's LDS latency under the node loads */
             const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
             float t0, t1, t2, t3;
             const bool h0 = slab_wide<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);           /* slot 0 is never empty */
@@ -601,18 +601,21 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
              * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
              * 2.15 / 2.22 ms against 2.05.) */
             int32_t next = kDone;
-            bool ovf = false;
             float tn = 3.0e38f;
             if (h0) { tn = t0; next = c0; }
             if (h1 && t1 < tn) { tn = t1; next = c1; }
             if (h2 && t2 < tn) { tn = t2; next = c2; }
             if (h3 && t3 < tn) { tn = t3; next = c3; }
-            if (h0 && c0 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c0; } else ovf = true; }
-            if (h1 && c1 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c1; } else ovf = true; }
-            if (h2 && c2 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c2; } else ovf = true; }
-            if (h3 && c3 != next) { if (sp < STACK) { ++sp; lds[sp * kBlock] = c3; } else ovf = true; }
-            if (ovf) { res = 2u; next = kDone; }                 /* needs more than the LDS stack: the tail kernel redoes this ray */
-            if (next == kDone && !ovf) { next = top; --sp; }    /* nothing hit: pop (slot 0 holds kDone) */
+            /* the stack pointer is the LDS address of the top entry, so a push is an add and a store.  A visit pushes at most three
+             * entries and the kernel reserves three guard entries above the STACK it may use: the bound is checked once, after the
+             * pushes (a ray that went past it is abandoned to the tail kernel; what it wrote into the guard entries is its own) */
+            const bool pop = next == kDone;                      /* nothing hit */
+            if (h0 && c0 != next) { sp += kBlock; *sp = c0; }
+            if (h1 && c1 != next) { sp += kBlock; *sp = c1; }
+            if (h2 && c2 != next) { sp += kBlock; *sp = c2; }
+            if (h3 && c3 != next) { sp += kBlock; *sp = c3; }
+            if (sp > lds + STACK * kBlock) { res = 2u; next = kDone; }     /* needs more than the LDS stack: the tail kernel redoes this ray */
+            else if (pop) { next = top; sp -= kBlock; }                     /* slot 0 holds kDone */
             cur = next;
         }
     }
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                               uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
                                                               const uint2* __restrict__ lists, uint32_t listStride, Counters* stats,
                                                               unsigned long long* __restrict__ clk) {
-    __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
+    __shared__ int32_t s_stack[(STACK + 1 + 3) * kBlock];    /* slot 0, below the stack, holds kDone for good; three guard entries above it (inner_nodes4) */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     }
     uint32_t regionTry = 0;                  /* wave-uniform: regions / lists found empty so far (cursors only grow) */
     int32_t cur = kDone;
-    int sp = 0;                              /* entries held; the top is lds[sp * kBlock] */
+    int32_t* sp = lds;                       /* LDS address of the top entry (lds = slot 0 = empty) */
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
     float tmax = 0.f;
     uint32_t slot = 0, rayIndex = 0, res = kResNone;
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         } else {
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
                             rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);      /* gb about the grid centre: the records' planes are offsets from it */
-                            cur = 0; sp = 0; res = 0u;
+                            cur = 0; sp = lds; res = 0u;
                         }
                     }
                     batchPos += (nIdle < avail) ? nIdle : avail;
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
             if (atLeaf) {
                 if (hit) { res = 1u; cur = kDone; }
-                else { cur = lds[sp * kBlock]; --sp; }
+                else { cur = *sp; sp -= kBlock; }
             }
         } else if (cur < 0 && cur != kDone) {
             const uint32_t code = (uint32_t)~cur;
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             bool hit = false;
             for (uint32_t i = 0; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
             if (hit) { res = 1u; cur = kDone; }
-            else { cur = lds[sp * kBlock]; --sp; }                   /* slot 0 holds kDone: an empty stack ends the ray (visible) */
+            else { cur = *sp; sp -= kBlock; }                        /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }
     }
     if (stamp || STATS) {
@@ -963,11 +966,11 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const uint32_t top = kTop < sc.numNodes4 ? kTop : sc.numNodes4;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<16, true, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<16, false, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<13, true, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<13, false, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<16, true, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<16, false, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<13, true, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<13, false, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
     } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
     if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
