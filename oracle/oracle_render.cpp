@@ -409,6 +409,7 @@ struct PixelOut { rtr_v3 analytic, shadowed, unshadowed, avgNormal, avgPosition;
 PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneInfo& info,
                      const rtr_render_params& prm, uint32_t px, uint32_t py, bool wantAnalytic, bool wantUnshadowed, Counters& c) {
     const rtr_scene_desc& D = sc.s->desc;
+    (void)wantUnshadowed;          /* every sum is evaluated for every sample, as the shader does; the flag only says which are stored */
     PixelOut o;
     o.analytic = o.shadowed = o.unshadowed = o.avgNormal = o.avgPosition = rtr_mk(0, 0, 0);
     const rtr_v3 camPos = rtr_ld3(cam.position);
@@ -498,9 +499,9 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
                     float lightDistance = rtr_length(lightVec);                           /* :222 */
                     Hit sh = trace(sc, shadowOrigin, sampledLightDir, 0.001f, lightDistance - 0.5f, true, c); /* :226-241 */
                     float currShadow = sh.hit ? 0.0f : 1.0f;                              /* :244 */
-                    /* an occluded sample adds contrib * 0 to the shadowed sum; when the unshadowed image is not an output its
-                     * BRDF is not evaluated (the product does the same; identical results whenever contrib is finite) */
-                    if (sh.hit && !wantUnshadowed) continue;
+                    /* every sample's BRDF is evaluated and multiplied by currShadow, as the shader does (the product skips the
+                     * BRDF of an occluded sample when only the shadowed image is kept: same bits whenever contrib is finite,
+                     * divergence D6 otherwise) */
                     rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir)); /* :247 */
                     float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f); /* :250 */
                     float Dg = GGX_Distribution(hitNormal, halfVector, roughness);        /* :252 */
@@ -509,17 +510,18 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
                     rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);                      /* :254 */
                     float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 0.1f);             /* :256 */
                     float NdotL = rtr_max(rtr_dot(hitNormal, sampledLightDir), 0.1f);     /* :257 */
-                    float den = 4.0f * NdotV * NdotL;                                     /* :259 */
-                    float DG = Dg * G;
-                    rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+                    float den = 4.0f * NdotV * NdotL;                                     /* :259: (D * F * G) / (4.0 * NdotV * NdotL), left to right */
+                    rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
                     rtr_v3 currDiffuse = rtr_mk((om * color.x) / PI_F, (om * color.y) / PI_F, (om * color.z) / PI_F); /* :260 */
                     float attenuation = 1.0f / (lightDistance * lightDistance);           /* :262-264 */
                     rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);                     /* :266 */
-                    float lscale = L.intensity * NdotL * attenuation * 10.0f;             /* :267 */
-                    rtr_v3 Lr = rtr_scale(lcol, lscale);
-                    rtr_v3 contrib = rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf);
-                    shadowedSample = rtr_madd(shadowedSample, contrib, currShadow);       /* :269 */
-                    unshadowedSample = rtr_add(unshadowedSample, contrib);                /* :270 */
+                    /* :267 currLight.color * currLight.intensity * NdotL * attenuation * 10.0, left to right */
+                    rtr_v3 Lr = rtr_mk((((lcol.x * L.intensity) * NdotL) * attenuation) * 10.0f, (((lcol.y * L.intensity) * NdotL) * attenuation) * 10.0f,
+                                       (((lcol.z * L.intensity) * NdotL) * attenuation) * 10.0f);
+                    /* :269 currShadow * BRDF * L / pdf and :270 BRDF * L / pdf, left to right */
+                    shadowedSample = rtr_add(shadowedSample, rtr_mk((((currShadow * BRDF.x) * Lr.x) / pdf), (((currShadow * BRDF.y) * Lr.y) / pdf),
+                                                                    (((currShadow * BRDF.z) * Lr.z) / pdf)));
+                    unshadowedSample = rtr_add(unshadowedSample, rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf));
                 }
                 float ns = (float)prm.numShadowRays;                                      /* :272-273 */
                 shadowedSample = rtr_mk(shadowedSample.x / ns, shadowedSample.y / ns, shadowedSample.z / ns);
@@ -531,11 +533,11 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
                     rtr_v3 fres = rtr_mk(rtr_fma(1.0f - mSpecular.x, t2[1], mSpecular.x * t2[0]),
                                          rtr_fma(1.0f - mSpecular.y, t2[1], mSpecular.y * t2[0]),
                                          rtr_fma(1.0f - mSpecular.z, t2[1], mSpecular.z * t2[0]));
-                    float li5 = L.intensity * 5.0f;
+                    /* :283 currLight.color * currLight.intensity * (specular + mDiffuse * diffuse) * 5.0, left to right */
                     o.analytic = rtr_add(o.analytic, rtr_mk(
-                        lcol.x * li5 * rtr_fma(mDiffuse.x, diffuse, spec * fres.x),
-                        lcol.y * li5 * rtr_fma(mDiffuse.y, diffuse, spec * fres.y),
-                        lcol.z * li5 * rtr_fma(mDiffuse.z, diffuse, spec * fres.z)));
+                        ((lcol.x * L.intensity) * rtr_fma(mDiffuse.x, diffuse, spec * fres.x)) * 5.0f,
+                        ((lcol.y * L.intensity) * rtr_fma(mDiffuse.y, diffuse, spec * fres.y)) * 5.0f,
+                        ((lcol.z * L.intensity) * rtr_fma(mDiffuse.z, diffuse, spec * fres.z)) * 5.0f));
                 }
                 o.shadowed = rtr_add(o.shadowed, shadowedSample);                         /* :284-285 */
                 o.unshadowed = rtr_add(o.unshadowed, unshadowedSample);
@@ -548,7 +550,6 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
         if (rtr_dot(hitNormal, directLightDir) <= 0.0f) continue;                         /* :293 */
         Hit sh = trace(sc, shadowOrigin, directLightDir, 0.001f, 10000.0f, true, c);      /* :303-313 */
         float currShadow = sh.hit ? 0.0f : 1.0f;                                          /* :316 */
-        if (sh.hit && !wantUnshadowed && !wantAnalytic) continue;                         /* contributes contrib * 0 to the only sum kept */
         rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, directLightDir));              /* :318 */
         float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);             /* :321 */
         float Dg = GGX_Distribution(hitNormal, halfVector, roughness);                    /* :323 */
@@ -557,17 +558,17 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
         rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
         float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 5.0f);                         /* :327 (quirk Q6) */
         float NdotL = rtr_max(rtr_dot(hitNormal, directLightDir), 0.0001f);               /* :328 */
-        float den = 4.0f * NdotV * NdotL;
-        float DG = Dg * G;
-        rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+        float den = 4.0f * NdotV * NdotL;                                                 /* :330 (D * F * G) / (4.0 * NdotV * NdotL), left to right */
+        rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
         rtr_v3 currDiffuse = rtr_mk((om * color.x) / PI_F, (om * color.y) / PI_F, (om * color.z) / PI_F);
         rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
-        float lscale = directLightIntensity * NdotL * 20.0f;                              /* :334 */
-        rtr_v3 Lr = rtr_scale(directLightColor, lscale);
-        rtr_v3 contrib = rtr_mul(BRDF, Lr);
-        o.shadowed = rtr_madd(o.shadowed, contrib, currShadow);                           /* :336-338 */
-        o.unshadowed = rtr_add(o.unshadowed, contrib);
-        o.analytic = rtr_add(o.analytic, contrib);
+        /* :334 directLightColor * directLightIntensity * NdotL * 20.0, left to right */
+        rtr_v3 Lr = rtr_mk(((directLightColor.x * directLightIntensity) * NdotL) * 20.0f, ((directLightColor.y * directLightIntensity) * NdotL) * 20.0f,
+                           ((directLightColor.z * directLightIntensity) * NdotL) * 20.0f);
+        /* :336-338 currShadow * BRDF * L, BRDF * L */
+        o.shadowed = rtr_add(o.shadowed, rtr_mk((currShadow * BRDF.x) * Lr.x, (currShadow * BRDF.y) * Lr.y, (currShadow * BRDF.z) * Lr.z));
+        o.unshadowed = rtr_add(o.unshadowed, rtr_mul(BRDF, Lr));
+        o.analytic = rtr_add(o.analytic, rtr_mul(BRDF, Lr));
     }
     float n = (float)prm.spp;                                                             /* :341-343 */
     o.shadowed = rtr_mk(o.shadowed.x / n, o.shadowed.y / n, o.shadowed.z / n);

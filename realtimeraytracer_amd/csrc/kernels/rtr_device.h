@@ -536,8 +536,9 @@ template <class Policy, bool STATS>
 __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
                                             const Surface& sf, uint32_t want, Accum& o, Policy& pol, LocalStats& st) {
     /* want: bit 0 = the analytic (LTC) image is an output, bit 1 = the unshadowed image is.  When the unshadowed image is not
-     * asked for, an occluded sample contributes contrib * 0 to the only sum that is kept, so its BRDF is not evaluated
-     * (same rule in the oracle; identical results whenever contrib is finite). */
+     * asked for, an occluded sample contributes contrib * 0 to the only sum that is kept, so its BRDF is not evaluated here.  The
+     * reference (and the oracle) evaluate it and multiply by 0: identical whenever contrib is finite; an occluded sample whose
+     * contrib overflows poisons the reference's pixel (0 * inf = NaN) and not this one — divergence D6, DESIGN.md §4. */
     const bool wantAnalytic = (want & 1u) != 0u, wantUnshadowed = (want & 2u) != 0u;
     const rtr_v3 hitPoint = sf.hitPoint, hitNormal = sf.hitNormal, viewDir = sf.viewDir, color = sf.color;
     const rtr_v3 mDiffuse = sf.mDiffuse, mSpecular = sf.mSpecular;
@@ -585,14 +586,15 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
                     const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
                     const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 0.1f);
                     const float NdotL = rtr_max(rtr_dot(hitNormal, sampledLightDir), 0.1f);
+                    /* the products in the order GLSL evaluates them, left to right (raygen.rgen:259-267): (D * F * G) / (4 NdotV NdotL),
+                     * color * intensity * NdotL * attenuation * 10, BRDF * L / pdf */
                     const float den = 4.0f * NdotV * NdotL;
-                    const float DG = Dg * G;
-                    const rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+                    const rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
                     const rtr_v3 currDiffuse = rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
                     const float attenuation = 1.0f / (lightDistance * lightDistance);
                     const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
-                    const float lscale = lintensity * NdotL * attenuation * 10.0f;
-                    const rtr_v3 Lr = rtr_scale(lcol, lscale);
+                    const rtr_v3 Lr = rtr_mk((((lcol.x * lintensity) * NdotL) * attenuation) * 10.0f, (((lcol.y * lintensity) * NdotL) * attenuation) * 10.0f,
+                                             (((lcol.z * lintensity) * NdotL) * attenuation) * 10.0f);
                     const rtr_v3 contrib = rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf);
                     shadowedSample = rtr_madd(shadowedSample, contrib, currShadow);
                     unshadowedSample = rtr_add(unshadowedSample, contrib);
@@ -608,10 +610,10 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
                     const rtr_v3 fres = rtr_mk(rtr_fma(1.0f - mSpecular.x, t2.y, mSpecular.x * t2.x),
                                                rtr_fma(1.0f - mSpecular.y, t2.y, mSpecular.y * t2.x),
                                                rtr_fma(1.0f - mSpecular.z, t2.y, mSpecular.z * t2.x));
-                    const float li5 = lintensity * 5.0f;
-                    o.analytic = rtr_add(o.analytic, rtr_mk(lcol.x * li5 * rtr_fma(mDiffuse.x, diffuse, spec * fres.x),
-                                                            lcol.y * li5 * rtr_fma(mDiffuse.y, diffuse, spec * fres.y),
-                                                            lcol.z * li5 * rtr_fma(mDiffuse.z, diffuse, spec * fres.z)));
+                    /* color * intensity * (specular + mDiffuse * diffuse) * 5, left to right (raygen.rgen:283) */
+                    o.analytic = rtr_add(o.analytic, rtr_mk(((lcol.x * lintensity) * rtr_fma(mDiffuse.x, diffuse, spec * fres.x)) * 5.0f,
+                                                            ((lcol.y * lintensity) * rtr_fma(mDiffuse.y, diffuse, spec * fres.y)) * 5.0f,
+                                                            ((lcol.z * lintensity) * rtr_fma(mDiffuse.z, diffuse, spec * fres.z)) * 5.0f));
                 }
                 o.shadowed = rtr_add(o.shadowed, shadowedSample);
                 o.unshadowed = rtr_add(o.unshadowed, unshadowedSample);
@@ -635,12 +637,12 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
         const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 5.0f);
         const float NdotL = rtr_max(rtr_dot(hitNormal, directLightDir), 0.0001f);
         const float den = 4.0f * NdotV * NdotL;
-        const float DG = Dg * G;
-        const rtr_v3 currSpecular = rtr_mk((DG * F.x) / den, (DG * F.y) / den, (DG * F.z) / den);
+        const rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
         const rtr_v3 currDiffuse = rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
         const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
-        const float lscale = directLightIntensity * NdotL * 20.0f;
-        const rtr_v3 Lr = rtr_scale(directLightColor, lscale);
+        /* directLightColor * directLightIntensity * NdotL * 20, left to right (raygen.rgen:334) */
+        const rtr_v3 Lr = rtr_mk(((directLightColor.x * directLightIntensity) * NdotL) * 20.0f, ((directLightColor.y * directLightIntensity) * NdotL) * 20.0f,
+                                 ((directLightColor.z * directLightIntensity) * NdotL) * 20.0f);
         const rtr_v3 contrib = rtr_mul(BRDF, Lr);
         o.shadowed = rtr_madd(o.shadowed, contrib, currShadow);
         o.unshadowed = rtr_add(o.unshadowed, contrib);

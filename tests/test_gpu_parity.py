@@ -576,6 +576,43 @@ print("two-wide ok")
     assert r.returncode == 0 and "two-wide ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_d6_occluded_sample_with_overflowing_contribution(gpu_ctx, oracle, scene_cache):
+    """Divergence D6.  The reference evaluates the BRDF of every light sample and multiplies by currShadow
+    (raygen.rgen:244-270); the oracle does the same.  The product, when only the shadowed image is kept, does not evaluate the BRDF
+    of an occluded sample.  Same bits whenever the contribution is finite (every other parity test); with a light whose
+    colour x intensity overflows fp32 an OCCLUDED sample gives 0 * inf = NaN in the reference and poisons its pixel (tone-mapped
+    to 0), while the product's pixel keeps its other, finite terms.  This test pins exactly that: every pixel that differs is
+    black in the oracle and lit by the directional light in the product, such pixels exist, and with the unshadowed image
+    requested too (the product then evaluates every sample) there is no difference at all."""
+    import ctypes as C
+    W, H = 256, 256
+    s = scenes.cornell_box(W, H)
+    lights = s.host.lightInfos()
+    hot = A.RtrAreaLightInfo.from_buffer_copy(bytes(lights[0]))
+    hot.color[0], hot.color[1], hot.color[2], hot.intensity = 3.0, 3.0, 3.0, 3.0e38        # colour * intensity = inf
+    arr = (A.RtrAreaLightInfo * 1)(hot)
+    d = A.rtr_scene_desc.from_buffer_copy(bytes(s.desc))
+    d.lights = C.cast(arr, C.POINTER(A.RtrAreaLightInfo))
+    scene = api.Scene(gpu_ctx, d)
+    bvh = scene.export_bvh()
+    p = api.make_params(W, H, spp=1)
+    frame = api.Frame(gpu_ctx, W, H)
+    api.render(scene, s.camera, s.scene_info(0), p, frame)
+    got = frame.download()
+    ref = oracle.render(d, s.camera, s.scene_info(0), p, bvh=bvh, threads=8).images[A.IMAGE_SHADOWED]
+    diff = got != ref
+    assert 0 < diff.sum() < W * H // 4, int(diff.sum())
+    assert np.all(ref[diff] == 0xff000000), "a differing pixel must be one the reference poisons (NaN -> 0)"
+    assert np.all(got[diff] != 0xff000000), "... and one the product still lights"
+    both = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_UNSHADOWED)
+    p2 = api.make_params(W, H, spp=1, images=both)
+    f2 = api.Frame(gpu_ctx, W, H, both)
+    api.render(scene, s.camera, s.scene_info(0), p2, f2)
+    ref2 = oracle.render(d, s.camera, s.scene_info(0), p2, bvh=bvh, images=both, threads=8)
+    _assert_same(f2.download(A.IMAGE_SHADOWED), ref2.images[A.IMAGE_SHADOWED], "D6 scene, shadowed image with every sample evaluated")
+    _assert_same(f2.download(A.IMAGE_UNSHADOWED), ref2.images[A.IMAGE_UNSHADOWED], "D6 scene, unshadowed image")
+
+
 def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
     """include/rtr_mgpu.h: the sharded frame behind the C ABI, ONE process driving every GPU of the box (1 on the test box) through a
     real RCCL communicator.  With one rank RTR_MGPU_SELF_EXCHANGE=1 makes the shard travel through grouped ncclSend / ncclRecv
