@@ -67,6 +67,10 @@ def main():
     ap.add_argument("--isolated-frames", type=int, default=10,
                     help="after the timed region, render this many frames ONE AT A TIME to report per-kernel durations free of "
                          "cross-frame overlap (0 = skip; profiles/run_rocprof.sh skips it so rocprof's averages cover the timed launches only)")
+    ap.add_argument("--present-frames", type=int, default=20,
+                    help="after the timed region (N=1), time this many PRESENTED frames of the same scene as the reference's frame loop makes them "
+                         "(application.cppm:391-457): ray-gen of all five images at 4 spp with the shipped LTC tables, four a-trous rounds on the "
+                         "sampled pair, combine -> FINAL; reported as `presented_frame` (0 = skip)")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame against the oracle on a row sample")
     ap.add_argument("--obj", default=None, metavar="PATH",
                     help="render a real asset instead of the procedural stand-in (SURVEY 8d: 'real bunny.obj / sponza.obj accepted if present'): "
@@ -335,6 +339,34 @@ def main():
                 clocks_iso.append(st.shadowTraceClockMHz)
         iso_ms_per_frame = (time.perf_counter() - t1) * 1e3 / args.isolated_frames
 
+    # The frame the reference presents, end to end, on the same scene (one at a time: rtr_denoise_combine is synchronous)
+    presented = None
+    if rank == 0 and not dist_on and not emu and not args.obj and args.present_frames > 0:
+        psetup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H, ltc=scenes.shipped_ltc())
+        pscene = api.Scene(ctx, psetup.desc)
+        pframe = api.Frame(ctx, W, H, 0xff)
+        pp = api.make_params(W, H, spp=4, shadow_rays=args.shadow_rays, images=A.IMAGES_RAYGEN5, pipeline=args.pipeline)
+        acc = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0}
+        for j in range(2 + args.present_frames):
+            if j == 2:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            api.render(pscene, psetup.camera, psetup.scene_info(j), pp if j else api.make_params(W, H, spp=4, shadow_rays=args.shadow_rays, images=A.IMAGES_RAYGEN5,
+                                                                                              pipeline=args.pipeline, collect_stats=1), pframe)
+            if j == 0:
+                prays = int(pframe.stats().numRays)
+            if j >= 2:
+                st = pframe.stats()
+                acc["primary"] += st.primaryMs; acc["shadow_gen"] += st.shadowGenMs; acc["shadow_trace"] += st.shadowTraceMs; acc["resolve"] += st.resolveMs
+            pframe.denoise_combine(4)
+        pms = (time.perf_counter() - t1) * 1e3 / args.present_frames
+        ray_ms = sum(acc.values()) / args.present_frames
+        presented = {"ms_per_frame": round(pms, 4), "frames": args.present_frames, "spp": 4, "images": 5, "denoise_iterations": 4, "combine": True,
+                     "ltc_tables": "shipped (realtimeraytracer_amd/data/ltc_tables.bin)", "ray_gen_kernels_ms": round(ray_ms, 4),
+                     "denoise_combine_and_host_ms": round(pms - ray_ms, 4), "rays_per_frame": prays,
+                     "scope": "one frame at a time, wall clock around rtr_render + rtr_denoise_combine; FINAL left in HBM"}
+        pframe.close(); pscene.close()
+
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     mrays = rays_per_frame * args.steps / elapsed / 1e6
 
@@ -368,7 +400,7 @@ def main():
                 # the ceiling that binds: one SIMD issues one vector instruction at a time; SQ_ACTIVE_INST_VALU counts, in units of 4
                 # cycles, the time SIMDs spent issuing them
                 "bound": "valu_issue",
-                "kernel": "k_shadow_trace4<16, true, false> (+ k_shadow_tail): any-hit traversal of the shadow-ray queue, revision " + rev,
+                "kernel": "k_shadow_trace4<13, true, false> (+ k_shadow_tail): any-hit traversal of the shadow-ray queue, revision " + rev,
                 "achieved": round(busy, 1) if busy else None, "peak": round(launch_cycles, 1) if launch_cycles else None,
                 "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch)",
                 "frac": round(busy / launch_cycles, 4) if (busy and launch_cycles) else None,
@@ -428,6 +460,7 @@ def main():
                                     "frames": args.isolated_frames, "scope": "rank 0's shard, no gather"} if iso_ms_per_frame else None,
             "algorithmic_gbps_all_kernels": round(counts[3].item() * K / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": roofline,
+            "presented_frame": presented,
         }
 
     # ---- reported CPU baseline (rank 0, N=1 only): the oracle on a bounded sample --------------------------

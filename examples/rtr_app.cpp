@@ -1,6 +1,8 @@
 // rtr_app — headless counterpart of the reference's main() (reference src/main.cpp:7-16): builds an
 // app::Application and runs it; any std::exception -> message on stderr + EXIT_FAILURE.
-//   rtr_app <scene.obj> <mtl_dir/> <out.ppm> [width height spp frames]
+//   rtr_app <scene.obj> <mtl_dir/> <out.ppm> [width height spp frames] [present] [keys=W,WD,,T ...]
+// `present`: the frame the reference presents (five ray-gen images, four a-trous rounds, combine) with the shipped LTC tables;
+// `keys=`: scripted input, one comma-separated entry per frame (Window::processInput of the reference).
 // The camera / light below reproduce realtimeraytracer_amd/scenes.py:cornell_box so the tests can compare outputs.
 #include <cstdlib>
 #include <iostream>
@@ -9,7 +11,7 @@
 
 int main(int argc, char** argv) {
     try {
-        if (argc < 4) { std::cerr << "usage: rtr_app scene.obj mtl_dir/ out.ppm [width height spp frames]\n"; return EXIT_FAILURE; }
+        if (argc < 4) { std::cerr << "usage: rtr_app scene.obj mtl_dir/ out.ppm [width height spp frames] [present] [keys=W,WD,,T]\n"; return EXIT_FAILURE; }
         const uint32_t w = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 256, h = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 256;
         app::Application app("MI355X ray tracer", w, h, true);
         app::Application::Config cfg;
@@ -21,6 +23,26 @@ int main(int argc, char** argv) {
         cfg.spp = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 1;
         cfg.frames = argc > 7 ? (uint32_t)std::atoi(argv[7]) : 1;
         cfg.outPPM = argv[3];
+        for (int i = 8; i < argc; ++i) {
+            const std::string opt = argv[i];
+            if (opt == "present") {
+                cfg.present = true;
+                std::string exe = argv[0];                                   // the tables ship next to the executable: <dir>/data/ltc_tables.bin
+                const size_t slash = exe.find_last_of('/');
+                cfg.dataDir = slash == std::string::npos ? "." : exe.substr(0, slash);
+            } else if (opt.rfind("keys=", 0) == 0) {
+                std::string rest = opt.substr(5);
+                size_t at = 0;
+                for (;;) {
+                    const size_t comma = rest.find(',', at);
+                    app::Application::Config::Input in;
+                    in.keys = rest.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+                    cfg.inputs.push_back(in);
+                    if (comma == std::string::npos) break;
+                    at = comma + 1;
+                }
+            } else { std::cerr << "unknown option " << opt << "\n"; return EXIT_FAILURE; }
+        }
         rtr_frame_stats st{};
         app.run(cfg, &st);
         std::cerr << "rendered " << w << "x" << h << " in " << st.totalMs << " ms (GPU kernels)\n";

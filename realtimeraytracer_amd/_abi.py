@@ -195,6 +195,7 @@ RTRH_SYMBOLS = {
     "rtrh_camera_set_position": (C.c_int, [VP, P(f32)]),
     "rtrh_camera_rotate_y": (C.c_int, [VP, f32]),
     "rtrh_camera_mouse": (C.c_int, [VP, f32, f32]),
+    "rtrh_camera_apply_input": (C.c_int, [VP, C.c_char_p, f32, f32, f32, f32, P(C.c_int)]),
     "rtrh_camera_state": (C.c_int, [VP, P(f32)]),
 }
 

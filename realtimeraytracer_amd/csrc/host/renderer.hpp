@@ -56,6 +56,8 @@ public:
         return px;
     }
     rtr_frame_stats stats() const { rtr_frame_stats s; check(rtr_frame_get_stats(h_, &s), "rtr_frame_get_stats"); return s; }
+    // the passes after the ray-gen dispatch in the reference's frame loop (application.cppm:391-445): a-trous rounds, then combine
+    void denoise_combine(int iterations) { check(rtr_denoise_combine(h_, iterations), "rtr_denoise_combine"); }
     uint32_t width() const { return width_; }
     uint32_t rows() const { return rows_; }
 private:

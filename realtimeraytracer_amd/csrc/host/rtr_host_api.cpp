@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "input.hpp"
 #include "scene_builder.hpp"
 
 namespace {
@@ -191,6 +192,14 @@ rtrh_camera* rtrh_camera_new(float fovY, const float* pos, const float* lookAt, 
     return c;
 }
 void rtrh_camera_free(rtrh_camera* c) { delete c; }
+// one frame of the headless input path (app::applyInput); state[0] = spinning, state[1] = T was down (in / out)
+int rtrh_camera_apply_input(rtrh_camera* c, const char* keys, float mouseDx, float mouseDy, float camSpeed, float mouseSensitivity, int* state) {
+    return guarded([&] {
+        bool spinning = state[0] != 0, tWasDown = state[1] != 0;
+        app::applyInput(*c->cam, keys ? keys : "", mouseDx, mouseDy, camSpeed, mouseSensitivity, spinning, tWasDown);
+        state[0] = spinning ? 1 : 0; state[1] = tWasDown ? 1 : 0;
+    });
+}
 int rtrh_camera_get(rtrh_camera* c, RtrCameraData* out) { return guarded([&] { *out = c->cam->getGPUData(); }); }
 int rtrh_camera_set_position(rtrh_camera* c, const float* p) { return guarded([&] { c->cam->setPosition({p[0], p[1], p[2]}); }); }
 int rtrh_camera_rotate_y(rtrh_camera* c, float a) { return guarded([&] { c->cam->rotateY(a); }); }

@@ -46,6 +46,14 @@ class Camera:
     def processMouseMovement(self, dx, dy):
         _chk(self.lib.rtrh_camera_mouse(self.h, float(dx), float(dy)), "processMouseMovement")
 
+    def applyInput(self, keys="", mouse=(0.0, 0.0), cam_speed=10.5, mouse_sensitivity=0.5):
+        """one frame of the headless input path (csrc/host/input.hpp = Window::processInput + mouse callback of the reference)"""
+        if not hasattr(self, "_input_state"):
+            self._input_state = (C.c_int * 2)(0, 0)
+        _chk(self.lib.rtrh_camera_apply_input(self.h, keys.encode(), float(mouse[0]), float(mouse[1]), float(cam_speed), float(mouse_sensitivity),
+                                              self._input_state), "applyInput")
+        return bool(self._input_state[0])
+
     def state(self):
         out = (A.f32 * 8)()
         _chk(self.lib.rtrh_camera_state(self.h, out), "state")

@@ -361,6 +361,16 @@ def synthetic_ltc():
     return l1.astype(np.float32), l2.astype(np.float32)
 
 
+def shipped_ltc():
+    """The product's own LTC tables (realtimeraytracer_amd/data/ltc_tables.bin, made by csrc/tools/ltc_fit.cpp — this project's
+    fit of the published procedure; what texSamplers[0], [1] hold in the reference, create_scene.cppm:162-214)."""
+    path = os.path.join(os.environ.get("RTR_DATA_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")), "ltc_tables.bin")
+    a = np.fromfile(path, np.float32)
+    if a.size != 2 * 64 * 64 * 4:
+        raise RuntimeError(f"{path}: expected 2 x 64 x 64 x 4 float32, found {a.size} values")
+    return a[:16384].reshape(64, 64, 4).copy(), a[16384:].reshape(64, 64, 4).copy()
+
+
 def cornell_box(width=256, height=256, directory=None, ltc=None):
     """Configs 1/2: camera (278,273,-800) -> (278,273,0), fovY 40; one one-sided 'square'
     area light scaled to the OBJ light quad, 1 unit below it, facing -Y; constant sky."""

@@ -34,6 +34,34 @@ def test_camera_controls():
     assert tuple(cam.getGPUData().position[:]) == (1.0, 2.0, 3.0)
 
 
+def test_headless_input_known_answers():
+    """csrc/host/input.hpp = Window::processInput + the mouse callback of the reference (window.cppm:68-133) on scripted input:
+    W / S / A / D step by forward / right x CAM_SPEED (10.5, application.cppm:497), T toggles the 0.1-degree-per-frame spin on its
+    press edge, cursor travel is scaled by MOUSE_SENSITIVITY (0.5) before the camera's own 0.1 degrees per unit."""
+    cam = host.Camera(60.0, (0, 0, 5), (0, 0, 0), (0, 1, 0), 800, 600)
+    assert cam.applyInput("W") is False
+    np.testing.assert_allclose(cam.getGPUData().position[:], (0, 0, 5 - 10.5), atol=1e-5)
+    cam.applyInput("D")
+    np.testing.assert_allclose(cam.getGPUData().position[:], (10.5, 0, -5.5), atol=1e-5)
+    cam.applyInput("SA")                                           # both held in one frame
+    np.testing.assert_allclose(cam.getGPUData().position[:], (0, 0, 5), atol=1e-5)
+    cam.applyInput("ws")                                           # opposite keys cancel; the position is still rewritten
+    np.testing.assert_allclose(cam.getGPUData().position[:], (0, 0, 5), atol=1e-5)
+    cam.applyInput("", mouse=(40.0, -20.0))                        # 40 * 0.5 * 0.1 = 2 degrees of yaw, -1 of pitch
+    st = cam.state()
+    assert abs(st["yaw"] - (-88.0)) < 1e-4 and abs(st["pitch"] - (-1.0)) < 1e-4
+    assert cam.applyInput("T") is True                             # press edge: spin on, and this frame already turns
+    assert abs(cam.state()["yaw"] - (-87.9)) < 1e-4
+    assert cam.applyInput("T") is True                             # still held: no second toggle
+    assert cam.applyInput("") is True                              # released: keeps spinning
+    assert abs(cam.state()["yaw"] - (-87.7)) < 1e-4
+    assert cam.applyInput("T") is False                            # second press: off
+    assert abs(cam.state()["yaw"] - (-87.7)) < 1e-4
+    cam.applyInput("W", cam_speed=2.0)
+    f = np.array(cam.state()["forward"])
+    np.testing.assert_allclose(cam.getGPUData().position[:], np.array((0, 0, 5.0)) + 2.0 * f, atol=1e-5)
+
+
 def test_object_transform_quirks():
     hs = host.HostScene()
     o = hs.addObject("square")
