@@ -150,14 +150,14 @@ typedef struct rtr_frame_stats {
     uint64_t numRays;          /* every traceRay-equivalent issued: primary + shadow */
     uint64_t numPrimaryRays;
     uint64_t numShadowRays;
-    uint64_t numNodeVisits;    /* N_node: 64-B node fetches */
+    uint64_t numNodeVisits;    /* N_node: node record fetches */
     uint64_t numTriTests;      /* N_tri : 48-B triangle record fetches */
     uint64_t numHits;          /* N_hit : closest-hit shading fetches (236 B each) */
     uint64_t numLightFetches;  /* N_lightfetch: LightInfo reads (96 B each) */
     uint64_t numLightTriFetches;/* light triangle vertex fetches (3 idx + 3 x 48 B = 156 B each) */
     uint64_t numTexFetches;    /* bilinear texture / HDRI lookups (4 texels, 16 B each) */
     uint64_t numAlphaTests;    /* opacity.rahit invocations that sampled an opacity map (236 B fetch + 1 lookup each) */
-    uint64_t algorithmicBytes; /* B = 32 N_node (RTR_BVH_NODE_BYTES) + 48 N_tri + 236 (N_hit + N_alpha) + 96 N_lf + 156 N_ltf + 16 N_tex + 4 k P (+16/32 P HDR) */
+    uint64_t algorithmicBytes; /* B = 32 N_node_primary (RTR_BVH_NODE_BYTES) + 64 N_node_shadow (RTR_WIDE_NODE_BYTES; 32 in the megakernel) + 48 N_tri + 236 (N_hit + N_alpha) + 96 N_lf + 156 N_ltf + 16 N_tex + 4 k P (+16/32 P HDR) */
     /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
     uint64_t numShadowNodeVisits;
     uint64_t numShadowTriTests;
@@ -177,6 +177,7 @@ typedef struct rtr_frame_stats {
     uint64_t shadowInnerIterations, shadowInnerActiveLanes;
     uint64_t shadowTriIterations, shadowTriActiveLanes;
     uint64_t shadowRefills;
+    uint64_t primaryTailRays;  /* camera rays that outgrew the 16-entry LDS stack of k_primary_persist and were redone by k_primary_tail over the BVH2 */
     uint64_t shadowTailRays;   /* rays that outgrew the 13-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
 } rtr_frame_stats;
 

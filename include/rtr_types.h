@@ -142,9 +142,10 @@ typedef struct RtrBvhGrid {
  * the root.  Built on the device after every build / refit (kernels/rtr_bvh.hip: k_wide_nodes, k_permute_wide).
  *   plane[k] : slot k: (xmin | ymin << 16) (xmax | ymax << 16) (zmin | zmax << 16), IEEE binary16 each
  *   child[k] : >= 0 index of a record of this array; < 0 leaf code as in RtrBvhNode (triangles in the same leaf-ordered array);
- *              0x80000000 = empty slot (slots 0 and 1 are never empty)
+ *              0x80000000 = empty slot (slots 0 and 1 are never empty); its planes are min = +inf, max = -inf: an inside-out box
+ *              no ray enters when the entry / exit planes are picked by the ray's direction signs (the kernel's octant forms)
  */
-#define RTR_WIDE_LAYOUT_VERSION 43
+#define RTR_WIDE_LAYOUT_VERSION 44
 #define RTR_WIDE_NODE_BYTES 64
 #define RTR_WIDE_EMPTY ((int32_t)0x80000000)
 typedef struct RtrWideNode {

@@ -27,9 +27,9 @@ namespace {
 
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
-    uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0;
+    uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0, primaryOverflow = 0;
     void add(const Counters& o) {
-        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests;
+        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests; primaryOverflow += o.primaryOverflow;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
     }
@@ -44,6 +44,7 @@ struct Scene {
     std::vector<const RtrInstance*> byCustom;
     rtr_v3 skyLinear;
     bool useWide = false;                   /* shadow rays over the wide view (oracle_scene::wide) */
+    int primaryStackLimit = 0;              /* 16 in the staged pipeline (k_primary_persist / k_primary + k_primary_tail), 0 = unbounded (megakernel) */
 };
 
 struct Hit { bool hit; float t, u, v; uint32_t custom, prim; };
@@ -126,7 +127,7 @@ Hit trace_brute(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, boo
     return best;
 }
 
-Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
+Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c, int stackLimit = 0) {
     const RtrBvhNode* nodes = sc.s->nodes;
     const RtrBvhTri* tris = sc.s->tris;
     Hit best{}; best.hit = false; best.t = tmax;
@@ -150,6 +151,9 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
             if (hl && hr) {
                 int32_t nearC = n.child[0], farC = n.child[1];
                 if (tr < tl) { nearC = n.child[1]; farC = n.child[0]; }
+                /* the primary kernels of the staged pipeline keep 16 stack entries in LDS; a camera ray that needs a 17th is abandoned
+                 * there and re-traced from scratch by k_primary_tail with a full-depth stack (both parts are counted) */
+                if (stackLimit > 0 && sp >= stackLimit) { c.primaryOverflow++; return trace_bvh(sc, o, d, tmin, tmax, anyHit, c, 0); }
                 stack[sp++] = farC;
                 cur = nearC;
                 continue;
@@ -260,7 +264,7 @@ inline Hit trace(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bo
     if (anyHit) c.shadow++; else c.primary++;
     if (!(tmax > tmin)) { Hit h{}; h.hit = false; return h; }
     if (anyHit && sc.useWide) return trace_wide(sc, o, d, tmin, tmax, c);
-    return sc.s->nodes ? trace_bvh(sc, o, d, tmin, tmax, anyHit, c) : trace_brute(sc, o, d, tmin, tmax, anyHit, c);
+    return sc.s->nodes ? trace_bvh(sc, o, d, tmin, tmax, anyHit, c, anyHit ? 0 : sc.primaryStackLimit) : trace_brute(sc, o, d, tmin, tmax, anyHit, c);
 }
 
 /* ---- cook-torrance.glsl ----------------------------------------------------------------------- */
@@ -661,6 +665,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     Scene sc;
     if (!prepare(s, sc)) return -1;
     sc.useWide = s->wide != nullptr && s->nodes != nullptr && s->numWide > 0 && prm.pipeline != 1;
+    sc.primaryStackLimit = (s->nodes != nullptr && prm.pipeline != 1) ? 16 : 0;
     const uint32_t rows = shard_rows(prm.height, prm.bandRows, prm.shardCount);
     const uint32_t W = prm.width;
     BandMap bm{prm.bandRows, prm.shardIndex, prm.shardCount, prm.height};
@@ -718,6 +723,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.numTexFetches = tot.texFetch; st.numAlphaTests = tot.alphaTests;
     const uint64_t shadowNodeBytes = sc.useWide ? RTR_WIDE_NODE_BYTES : RTR_BVH_NODE_BYTES;
     st.shadowTraceBytes = shadowNodeBytes * tot.shadowNodes + 48 * tot.shadowTris + 33 * tot.shadow;
+    st.primaryTailRays = tot.primaryOverflow;
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;

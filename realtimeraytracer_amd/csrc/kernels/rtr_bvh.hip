@@ -311,13 +311,15 @@ __host__ __device__ inline uint32_t rtr_f16_ceil_bits(int32_t v) {          /* t
  * BVH2 node n and, while a slot is free, opens the inner entry with the largest box into its own two children; boxes are
  * copied from the BVH2 nodes that own them and child codes keep BVH2 node ids, so entry 0 roots a complete 4-wide tree.
  * Word layout (16 words = RtrWideNode): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16) as half floats about the grid centre,
- * then the four child codes; an empty slot has the code 0x80000000. */
+ * then the four child codes; an empty slot has the code 0x80000000 and an inside-out infinite box. */
 __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
                                                    const RtrBvhGrid* __restrict__ grid, uint4* __restrict__ wide) {
     const uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i >= numNodes) return;
     uint32_t o[16];
-    for (int k = 0; k < 16; ++k) o[k] = 0u;
+    /* an empty slot: the code RTR_WIDE_EMPTY and an inside-out box with infinite planes (min = +inf, max = -inf as half floats),
+     * which no ray enters in the kernel's octant forms: those forms skip the test of the code */
+    for (int k = 0; k < 4; ++k) { o[k * 3] = 0x7c007c00u; o[k * 3 + 1] = 0xfc00fc00u; o[k * 3 + 2] = 0xfc007c00u; }
     for (int k = 12; k < 16; ++k) o[k] = 0x80000000u;
     if (!parent || parent[i] != -2) {
         const float sx = grid->scale[0], sy = grid->scale[1], sz = grid->scale[2];

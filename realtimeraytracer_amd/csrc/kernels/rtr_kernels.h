@@ -8,12 +8,13 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
-#define RTR_ANYHIT_KERNEL_REVISION "r02.3"
+#define RTR_ANYHIT_KERNEL_REVISION "r02.4"
 
 constexpr uint32_t kQueueRegions = 8;                       /* one batch cursor per XCD: eight times the atomic rate of one counter */
 constexpr uint32_t kQueueLists = kQueueRegions * kQueueRegions;        /* batch lists of the binned queue: (direction octant, consumer XCD) */
 constexpr uint32_t kQueueListLens = 16 + 16 * kQueueLists;            /* first word of the list lengths (read-only while the queue drains) */
-constexpr uint32_t kQueueCtrlWords = kQueueListLens + kQueueLists;
+constexpr uint32_t kPrimaryCursors = kQueueListLens + kQueueLists;   /* kQueueRegions batch cursors of k_primary_persist, 64 B apart */
+constexpr uint32_t kQueueCtrlWords = kPrimaryCursors + 16 * kQueueRegions;
 static_assert(kQueueLists == 64, "k_shadow_gen_oct reserves the batch lists with one lane per list");
 
 /* Scratch of the wavefront (staged) pipeline, owned by an rtr_frame. */
@@ -22,7 +23,7 @@ struct Workspace {
     uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
     float4*   rayQueue = nullptr;    /* 2 x float4 per queued shadow ray: (o.xyz,tmax) (d.xyz,bits(slot)) */
     uint8_t*  vis = nullptr;         /* per slot: 1 = occluded */
-    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [16 + 16 r] batch cursor of queue region r (2-wide kernel, r < 8) or of batch list r = octant * 8 + xcd (64 B apart: a cursor is hammered by one XCD's waves), [kQueueListLens + r] length of list r */
+    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [16 + 16 r] batch cursor of queue region r (2-wide kernel, r < 8) or of batch list r = octant * 8 + xcd (64 B apart: a cursor is hammered by one XCD's waves), [kQueueListLens + r] length of list r, [kPrimaryCursors + 16 r] batch cursor of region r of the camera rays (k_primary_persist) */
     uint2*    batchLists = nullptr;  /* kQueueLists lists of listStride batches {first queue index, rays}: the queue binned by direction octant */
     uint32_t  listStride = 0;
     uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail (capacity: one per slot) */

@@ -150,15 +150,13 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
 }
 
 /* ---- wavefront stage 1: primary visibility ---------------------------------------------------- */
-/* The production form (STATS = false) always runs with a 16-entry LDS stack (16 KiB per workgroup): ordered traversal seldom
- * holds more, the kernel fits next to another frame's persistent traversal kernel much earlier (frames in flight: +3 %), and
- * the rare ray that needs more is listed in `redo` and re-traced by k_primary_tail with a full-depth stack in global memory.
- * The counting form keeps the depth-bound stack so its counters are exactly the oracle's. */
+/* One camera ray per lane (the comparison form, RTR_PRIMARY_PERSIST=0; k_primary_persist is the production kernel).  16-entry LDS
+ * stack (16 KiB per workgroup): ordered traversal seldom holds more, and the rare ray that needs more is listed in `redo` and
+ * re-traced by k_primary_tail with a full-depth stack in global memory — the same rule in the timed and the counting form. */
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
                                                     Counters* stats, uint32_t* redoCount, uint32_t* redoList) {
-    constexpr int kLds = STATS ? STACK : 16;
-    __shared__ int32_t s_stack[kLds * kBlock];
+    __shared__ int32_t s_stack[16 * kBlock];
     int32_t* stack = s_stack + threadIdx.x;
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     uint32_t px, lrow, py;
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const rtr_v3 dir = primary_dir(ra, px, py, i);
         HitRec h;
-        if (STATS) trace<false, STATS, kBlock, 0>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
+        if (STATS) trace<false, true, kBlock, 16, 8>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
         else {
             /* camera rays of one 8x8 tile nearly always share their direction signs: run the traversal compiled for that octant */
             const uint32_t oct = ray_octant(sc, camPos, dir);
@@ -187,17 +185,19 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
         }
         /* sample-major planes keep each store of a wave contiguous */
         const size_t k = (size_t)i * gridDim.x * kBlock + q;
-        if (!STATS && h.custom == RTR_STACK_OVERFLOW) { redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k; continue; }
+        if (h.custom == RTR_STACK_OVERFLOW) { redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k; continue; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
     }
     if (STATS) st.flush(stats);
 }
 
-/* Re-traces the pixel-samples k_primary abandoned: full-depth stack in global memory (no LDS, so it can always run). */
+/* Re-traces the pixel-samples the primary kernels abandoned: BVH2 walk with a full-depth stack in global memory (no LDS, so it
+ * can always run).  STATS: the counting form (the ray itself was counted by the kernel that abandoned it). */
+template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
                                                          const uint32_t* __restrict__ redoCount, const uint32_t* __restrict__ redoList,
-                                                         int32_t* __restrict__ spill, uint32_t planeStride) {
+                                                         int32_t* __restrict__ spill, uint32_t planeStride, Counters* stats) {
     const uint32_t n = *redoCount;
     if (n == 0) return;
     int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;
@@ -209,10 +209,12 @@ __global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, RenderA
         uint32_t px, lrow, py;
         if (!pixel_of(ra, q, px, lrow, py)) continue;
         HitRec h;
-        trace<false, false, 64 * kBlock>(sc, stack, camPos, primary_dir(ra, px, py, i), 0.001f, 10000.0f, h, st);
+        trace<false, STATS, 64 * kBlock>(sc, stack, camPos, primary_dir(ra, px, py, i), 0.001f, 10000.0f, h, st);
+        if (STATS) { st.rays--; st.primary--; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
     }
+    if (STATS) st.flush(stats);
 }
 
 /* ---- wavefront stage 2: shadow-ray generation into the compacted queue ------------------------- */
@@ -567,6 +569,7 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
                                              const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
                                              WaveStats& ws, LocalStats& st) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const float tmaxC = rtr_hwmin(tmax, tmax);           /* the far limit as a min's result: the loop's min3 need not quiet it again on every trip */
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
         if (innerMask == 0ull) break;
@@ -592,30 +595,38 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
             const int32_t top = *sp;                           /* speculative: hides the pop's LDS latency under the node loads */
             const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
             float t0, t1, t2, t3;
-            const bool h0 = slab_wide<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmax, t0);           /* slot 0 is never empty */
-            const bool h1 = slab_wide<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmax, t1);
-            const bool h2 = slab_wide<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmax, t2) && c2 != kDone;
-            const bool h3 = slab_wide<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmax, t3) && c3 != kDone;
-            /* descend into the nearest child that is hit; the others go on the stack in slot order.  (Taking the first hit slot
-             * instead of the nearest saves eight instructions and costs 2 % more time; ordering the others too —
+            /* an empty slot (only slots 2, 3 can be) holds an inside-out box with infinite planes: in the octant forms its entry
+             * is +inf and its exit -inf, so it is never hit and needs no test of its code; the mixed form's per-axis min / max would
+             * turn it back into an all-enclosing box, so that form looks at the code */
+            const bool h0 = slab_wide<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmaxC, t0);
+            const bool h1 = slab_wide<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmaxC, t1);
+            const bool h2 = slab_wide<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmaxC, t2) & (OCT < 8 || c2 != kDone);
+            const bool h3 = slab_wide<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmaxC, t3) & (OCT < 8 || c3 != kDone);
+            /* descend into the nearest child that is hit (strict <: ties go to the lower slot); the others go on the stack in slot
+             * order.  e_k: slot k displaced the nearest so far; the slot entered is the last one that did (slot 0 if none did).
+             * (Taking the first hit slot instead of the nearest saves instructions and costs 2 % more time; ordering the others too —
              * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
-             * 2.15 / 2.22 ms against 2.05.) */
-            int32_t next = kDone;
-            float tn = 3.0e38f;
-            if (h0) { tn = t0; next = c0; }
-            if (h1 && t1 < tn) { tn = t1; next = c1; }
-            if (h2 && t2 < tn) { tn = t2; next = c2; }
-            if (h3 && t3 < tn) { tn = t3; next = c3; }
-            /* the stack pointer is the LDS address of the top entry, so a push is an add and a store.  A visit pushes at most three
+             * 2.15 / 2.22 ms against 2.05.)  Which slots are stacked is mask arithmetic on the comparison results, not a
+             * comparison of codes. */
+            float tn = h0 ? t0 : 3.0e38f;
+            const bool e1 = h1 & (t1 < tn); tn = e1 ? t1 : tn;
+            const bool e2 = h2 & (t2 < tn); tn = e2 ? t2 : tn;
+            const bool e3 = h3 & (t3 < tn);
+            int32_t next = e3 ? c3 : (e2 ? c2 : (e1 ? c1 : c0));
+            const bool any = h0 | h1 | h2 | h3;
+            /* the stack pointer is the LDS address of the top entry, so a push is a store and an add.  A visit pushes at most three
              * entries and the kernel reserves three guard entries above the STACK it may use: the bound is checked once, after the
-             * pushes (a ray that went past it is abandoned to the tail kernel; what it wrote into the guard entries is its own) */
-            const bool pop = next == kDone;                      /* nothing hit */
-            if (h0 && c0 != next) { sp += kBlock; *sp = c0; }
-            if (h1 && c1 != next) { sp += kBlock; *sp = c1; }
-            if (h2 && c2 != next) { sp += kBlock; *sp = c2; }
-            if (h3 && c3 != next) { sp += kBlock; *sp = c3; }
-            if (sp > lds + STACK * kBlock) { res = 2u; next = kDone; }     /* needs more than the LDS stack: the tail kernel redoes this ray */
-            else if (pop) { next = top; sp -= kBlock; }                     /* slot 0 holds kDone */
+             * pushes, by a branch the whole wave takes or skips (a ray that went past it is abandoned to the tail kernel; what it
+             * wrote into the guard entries is its own) */
+            if (h0 & (e1 | e2 | e3)) { sp[kBlock] = c0; sp += kBlock; }
+            if (h1 & !(e1 & !e2 & !e3)) { sp[kBlock] = c1; sp += kBlock; }
+            if (h2 & !(e2 & !e3)) { sp[kBlock] = c2; sp += kBlock; }
+            if (h3 & !e3) { sp[kBlock] = c3; sp += kBlock; }
+            const bool over = sp > lds + STACK * kBlock;       /* taken before the pop: popping the empty stack leaves sp below its base */
+            if (!any) { next = top; sp -= kBlock; }             /* nothing hit: pop (slot 0 holds kDone) */
+            if (__ballot(over) != 0ull) {
+                if (over) { res = 2u; next = kDone; }           /* needs more than the LDS stack: the tail kernel redoes this ray */
+            }
             cur = next;
         }
     }
@@ -811,6 +822,171 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (STATS) st.flush(stats);
 }
 
+/* ---- wavefront stage 1, persistent form: closest hit of the camera rays ----------------------------------------------------------
+ * The any-hit kernel's machinery around the BVH2 walk of trace(): persistent waves; the work items are (sample, pixel slot) pairs
+ * k = sample * planeStride + slot in the canonical 8x8-tile order, cut into kQueueRegions contiguous regions (a band of the image
+ * per XCD) with one batch cursor each; a wave refills its idle lanes by ballot, so a lane whose ray ends early takes the next
+ * camera ray instead of waiting for the deepest ray of its tile (the one-ray-per-lane k_primary ran at 67 % lane use, 56 % VALU
+ * issue and an average of 2.9 resident waves per SIMD: profiles/r02/pmc_summary_bench_sponza1080p_serial.txt).
+ * A ray's walk is trace()'s, visit for visit: near child first (ties: child 0), far child stacked, boxes tested against the best t
+ * so far, ALL triangles of a leaf tested, closest = min over (t, customIndex, primitiveID); 16 LDS stack entries, beyond which the
+ * ray is left to k_primary_tail — so the counters are the oracle's trace_bvh() with its 16-entry rule.
+ * (The 4-wide records do not pay here: a closest-hit walk over them makes 18.3 visits per camera ray instead of 31.7, but a
+ * 4-wide visit costs ~90 vector instructions against ~45, and this kernel is bound by vector-instruction issue like the any-hit
+ * kernel: 349 M wave-instructions and 0.52-0.58 ms against 112 M and 0.35 ms — profiles/r02/primary_wide_kernel.txt.) */
+template <int STACK, int OCT, bool STATS>
+__device__ __forceinline__ void inner_nodes2(const __amdgpu_buffer_rsrc_t nodeBuf, int32_t* lds, int32_t& cur, int32_t*& sp, uint32_t& res,
+                                             const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin, LocalStats& st) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (;;) {
+        const unsigned long long innerMask = __ballot(cur >= 0);
+        if (innerMask == 0ull) break;
+        if ((uint32_t)__popcll(innerMask) <= kInnerMin && __ballot(cur < 0 && cur != kDone) != 0ull) break;
+        if (cur >= 0) {
+            if (STATS) st.nodes++;
+            const int32_t nodeOff = cur << 5;                   /* one 32-B RtrBvhNode = the whole visit */
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, 0);
+            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, 0);
+            const int32_t top = *sp;                             /* speculative: hides the pop's LDS latency under the node loads */
+            float tl, tr;
+            const bool hl = slab_oct<OCT>(a.x, a.y, b.x, ga, gb, tmin, tmax, tl);
+            const bool hr = slab_oct<OCT>(a.z, a.w, b.y, ga, gb, tmin, tmax, tr);
+            const bool swap = tr < tl;
+            const int32_t c0 = (int32_t)b.z, c1 = (int32_t)b.w;
+            const bool both = hl && hr, none = !(hl || hr);
+            const bool second = both ? swap : !hl;               /* descend into child 1? (the near child if both are hit) */
+            int32_t next = second ? c1 : c0;
+            if (both) { sp += kBlock; *sp = swap ? c0 : c1; }    /* one guard entry above the STACK the ray may use */
+            if (sp > lds + STACK * kBlock) { res = 2u; next = kDone; }     /* needs a deeper stack: k_primary_tail redoes this ray */
+            else if (none) { next = top; sp -= kBlock; }                    /* slot 0 holds kDone */
+            cur = next;
+        }
+    }
+}
+
+template <int STACK, bool STATS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_primary_persist(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
+                                                         Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t* cursors,
+                                                         uint32_t planeStride, uint32_t kBatch, uint32_t kRefill, uint32_t kInnerMin) {
+    __shared__ int32_t s_stack[(STACK + 1 + 1) * kBlock];    /* slot 0 holds kDone for good; one guard entry above the stack (inner_nodes2) */
+    int32_t* lds = s_stack + threadIdx.x;
+    lds[0] = kDone;
+    LocalStats st;
+    uint32_t batchPos = 0, batchEnd = 0;     /* wave-uniform */
+    bool exhausted = false;
+    const uint32_t n = ra.spp * planeStride;
+    const uint32_t regionLen = ((n + kQueueRegions - 1) / kQueueRegions + kBatch - 1) / kBatch * kBatch;
+    const uint32_t myRegion = blockIdx.x % kQueueRegions;
+    uint32_t regionTry = 0;
+    int32_t cur = kDone;
+    int32_t* sp = lds;
+    const rtr_v3 o = rtr_ld3(ra.cam.position);
+    rtr_v3 d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);
+    HitRec best; best.t = 0.f; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+    uint32_t item = 0, res = kResNone;
+    const float tmin = 0.001f, tmax = 10000.0f;
+    const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, 0, 0xffffffff, 0x00020000);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    for (;;) {
+        const unsigned long long idle = __ballot(cur == kDone);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (nIdle >= kRefill || nIdle == 64u) {
+            if (cur == kDone && res != kResNone) {
+                if (res == 2u) redoList[atomicAdd(redoCount, 1u)] = item;              /* finished by k_primary_tail */
+                else { hitTuvp[item] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[item] = best.custom; }
+                res = kResNone;
+            }
+            if (!exhausted) {
+                if (batchPos == batchEnd) {
+                    for (;;) {
+                        if (regionTry >= kQueueRegions) { exhausted = true; break; }
+                        const uint32_t r = (myRegion + regionTry) % kQueueRegions;
+                        const uint32_t lo = r * regionLen;
+                        uint32_t hi = lo + regionLen; if (hi > n) hi = n;
+                        uint32_t b = hi;
+                        if (lo < hi) {
+                            uint32_t got = 0;
+                            if ((threadIdx.x & 63u) == 0) got = atomicAdd(cursors + 16u * r, kBatch);
+                            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                            b = got < regionLen ? lo + got : hi;
+                        }
+                        if (b < hi) { batchPos = b; batchEnd = (b + kBatch < hi) ? b + kBatch : hi; break; }
+                        ++regionTry;
+                    }
+                }
+                if (!exhausted) {
+                    const uint32_t avail = batchEnd - batchPos;
+                    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (cur == kDone && prefix < avail) {
+                        item = batchPos + prefix;
+                        const uint32_t i = item / planeStride, q = item - i * planeStride;      /* sample, pixel slot */
+                        uint32_t px, lrow, py;
+                        if (pixel_of(ra, q, px, lrow, py)) {                                   /* padding slots issue no ray */
+                            d = primary_dir(ra, px, py, i);
+                            if (STATS) { st.rays++; st.primary++; }
+                            const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+                            rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
+                            best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+                            cur = 0; sp = lds; res = 0u;
+                        }
+                    }
+                    batchPos += (nIdle < avail) ? nIdle : avail;
+                }
+            }
+        }
+        if (__ballot(cur != kDone) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        {
+            const unsigned long long innerNow = __ballot(cur >= 0);
+            if (innerNow != 0ull) {
+                const uint32_t oct = (ga.x < 0.f ? 1u : 0u) | (ga.y < 0.f ? 2u : 0u) | (ga.z < 0.f ? 4u : 0u);
+                const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
+                const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
+                const float limit = best.t;                  /* best t so far (tmax until something is hit): fixed during the node phase */
+                switch (mixed ? 8u : woct) {
+                    case 0: inner_nodes2<STACK, 0, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 1: inner_nodes2<STACK, 1, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 2: inner_nodes2<STACK, 2, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 3: inner_nodes2<STACK, 3, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 4: inner_nodes2<STACK, 4, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 5: inner_nodes2<STACK, 5, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 6: inner_nodes2<STACK, 6, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    case 7: inner_nodes2<STACK, 7, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                    default: inner_nodes2<STACK, 8, STATS>(nodeBuf, lds, cur, sp, res, ga, gb, tmin, limit, kInnerMin, st); break;
+                }
+            }
+        }
+        /* ---- leaves: every triangle, keep the closest (same acceptance and tie rule as trace()) ---- */
+        if (cur < 0 && cur != kDone) {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const int32_t triOff = (int32_t)((first + i) * 48u);
+                const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff, 0, 0);
+                const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 16, 0, 0);
+                const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 32, 0, 0);
+                if (STATS) st.tris++;
+                float t, u, v;
+                if (rtr_mt_intersect(o, d, rtr_mk(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                     rtr_mk(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z)),
+                                     rtr_mk(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z)), tmin, &t, &u, &v) && t < tmax) {
+                    const uint32_t cu = r0.w, pr = r1.w;
+                    if ((r2.w & 1u) && !alpha_pass<STATS>(sc, cu, pr, u, v, st)) continue;
+                    if (t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)))) {
+                        best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                    }
+                }
+            }
+            cur = *sp; sp -= kBlock;                         /* slot 0 holds kDone: an empty stack ends the ray */
+        }
+    }
+    if (STATS) st.flush(stats);
+}
+
 /* Finishes the rays the production kernels abandoned (stack deeper than their 16 LDS entries): one ray per lane, plain
  * trace<true>() with a full-depth 64-entry stack.  Usually zero rays.  The stack lives in GLOBAL memory (the frame's spill
  * area): a 64-KiB LDS stack could not become resident next to another frame's persistent traversal kernel, so with frames
@@ -919,11 +1095,26 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (ev) hipEventRecord(ev[0], s);
     /* the storage of ws.overflow is used twice per frame: first as k_primary's redo list (count in queueCount[2], consumed by
      * k_primary_tail), then as the any-hit kernel's overflow list (count in overflow[0]) */
-    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1);
-    else {
-        hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1);
-        hipLaunchKernelGGL(k_primary_tail, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, blocks * kBlock);
-    }
+    /* camera rays: the persistent kernel (k_primary_persist), or one ray per lane (k_primary; RTR_PRIMARY_PERSIST=0, for comparison).
+     * Both walk the BVH2 and leave the rays that outgrow their 16-entry LDS stack to k_primary_tail; the counting form takes the
+     * same path as the timed one. */
+    static const uint32_t kPersist = env_u32("RTR_PRIMARY_PERSIST", 0u, 0u, 1u);
+    static const uint32_t kPBatch = env_u32("RTR_PRIMARY_BATCH", 64u, 64u, 1u << 16);
+    static const uint32_t kPRefill = env_u32("RTR_PRIMARY_REFILL", 24u, 1u, 64u);
+    static const uint32_t kPInnerMin = env_u32("RTR_PRIMARY_INNER_MIN", 20u, 0u, 63u);
+    static const uint32_t kPWgsPerCu = env_u32("RTR_PRIMARY_WGS_PER_CU", 8u, 1u, 8u);
+    const uint32_t planeStride = blocks * kBlock;
+    if (kPersist && (unsigned long long)planeStride * ra.spp < 0xffffffffull) {
+        uint32_t pblocks = numCus * kPWgsPerCu;
+        const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
+        if (pblocks > pneeded) pblocks = pneeded;
+        if (pblocks == 0) pblocks = 1;
+        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1);
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1);
+    if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
+    else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);

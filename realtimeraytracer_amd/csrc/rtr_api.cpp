@@ -942,6 +942,7 @@ int rtr_frame_wait(rtr_frame* f) {
         s.shadowInnerIterations = h.innerIters; s.shadowInnerActiveLanes = h.innerLanes;
         s.shadowTriIterations = h.triIters; s.shadowTriActiveLanes = h.triLanes; s.shadowRefills = h.refills;
         if (f->overflow.p) { uint32_t ov = 0; HIP_TRY(hipMemcpy(&ov, f->overflow.p, sizeof ov, hipMemcpyDeviceToHost)); s.shadowTailRays = ov; }
+        if (f->pendingWave && f->queueCount.p) { uint32_t rd = 0; HIP_TRY(hipMemcpy(&rd, f->queueCount.p + 2, sizeof rd, hipMemcpyDeviceToHost)); s.primaryTailRays = rd; }
         s.algorithmicBytes = (uint64_t)RTR_BVH_NODE_BYTES * (h.nodes - h.shadowNodes) + shadowNodeBytes * h.shadowNodes + 48ull * h.tris + 236ull * (h.hits + h.alphaTests) + 96ull * h.lightFetch + 156ull * h.lightTriFetch +
                              16ull * h.texFetch +
                              4ull * f->pendingImagesK * s.localPixels + (f->pendingHdr ? (f->pendingAccum ? 32ull : 16ull) * s.localPixels : 0ull);
