@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 --isolated-frames 0 $@"
+BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 --isolated-frames 0 --present-frames 0 $@"
 pass() { name=$1; shift; timeout -k 10 170 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/bench_$name.log" 2>&1 || echo "$name failed"; }
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.log" 2>&1 || echo "stats failed"
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY

@@ -10,9 +10,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# the default bench command (3 frames in flight); --isolated-frames 0 drops the untimed one-at-a-time pass so the
+# the default bench command (3 frames in flight); --isolated-frames 0 --present-frames 0 drops the untimed one-at-a-time pass so the
 # averages below cover the timed launches only.  stats_serial = the same frames one at a time (kernel cost in isolation).
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --isolated-frames 0"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --isolated-frames 0 --present-frames 0"
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.log" 2>&1
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -- $BENCH --frames-in-flight 1 > "$OUT/bench_stats_serial.log" 2>&1
 timeout -k 10 170 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_pmc_fetch.log" 2>&1

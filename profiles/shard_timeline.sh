@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_shard8
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 170 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 $REPO/bench.py --steps 40 --warmup 6 --emulate-rank-of ${1:-8} --isolated-frames 0 > "$OUT/bench.log" 2>&1
+timeout -k 10 170 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 $REPO/bench.py --steps 40 --warmup 6 --emulate-rank-of ${1:-8} --isolated-frames 0 --present-frames 0 > "$OUT/bench.log" 2>&1
 python3 - "$OUT" <<'PY' > $REPO/gpurun_out/shard_timeline.txt
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -402,7 +402,16 @@ constexpr uint32_t kRefillDefault = 20;    /* idle lanes that trigger a refill (
  *   * node and triangle addresses are 32-bit offsets from a scalar base (global_load ... saddr), not 64-bit lane math.
  * (This is the 2-wide form, RTR_TRACE_BVH4=0: kept as a second implementation the tests hold against the 4-wide kernel.) */
 constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
-constexpr uint32_t kTopNodes = 40;         /* four-wide entries k_shadow_trace4 keeps in LDS: 2.5 KiB next to the 17-KiB stack = 8 workgroups per CU */
+#ifndef RTR_TRACE_BLOCK
+#define RTR_TRACE_BLOCK 256
+#endif
+/* The any-hit kernel's workgroup: 256 lanes, eight per CU = the 32-wave hardware maximum.  Its LDS: 17 stack entries per lane
+ * (17 KiB) + the first kTopNodes four-wide records of the tree (2.5 KiB).  Larger workgroups would share one larger copy of the
+ * tree's top (1024 lanes: two copies of 160 records per CU instead of eight of 40) and the kernel alone gets faster with them
+ * (1.86 -> 1.80 ms), but a big workgroup frees its LDS only when its last wave retires, which is when the other frames' kernels
+ * can start: with four frames in flight 11.57 G rays/s became 11.1 (512 lanes) and 10.3 (1024) — profiles/r02/trace_block_size.log. */
+constexpr int kTraceBlock = RTR_TRACE_BLOCK;
+constexpr uint32_t kTopNodes = 40u * (RTR_TRACE_BLOCK / 256);
 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
@@ -618,12 +627,12 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
              * entries and the kernel reserves three guard entries above the STACK it may use: the bound is checked once, after the
              * pushes, by a branch the whole wave takes or skips (a ray that went past it is abandoned to the tail kernel; what it
              * wrote into the guard entries is its own) */
-            if (h0 & (e1 | e2 | e3)) { sp[kBlock] = c0; sp += kBlock; }
-            if (h1 & !(e1 & !e2 & !e3)) { sp[kBlock] = c1; sp += kBlock; }
-            if (h2 & !(e2 & !e3)) { sp[kBlock] = c2; sp += kBlock; }
-            if (h3 & !e3) { sp[kBlock] = c3; sp += kBlock; }
-            const bool over = sp > lds + STACK * kBlock;       /* taken before the pop: popping the empty stack leaves sp below its base */
-            if (!any) { next = top; sp -= kBlock; }             /* nothing hit: pop (slot 0 holds kDone) */
+            if (h0 & (e1 | e2 | e3)) { sp[kTraceBlock] = c0; sp += kTraceBlock; }
+            if (h1 & !(e1 & !e2 & !e3)) { sp[kTraceBlock] = c1; sp += kTraceBlock; }
+            if (h2 & !(e2 & !e3)) { sp[kTraceBlock] = c2; sp += kTraceBlock; }
+            if (h3 & !e3) { sp[kTraceBlock] = c3; sp += kTraceBlock; }
+            const bool over = sp > lds + STACK * kTraceBlock;       /* taken before the pop: popping the empty stack leaves sp below its base */
+            if (!any) { next = top; sp -= kTraceBlock; }             /* nothing hit: pop (slot 0 holds kDone) */
             if (__ballot(over) != 0ull) {
                 if (over) { res = 2u; next = kDone; }           /* needs more than the LDS stack: the tail kernel redoes this ray */
             }
@@ -640,17 +649,17 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
  * form or the queue mode, so the counting form's numbers are the timed form's, and the oracle restates them), per-trip lane counts
  * of the two phases, and a shader-clock stamp pair per wave. */
 template <int STACK, bool LISTS, bool STATS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
                                                               uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
                                                               const uint2* __restrict__ lists, uint32_t listStride, Counters* stats,
                                                               unsigned long long* __restrict__ clk) {
-    __shared__ int32_t s_stack[(STACK + 1 + 3) * kBlock];    /* slot 0, below the stack, holds kDone for good; three guard entries above it (inner_nodes4) */
+    __shared__ int32_t s_stack[(STACK + 1 + 3) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good; three guard entries above it (inner_nodes4) */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
-    for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kBlock) s_top[i] = sc.nodes4[i];
+    for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kTraceBlock) s_top[i] = sc.nodes4[i];
     __syncthreads();
     /* clock of this launch: shader-clock ticks over 100-MHz ticks, lane 0 of the first workgroup of each XCD (bench.py: roofline.clock_mhz) */
     const bool stamp = clk != nullptr && blockIdx.x < kQueueRegions && threadIdx.x == 0;
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
             if (atLeaf) {
                 if (hit) { res = 1u; cur = kDone; }
-                else { cur = *sp; sp -= kBlock; }
+                else { cur = *sp; sp -= kTraceBlock; }
             }
         } else if (cur < 0 && cur != kDone) {
             const uint32_t code = (uint32_t)~cur;
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             bool hit = false;
             for (uint32_t i = 0; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
             if (hit) { res = 1u; cur = kDone; }
-            else { cur = *sp; sp -= kBlock; }                        /* slot 0 holds kDone: an empty stack ends the ray (visible) */
+            else { cur = *sp; sp -= kTraceBlock; }                        /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }
     }
     if (stamp || STATS) {
@@ -1155,13 +1164,16 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u);
     static const uint32_t kTop = env_u32("RTR_TRACE_TOP_NODES", kTopNodes, 0u, kTopNodes);
     const uint32_t top = kTop < sc.numNodes4 ? kTop : sc.numNodes4;
+    /* the 4-wide kernel's workgroups are kTraceBlock lanes: the same number of waves in fewer workgroups */
+    uint32_t tblocks4 = tblocks * (uint32_t)kBlock / (uint32_t)kTraceBlock;
+    if (tblocks4 == 0) tblocks4 = 1;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<13, true, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<13, false, true>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<13, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<13, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<13, true, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<13, false, false>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<13, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<13, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
     } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
     if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
