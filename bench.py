@@ -190,7 +190,7 @@ def main():
              "wide_visits": int(fs.numShadowNodeVisits), "triangle_tests": int(fs.numShadowTriTests), "shadow_rays": int(fs.numShadowRays)}
 
     p_run = [params(0, j=j) for j in range(K)]
-    kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0}
+    kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
     clocks = []
 
     works = [None] * nbuf
@@ -249,7 +249,7 @@ def main():
         inflight[buf] = False
         st = frames[buf].stats()
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
-        kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
+        kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
         if st.shadowTraceClockMHz > 0:
             clocks.append(st.shadowTraceClockMHz)
 
@@ -260,7 +260,7 @@ def main():
         inflight[b] = False
         st = mg.frame_stats(b, 0)
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
-        kern["shadow_trace"] += st.shadowTraceMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
+        kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
         if st.shadowTraceClockMHz > 0:
             clocks.append(st.shadowTraceClockMHz)
 
@@ -306,7 +306,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0, "n": 0})
+    kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0})
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -326,7 +326,7 @@ def main():
     # and the roofline are taken from this pass; rocprofv3 of `--frames-in-flight 1` reproduces it (profiles/).
     kern_iso, iso_ms_per_frame, clocks_iso = None, None, []
     if nbuf > 1 and args.isolated_frames > 0:
-        kern_iso = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0}
+        kern_iso = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0}
         clocks_iso = []
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -335,6 +335,7 @@ def main():
             st = frames[0].stats()
             kern_iso["primary"] += st.primaryMs / args.isolated_frames; kern_iso["shadow_gen"] += st.shadowGenMs / args.isolated_frames
             kern_iso["shadow_trace"] += st.shadowTraceMs / args.isolated_frames; kern_iso["resolve"] += st.resolveMs / args.isolated_frames
+            kern_iso["shadow_tail"] += st.shadowTailMs / args.isolated_frames
             if st.shadowTraceClockMHz > 0:
                 clocks_iso.append(st.shadowTraceClockMHz)
         iso_ms_per_frame = (time.perf_counter() - t1) * 1e3 / args.isolated_frames
@@ -346,7 +347,7 @@ def main():
         pscene = api.Scene(ctx, psetup.desc)
         pframe = api.Frame(ctx, W, H, 0xff)
         pp = api.make_params(W, H, spp=4, shadow_rays=args.shadow_rays, images=A.IMAGES_RAYGEN5, pipeline=args.pipeline)
-        acc = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "resolve": 0.0}
+        acc = {"kernels": 0.0}
         for j in range(2 + args.present_frames):
             if j == 2:
                 torch.cuda.synchronize()
@@ -357,7 +358,7 @@ def main():
                 prays = int(pframe.stats().numRays)
             if j >= 2:
                 st = pframe.stats()
-                acc["primary"] += st.primaryMs; acc["shadow_gen"] += st.shadowGenMs; acc["shadow_trace"] += st.shadowTraceMs; acc["resolve"] += st.resolveMs
+                acc["kernels"] += st.totalMs
             pframe.denoise_combine(4)
         pms = (time.perf_counter() - t1) * 1e3 / args.present_frames
         ray_ms = sum(acc.values()) / args.present_frames
@@ -400,7 +401,7 @@ def main():
                 # the ceiling that binds: one SIMD issues one vector instruction at a time; SQ_ACTIVE_INST_VALU counts, in units of 4
                 # cycles, the time SIMDs spent issuing them
                 "bound": "valu_issue",
-                "kernel": "k_shadow_trace4<13, true, false> (+ k_shadow_tail): any-hit traversal of the shadow-ray queue, revision " + rev,
+                "kernel": "k_shadow_trace4<13, true, false>: any-hit traversal of the shadow-ray queue, revision " + rev,
                 "achieved": round(busy, 1) if busy else None, "peak": round(launch_cycles, 1) if launch_cycles else None,
                 "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch)",
                 "frac": round(busy / launch_cycles, 4) if (busy and launch_cycles) else None,
@@ -426,6 +427,7 @@ def main():
                 "traffic": traffic,
                 "hbm_frac": round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "l2_frac": round(pmc["TCP_TCC_READ_REQ"] * 64 / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if pmc else None,
+                # the second unit that is nearly full: one L1 (TCP) per CU, one tag look-up per clock
                 "l1_tag_lookups_per_l1_clock": round(pmc["TCP_TOTAL_CACHE_ACCESSES"] / (num_simds / 4 * launch_cycles), 4) if (pmc and launch_cycles) else None,
                 # algorithmic bytes of the same kernel (its counting form): 64 B per 4-wide record visited + 48 B per triangle test + 33 B per
                 # ray.  Served by LDS / L1 / L2 / Infinity Cache: this rate is NOT a fraction of any ceiling and is not the roofline

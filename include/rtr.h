@@ -166,7 +166,7 @@ typedef struct rtr_frame_stats {
     float    totalMs;
     float    primaryMs;        /* k_primary (wavefront) or the whole megakernel */
     float    shadowGenMs;      /* k_shadow_gen */
-    float    shadowTraceMs;    /* k_shadow_trace: the dominant kernel */
+    float    shadowTraceMs;    /* the any-hit kernel (k_shadow_trace4) alone: the dominant kernel */
     float    resolveMs;        /* k_resolve */
     uint32_t localRows;        /* rows this shard rendered */
     uint32_t localPixels;
@@ -177,6 +177,8 @@ typedef struct rtr_frame_stats {
     uint64_t shadowInnerIterations, shadowInnerActiveLanes;
     uint64_t shadowTriIterations, shadowTriActiveLanes;
     uint64_t shadowRefills;
+    float    shadowTailMs;     /* k_shadow_tail (the rays that outgrew the LDS stack, redone over the BVH2); part of totalMs */
+    uint32_t _padTail;
     uint64_t primaryTailRays;  /* camera rays that outgrew the 16-entry LDS stack of k_primary_persist and were redone by k_primary_tail over the BVH2 */
     uint64_t shadowTailRays;   /* rays that outgrew the 13-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
 } rtr_frame_stats;
@@ -211,10 +213,20 @@ int  rtr_scene_export_wide(const rtr_scene* scene, RtrWideNode* nodes, size_t no
  * in `stats`.  Used by the CPU-side tests (BVH invariants, oracle BVH-vs-brute-force). */
 int  rtr_host_build_bvh(const rtr_scene_desc* desc, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes,
                         RtrBvhTri* tris, size_t triBytes);
+/* Limits of the 32-bit record offsets the traversal kernels use: RTR_OK if a scene of numTriangles triangles and numNodes BVH nodes
+ * can be addressed (triangle records and 4-wide records each below 2 GiB: at most 44 739 242 triangles, 33 554 431 nodes; and the
+ * 2^28 of the leaf encoding), else RTR_ERR_INVALID_ARGUMENT with the reason in rtr_last_error().  rtr_scene_create applies it
+ * to the worst case for its triangle count (numTriangles - 1 nodes) before anything is built or allocated. */
+int  rtr_check_scene_limits(uint64_t numTriangles, uint64_t numNodes);
 /* Dynamic scenes: new instance transforms (same instances, meshes and customIndex as at creation) and, optionally,
  * new light infos (NULL keeps them).  World-space triangle records are recomputed and every BVH box is re-fitted ON
  * THE DEVICE; the topology is kept.  Replaces TLAS::updateTransform + TLAS::refit
  * (src/vulkan/raytracing/tlas.cppm:151-207; present in the reference, never called by its app). */
+/* Both update calls rewrite device arrays that renders read (nodes, 4-wide records, triangle records, light tables).  A scene may be
+ * rendered by frames of several contexts / streams at once, so the calls first JOIN THE WHOLE DEVICE (hipDeviceSynchronize: every
+ * frame in flight on any stream of this process finishes with the old scene), rewrite, and return when the new state is complete.
+ * They are therefore safe to call at any time from the thread that enqueues the renders; a caller that renders the scene from
+ * other threads or processes must itself keep those from enqueueing new frames of this scene until the call has returned. */
 int  rtr_scene_update_instances(rtr_scene* scene, const RtrInstance* instances, uint32_t numInstances,
                                 const RtrAreaLightInfo* lights, uint32_t numLights);
 /* replaces the host-visible LightInfo buffer rewrite (src/app/application.cppm:264-271). */

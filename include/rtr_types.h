@@ -147,6 +147,11 @@ typedef struct RtrBvhGrid {
  */
 #define RTR_WIDE_LAYOUT_VERSION 44
 #define RTR_WIDE_NODE_BYTES 64
+/* entries of the per-ray stack the any-hit kernel keeps in LDS while it walks the wide view; a ray that holds more after a visit is
+ * redone over the BVH2 (k_shadow_tail).  Part of the definition of a ray's walk (the counting form and the oracle follow it). */
+#ifndef RTR_WIDE_STACK
+#define RTR_WIDE_STACK 13
+#endif
 #define RTR_WIDE_EMPTY ((int32_t)0x80000000)
 typedef struct RtrWideNode {
     uint32_t plane[4][3];

@@ -144,7 +144,7 @@ struct rtr_frame {
     DevBuf<unsigned long long> clk;
     uint32_t listStride = 0;
     DevBuf<Counters> counters;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* [5]: between the any-hit kernel and k_shadow_tail */
     hipEvent_t evMega[2] = {nullptr, nullptr};
     rtr_frame_stats stats{};
     bool pendingStats = false, pendingWave = false, pendingCounters = false;
@@ -497,7 +497,9 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     HIP_TRY(hipSetDevice(ctx->device));
     size_t totalPrims = 0;
     for (uint32_t i = 0; i < d->numInstances; ++i) totalPrims += d->meshes[d->instances[i].meshIndex].indexCount / 3u;
-    if (totalPrims >= (1u << 28)) return fail(RTR_ERR_INVALID_ARGUMENT, "too many triangles for the leaf encoding (2^28)");
+    /* every triangle may end up in a leaf of its own: numTriangles - 1 inner nodes, hence as many 4-wide records at most */
+    rc = rtr_check_scene_limits(totalPrims, totalPrims ? totalPrims - 1 : 0);
+    if (rc != RTR_OK) return rc;
     /* tiny scenes always take the host builder (the radix tree needs a root with more than one leaf's worth of primitives) */
     const bool deviceBuild = d->buildFlags == RTR_BUILD_DEVICE_LBVH && totalPrims >= 16;
     rtr::BvhResult bvh; std::vector<float> xforms, nmats; uint32_t stackEntries = 0; size_t numTris = 0;
@@ -648,6 +650,9 @@ int rtr_scene_update_instances(rtr_scene* s, const RtrInstance* instances, uint3
     HIP_TRY(hipSetDevice(s->ctx->device));
     int rc = ensure_refit_ready(s);
     if (rc != RTR_OK) return rc;
+    /* frames of OTHER contexts (other streams) may be rendering this scene: everything enqueued on the device so far is joined
+     * before the nodes, records and light tables are rewritten (contract in rtr.h) */
+    HIP_TRY(hipDeviceSynchronize());
     hipStream_t st = s->ctx->stream;
     rtr_scene_desc view{};
     view.meshes = s->hostMeshes.data(); view.numMeshes = (uint32_t)s->hostMeshes.size();
@@ -727,10 +732,26 @@ int rtr_scene_update_lights(rtr_scene* s, const RtrAreaLightInfo* lights, uint32
     }
     HIP_TRY(hipSetDevice(s->ctx->device));
     if (n) {
+        HIP_TRY(hipDeviceSynchronize());       /* frames in flight on other streams read s->lights: joined before the rewrite (contract in rtr.h) */
         HIP_TRY(hipMemcpyAsync(s->lights.p, lights, n * sizeof(RtrAreaLightInfo), hipMemcpyHostToDevice, s->ctx->stream));
         HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         s->hostLights.assign(lights, lights + n);
     }
+    return RTR_OK;
+}
+
+/* The traversal kernels address triangle records, BVH2 nodes and 4-wide records through 32-bit byte offsets from one buffer base
+ * each ((first + i) * 48, node << 5, record << 6 in signed 32-bit lane arithmetic: kernels/rtr_device.h trace(), kernels/rtr_kernels.hip
+ * inner_nodes4 / tri_any): a scene whose arrays reach 2 GiB would silently intersect the wrong records, so it is refused here. */
+int rtr_check_scene_limits(uint64_t numTriangles, uint64_t numNodes) {
+    const uint64_t kMaxBytes = 1ull << 31;
+    if (numTriangles >= (1ull << 28)) return fail(RTR_ERR_INVALID_ARGUMENT, "%llu triangles: too many for the leaf encoding (2^28)", (unsigned long long)numTriangles);
+    if (numTriangles * sizeof(RtrBvhTri) >= kMaxBytes)
+        return fail(RTR_ERR_INVALID_ARGUMENT, "%llu triangles: the %zu-byte triangle records would reach 2 GiB, past the kernels' 32-bit record offsets (at most %llu triangles)",
+                    (unsigned long long)numTriangles, sizeof(RtrBvhTri), (unsigned long long)((kMaxBytes - 1) / sizeof(RtrBvhTri)));
+    if (numNodes * RTR_WIDE_NODE_BYTES >= kMaxBytes)
+        return fail(RTR_ERR_INVALID_ARGUMENT, "%llu BVH nodes: the %d-byte 4-wide records would reach 2 GiB, past the kernels' 32-bit record offsets (at most %llu nodes)",
+                    (unsigned long long)numNodes, RTR_WIDE_NODE_BYTES, (unsigned long long)((kMaxBytes - 1) / RTR_WIDE_NODE_BYTES));
     return RTR_OK;
 }
 
@@ -752,7 +773,7 @@ int rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t image
         if (images & RTR_IMG_BIT(i)) { e = f->img[i].alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->img[i].p, 0, px * 4, ctx->stream); }
     if (e == hipSuccess && (images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { e = f->hdr.alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->hdr.p, 0, px * 16, ctx->stream); }
     if (e == hipSuccess) e = f->counters.alloc(1);
-    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&f->ev[i]);
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&f->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&f->evMega[i]);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { rtr_frame_destroy(f); return fail(e == hipErrorOutOfMemory ? RTR_ERR_OUT_OF_MEMORY : RTR_ERR_HIP, "rtr_frame_create: %s", hipGetErrorString(e)); }
@@ -911,9 +932,12 @@ int rtr_frame_wait(rtr_frame* f) {
         float a = 0, b = 0, c = 0, d = 0;
         (void)hipEventElapsedTime(&a, f->ev[0], f->ev[1]);
         (void)hipEventElapsedTime(&b, f->ev[1], f->ev[2]);
-        (void)hipEventElapsedTime(&c, f->ev[2], f->ev[3]);
+        (void)hipEventElapsedTime(&c, f->ev[2], f->ev[5]);
+        float tail = 0;
+        (void)hipEventElapsedTime(&tail, f->ev[5], f->ev[3]);
+        s.shadowTailMs = tail;
         (void)hipEventElapsedTime(&d, f->ev[3], f->ev[4]);
-        s.primaryMs = a; s.shadowGenMs = b; s.shadowTraceMs = c; s.resolveMs = d; s.totalMs = a + b + c + d;
+        s.primaryMs = a; s.shadowGenMs = b; s.shadowTraceMs = c; s.resolveMs = d; s.totalMs = a + b + c + tail + d;
         s.pipelineUsed = 2;
         if (f->clk.p) {      /* shader clock held during the any-hit launch: s_memtime ticks over 100-MHz ticks, median of one wave per XCD */
             unsigned long long h[2 * rtrdev::kQueueRegions];

@@ -135,3 +135,20 @@ def test_product_never_touches_the_oracle():
                     f"{fn} references the oracle"
     ldd = subprocess.check_output(["ldd", A.LIB_HIP_PATH]).decode()
     assert "oracle" not in ldd
+
+
+def test_scene_limits_at_the_boundary_of_the_32_bit_record_offsets():
+    """the traversal kernels address records through 32-bit byte offsets, so a scene whose triangle records (48 B) or
+    4-wide records (64 B) would reach 2 GiB is refused before anything is built — checked on the arithmetic, no giant allocation."""
+    lib = A.hip_lib()
+    max_tris = (2**31 - 1) // 48            # 44 739 242
+    max_nodes = (2**31 - 1) // 64           # 33 554 431
+    assert lib.rtr_check_scene_limits(max_tris, 0) == 0
+    assert lib.rtr_check_scene_limits(max_tris + 1, 0) == -1 and b"triangle records would reach 2 GiB" in lib.rtr_last_error()
+    assert lib.rtr_check_scene_limits(1000, max_nodes) == 0
+    assert lib.rtr_check_scene_limits(1000, max_nodes + 1) == -1 and b"4-wide records would reach 2 GiB" in lib.rtr_last_error()
+    assert lib.rtr_check_scene_limits(2**28, 0) == -1 and b"leaf encoding" in lib.rtr_last_error()
+    # what rtr_scene_create asks: every triangle in a leaf of its own -> numTriangles - 1 nodes; the node limit binds first
+    assert lib.rtr_check_scene_limits(max_nodes + 1, max_nodes) == 0
+    assert lib.rtr_check_scene_limits(max_nodes + 2, max_nodes + 1) == -1
+    assert lib.rtr_check_scene_limits(0, 0) == 0

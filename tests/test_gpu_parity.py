@@ -578,6 +578,39 @@ print("two-wide ok")
     assert r.returncode == 0 and "two-wide ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_persistent_camera_ray_kernel_matches(scene_cache, tmp_path):
+    """RTR_PRIMARY_PERSIST=1 selects k_primary_persist (persistent waves with ballot refill over the camera rays; off by default: it
+    loses with several frames in flight, profiles/r02/ab_primary_kernels.log).  Same walk per ray as k_primary, so: same five
+    images as the oracle's from the timed form, same counters from the counting form — in a child process, the switch being read
+    once per process."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import numpy as np
+from realtimeraytracer_amd import _abi as A, api, scenes
+from oracle import oracle_py as O
+W, H = 333, 187
+s = scenes.textured_room(W, H, ltc=scenes.synthetic_ltc())
+ctx = api.Context(0); scene = api.Scene(ctx, s.desc); frame = api.Frame(ctx, W, H, A.IMAGES_RAYGEN5)
+for collect in (0, 1):
+    p = api.make_params(W, H, spp=3, images=A.IMAGES_RAYGEN5, collect_stats=collect)
+    api.render(scene, s.camera, s.scene_info(5), p, frame)
+    ref = O.render(s.desc, s.camera, s.scene_info(5), p, bvh=scene.export_bvh(), images=A.IMAGES_RAYGEN5, threads=8)
+    for which in (0, 1, 2, 6, 7):
+        assert np.array_equal(frame.download(which), ref.images[which]), (collect, which)
+    if collect:
+        g = frame.stats()
+        for f in ("numRays", "numPrimaryRays", "numNodeVisits", "numTriTests", "numHits", "numAlphaTests", "primaryTailRays"):
+            assert getattr(g, f) == getattr(ref.stats, f), f
+print("persistent ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTR_PRIMARY_PERSIST="1", PYTHONPATH=root, RTR_SCENE_CACHE=str(scene_cache))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "persistent ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_d6_occluded_sample_with_overflowing_contribution(gpu_ctx, oracle, scene_cache):
     """Divergence D6.  The reference evaluates the BRDF of every light sample and multiplies by currShadow
     (raygen.rgen:244-270); the oracle does the same.  The product, when only the shadowed image is kept, does not evaluate the BRDF
