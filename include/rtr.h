@@ -180,7 +180,7 @@ typedef struct rtr_frame_stats {
     float    shadowTailMs;     /* k_shadow_tail (the rays that outgrew the LDS stack, redone over the BVH2); part of totalMs */
     uint32_t _padTail;
     uint64_t primaryTailRays;  /* camera rays that outgrew the 16-entry LDS stack of k_primary_persist and were redone by k_primary_tail over the BVH2 */
-    uint64_t shadowTailRays;   /* rays that outgrew the 13-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
+    uint64_t shadowTailRays;   /* rays that outgrew the 16-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
 } rtr_frame_stats;
 
 /* ---- context -------------------------------------------------------------------------- */

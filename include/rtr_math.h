@@ -294,14 +294,13 @@ RTR_HD void rtr_ray_grid(rtr_v3 o, rtr_v3 idir, const float* origin, const float
     ga->x = scale[0] * idir.x; ga->y = scale[1] * idir.y; ga->z = scale[2] * idir.z;
     gb->x = (origin[0] - o.x) * idir.x; gb->y = (origin[1] - o.y) * idir.y; gb->z = (origin[2] - o.z) * idir.z;
 }
-/* The same constants with the plane coordinate counted from the CENTRE of the grid (q - 32768): what the half-float planes of the
- * 4-wide records (RtrWideNode) are offsets from.  ga is unchanged; gbc = (origin + 32768 scale - o) * idir. */
-#define RTR_GRID_CENTRE 32768.0f
-RTR_HD void rtr_ray_grid_centre(rtr_v3 o, rtr_v3 idir, const float* origin, const float* scale, rtr_v3* ga, rtr_v3* gbc) {
+/* The same constants with the plane coordinate counted from the scene's wide centre c (RtrBvhGrid::wideCentreXY / Z, grid steps): what
+ * the half-float planes of the 4-wide records (RtrWideNode) are offsets from.  ga is unchanged; gbc = (origin + c scale - o) * idir. */
+RTR_HD void rtr_ray_grid_centre(rtr_v3 o, rtr_v3 idir, const float* origin, const float* scale, uint32_t centreXY, uint32_t centreZ, rtr_v3* ga, rtr_v3* gbc) {
     ga->x = scale[0] * idir.x; ga->y = scale[1] * idir.y; ga->z = scale[2] * idir.z;
-    gbc->x = (rtr_fma(RTR_GRID_CENTRE, scale[0], origin[0]) - o.x) * idir.x;
-    gbc->y = (rtr_fma(RTR_GRID_CENTRE, scale[1], origin[1]) - o.y) * idir.y;
-    gbc->z = (rtr_fma(RTR_GRID_CENTRE, scale[2], origin[2]) - o.z) * idir.z;
+    gbc->x = (rtr_fma((float)(centreXY & 0xffffu), scale[0], origin[0]) - o.x) * idir.x;
+    gbc->y = (rtr_fma((float)(centreXY >> 16), scale[1], origin[1]) - o.y) * idir.y;
+    gbc->z = (rtr_fma((float)(centreZ & 0xffffu), scale[2], origin[2]) - o.z) * idir.z;
 }
 /* Slab test of one child box given its six grid coordinates (already widened to 32 bits). */
 RTR_HD int rtr_slab_q(uint32_t qminx, uint32_t qminy, uint32_t qminz, uint32_t qmaxx, uint32_t qmaxy, uint32_t qmaxz,

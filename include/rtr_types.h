@@ -129,15 +129,16 @@ typedef struct RtrBvhNode {
 
 /* The grid the planes of every node live on (one per scene; rewritten by a refit). */
 typedef struct RtrBvhGrid {
-    float origin[3]; float _pad0;
-    float scale[3];  float _pad1;
+    float origin[3]; uint32_t wideCentreXY;    /* x | y << 16: grid coordinate the planes of the 4-wide records are offsets from (below) */
+    float scale[3];  uint32_t wideCentreZ;     /* z */
 } RtrBvhGrid;
 
 /* ---- 4-wide view of the same tree (layout W4.0): what the any-hit kernel walks (k_shadow_trace4) ---------------------------
  * One 64-B record = a collapsed subtree of the BVH2 (greedy: open the inner child with the largest box while a slot is free):
  * up to four child boxes and their four child codes, so a ray makes about half as many DEPENDENT visits.  A plane is stored as
- * a HALF FLOAT: its offset from the centre of the scene grid in grid steps (q - 32768), rounded outward to 11 significant bits
- * (exact within 2048 steps of the centre, 2^-11 of the distance from it beyond), so that its parameter on a ray is ONE
+ * a HALF FLOAT: its offset in grid steps from the scene's WIDE CENTRE c (q - c; RtrBvhGrid::wideCentreXY / Z: per axis the mean midpoint of
+ * the tree's leaf boxes, so the half floats are finest where the geometry is), rounded outward to 11 significant bits
+ * (exact within 2048 steps of c, 2^-11 of the distance from it beyond; a magnitude above 65504 becomes infinite), so that its parameter on a ray is ONE
  * instruction, t = fma(f16 plane, ga, gbc) with v_fma_mix_f32, no conversion (ga, gbc: rtr_ray_grid_centre).  Records are in breadth-first order (the first ones are the top levels, which the kernel keeps in LDS); record 0 is
  * the root.  Built on the device after every build / refit (kernels/rtr_bvh.hip: k_wide_nodes, k_permute_wide).
  *   plane[k] : slot k: (xmin | ymin << 16) (xmax | ymax << 16) (zmin | zmax << 16), IEEE binary16 each
@@ -145,12 +146,12 @@ typedef struct RtrBvhGrid {
  *              0x80000000 = empty slot (slots 0 and 1 are never empty); its planes are min = +inf, max = -inf: an inside-out box
  *              no ray enters when the entry / exit planes are picked by the ray's direction signs (the kernel's octant forms)
  */
-#define RTR_WIDE_LAYOUT_VERSION 44
+#define RTR_WIDE_LAYOUT_VERSION 45
 #define RTR_WIDE_NODE_BYTES 64
 /* entries of the per-ray stack the any-hit kernel keeps in LDS while it walks the wide view; a ray that holds more after a visit is
  * redone over the BVH2 (k_shadow_tail).  Part of the definition of a ray's walk (the counting form and the oracle follow it). */
 #ifndef RTR_WIDE_STACK
-#define RTR_WIDE_STACK 13
+#define RTR_WIDE_STACK 16
 #endif
 #define RTR_WIDE_EMPTY ((int32_t)0x80000000)
 typedef struct RtrWideNode {

@@ -197,14 +197,14 @@ inline float half_bits_to_float(uint32_t h) {
  * per-octant forms give the same bits as the min / max form here because the fma is monotone in the plane), descend into
  * the nearest child that is hit (strict <, so ties go to the lower slot), push the other hit children in slot order (skipping a
  * code equal to the one entered, as the kernel's `c != next` does), test a leaf's triangles in storage order until one hits;
- * RTR_WIDE_STACK (13) stack entries, beyond which the ray is redone over the BVH2 as k_shadow_tail does. */
+ * RTR_WIDE_STACK (16) stack entries, beyond which the ray is redone over the BVH2 as k_shadow_tail does. */
 Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Counters& c) {
     const RtrWideNode* nodes = sc.s->wide;
     const RtrBvhTri* tris = sc.s->tris;
     Hit best{}; best.hit = false; best.t = tmax;
     rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
     rtr_v3 ga, gb;
-    rtr_ray_grid_centre(o, idir, sc.s->grid.origin, sc.s->grid.scale, &ga, &gb);
+    rtr_ray_grid_centre(o, idir, sc.s->grid.origin, sc.s->grid.scale, sc.s->grid.wideCentreXY, sc.s->grid.wideCentreZ, &ga, &gb);
     std::vector<int32_t> stack;
     int32_t cur = 0;
     for (;;) {
@@ -229,7 +229,7 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
             for (int k = 1; k < 4; ++k) if (hit[k] && te[k] < tn) { tn = te[k]; next = n.child[k]; }
             bool overflow = false;
             for (int k = 0; k < 4; ++k) if (hit[k] && n.child[k] != next) { stack.push_back(n.child[k]); }
-            /* the kernel keeps RTR_WIDE_STACK stack entries in LDS (+ 3 guard entries, checked once after a visit's pushes); a ray that holds more
+            /* the kernel keeps RTR_WIDE_STACK stack entries in LDS; a ray that would hold more
              * after a visit is abandoned there and re-traced from scratch over the BVH2 by k_shadow_tail (counting form: both parts
              * are counted) */
             overflow = stack.size() > RTR_WIDE_STACK;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -249,6 +250,7 @@ int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : "/tmp/wsim";
     nodes2 = load<Node2>(dir + "/nodes.bin"); tris = load<Tri>(dir + "/tris.bin"); rays = load<Ray>(dir + "/rays.bin");
     auto g = load<float>(dir + "/grid.bin"); for (int k = 0; k < 3; ++k) { gorg[k] = g[k]; gscl[k] = g[4 + k]; g_center[k] = gorg[k] + 32768.0f * gscl[k]; }
+    if (const char* e = getenv("WSIM_CENTRE")) { float c[3]; if (sscanf(e, "%f,%f,%f", &c[0], &c[1], &c[2]) == 3) for (int k = 0; k < 3; ++k) g_center[k] = gorg[k] + c[k] * gscl[k]; }   /* grid steps */
     const Config cfgs[] = {
         {"W4 scene16 nearest (r01 kernel)    64B", 4, false, Q_SCENE16, O_NEAREST, 64, 8},
         {"W4 f16 about the scene centre      64B", 4, false, Q_F16CENTER, O_NEAREST, 64, 8},

@@ -19,7 +19,8 @@ api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, spp=spp, coll
 t0 = frame.stats()
 api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, spp=spp, collect_stats=1), frame)
 st = frame.stats()
-print(f"{name} {W}x{H} {spp}spp: {ss.numTriangles} triangles, {ss.numNodes} BVH2 nodes, {ss.numWideNodes} 4-wide records (layout {ss.wideLayoutVersion})")
+print(f"{name} {W}x{H} {spp}spp: {ss.numTriangles} triangles, {ss.numNodes} BVH2 nodes, {ss.numWideNodes} 4-wide records (layout {ss.wideLayoutVersion}), "
+      f"wide centre ({ss.grid.wideCentreXY & 0xffff}, {ss.grid.wideCentreXY >> 16}, {ss.grid.wideCentreZ}) grid steps")
 print("rays", st.numRays, "shadow", st.numShadowRays, "4-wide visits", st.numShadowNodeVisits, "shadow tri tests", st.numShadowTriTests, "tail rays", st.shadowTailRays)
 print("per shadow ray: 4-wide visits %.2f  tri tests %.2f ; per primary ray: BVH2 visits %.2f  tri tests %.2f" % (
     st.numShadowNodeVisits / st.numShadowRays, st.numShadowTriTests / st.numShadowRays,

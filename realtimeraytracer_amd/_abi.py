@@ -52,7 +52,7 @@ class RtrBvhNode(C.Structure):
 
 
 class RtrBvhGrid(C.Structure):
-    _fields_ = [("origin", f32 * 3), ("_pad0", f32), ("scale", f32 * 3), ("_pad1", f32)]
+    _fields_ = [("origin", f32 * 3), ("wideCentreXY", u32), ("scale", f32 * 3), ("wideCentreZ", u32)]
 
 
 class RtrBvhTri(C.Structure):

@@ -282,16 +282,19 @@ __global__ __launch_bounds__(kB) void k_quantize(uint32_t numNodes, const float4
     nodes[(size_t)i * 2] = w0; nodes[(size_t)i * 2 + 1] = w1;
 }
 
-/* f16 bits of a signed plane offset v (scene-grid steps from the grid's CENTRE, |v| <= 32768), rounded towards -inf / +inf to the
- * 11 significant bits of a half float.  Integer arithmetic, so a host restatement agrees bit for bit. */
-__host__ __device__ inline uint32_t rtr_f16_bits_of_int(uint32_t a) {      /* a has at most 11 significant bits, a <= 65504 */
+/* f16 bits of a signed plane offset v (scene-grid steps from the scene's wide centre, |v| <= 65535), rounded towards -inf / +inf to
+ * the 11 significant bits of a half float; a magnitude past the largest half float (65504) rounds away from zero to infinity and
+ * towards zero to 65504.  Integer arithmetic, so a host restatement agrees bit for bit. */
+__host__ __device__ inline uint32_t rtr_f16_bits_of_int(uint32_t a) {      /* a has at most 11 significant bits; a > 65504 (only 65536 can arrive) -> inf */
     if (a == 0) return 0u;
+    if (a > 65504u) return 0x7c00u;
     const int e = 31 - __builtin_clz(a);                                   /* a = 1.m * 2^e, e <= 15 */
     const uint32_t m = (e >= 10) ? (a >> (e - 10)) : (a << (10 - e));      /* 11 bits, leading one at bit 10 */
     return ((uint32_t)(e + 15) << 10) | (m & 0x3ffu);
 }
 __host__ __device__ inline uint32_t rtr_f16_mag_down(uint32_t a) {          /* largest representable <= a */
     if (a <= 2048u) return a;
+    if (a > 65504u) return 65504u;
     const int sh = (31 - __builtin_clz(a)) - 10;
     return (a >> sh) << sh;
 }
@@ -305,6 +308,106 @@ __host__ __device__ inline uint32_t rtr_f16_floor_bits(int32_t v) {         /* t
 }
 __host__ __device__ inline uint32_t rtr_f16_ceil_bits(int32_t v) {          /* towards +inf */
     return v >= 0 ? rtr_f16_bits_of_int(rtr_f16_mag_up((uint32_t)v)) : (0x8000u | rtr_f16_bits_of_int(rtr_f16_mag_down((uint32_t)(-v))));
+}
+
+/* The wide centre of a tree: the grid coordinate c (per axis) the 4-wide records' half-float planes are offsets from.  Half floats
+ * are exact within 2048 steps of c and lose a bit per doubling beyond, so c decides where the boxes stay tight.  Two candidates per
+ * axis, both from the tree's leaf boxes (integer sums in 64-bit atomics: the same bytes on every run):
+ *   mean : the mean midpoint of the leaf boxes — tight where most leaves are;
+ *   flat : the 4096-step window holding the most face area of leaves that are FLAT on this axis (extent <= 2 steps: floors, walls).
+ *          A flat leaf whose planes move outward by more than the 0.01 a shadow ray is lifted off its surface swallows the origin
+ *          of every ray leaving that surface; on the bunny-class scene (a small object on a large ground plane, planes about the
+ *          grid's own centre) that cost +47 % node visits and +125 % triangle tests per shadow ray.
+ * The flat candidate is taken on an axis where it cuts the area-weighted relative inflation of the leaf boxes (capped at the
+ * box's own extent) to a quarter or less of the mean candidate's — measured choices and counts in profiles/r02/wide_centre.log. */
+constexpr uint32_t kCentreBins = 512;                 /* of 128 grid steps */
+constexpr uint32_t kCentreWindow = 32;                /* bins: the +-2048 steps a half float holds exactly */
+constexpr uint32_t kCentreWords = 4 + 3 * kCentreBins + 6 + 6;    /* sums[4], flat-area histograms, candidates [axis][2], costs [axis][2] */
+
+struct LeafBox { uint32_t lo[3], hi[3]; };
+__device__ __forceinline__ int leaf_boxes(uint32_t i, uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent, LeafBox out[2]) {
+    int n = 0;
+    if (i < numNodes && (!parent || parent[i] != -2)) {
+        const uint4 a = nodes[(size_t)i * 2], b = nodes[(size_t)i * 2 + 1];
+        if ((int32_t)b.z < 0) { LeafBox& l = out[n++]; l.lo[0] = a.x & 0xffffu; l.lo[1] = a.x >> 16; l.lo[2] = b.x & 0xffffu; l.hi[0] = a.y & 0xffffu; l.hi[1] = a.y >> 16; l.hi[2] = b.x >> 16; }
+        if ((int32_t)b.w < 0) { LeafBox& l = out[n++]; l.lo[0] = a.z & 0xffffu; l.lo[1] = a.z >> 16; l.lo[2] = b.y & 0xffffu; l.hi[0] = a.w & 0xffffu; l.hi[1] = a.w >> 16; l.hi[2] = b.y >> 16; }
+    }
+    return n;
+}
+__device__ __forceinline__ unsigned long long wave_total(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(kB) void k_wide_centre_sum(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
+                                                        unsigned long long* __restrict__ w) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    LeafBox lb[2];
+    const int nl = leaf_boxes(i, numNodes, nodes, parent, lb);
+    unsigned long long s[4] = {0, 0, 0, 0};
+    for (int j = 0; j < nl; ++j) {
+        for (int k = 0; k < 3; ++k) {
+            s[k] += lb[j].lo[k] + lb[j].hi[k];
+            if (lb[j].hi[k] - lb[j].lo[k] <= 2u) {          /* flat on axis k: its face area goes to the bins of its two planes */
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                const unsigned long long area = (((unsigned long long)(lb[j].hi[a] - lb[j].lo[a]) * (lb[j].hi[b] - lb[j].lo[b])) >> 8) + 1ull;
+                atomicAdd(w + 4 + k * kCentreBins + (lb[j].lo[k] >> 7), area);
+                atomicAdd(w + 4 + k * kCentreBins + (lb[j].hi[k] >> 7), area);
+            }
+        }
+        s[3] += 2;
+    }
+    for (int k = 0; k < 4; ++k) { const unsigned long long t = wave_total(s[k]); if ((threadIdx.x & 63u) == 0 && t) atomicAdd(w + k, t); }
+}
+__global__ void k_wide_centre_candidates(unsigned long long* __restrict__ w) {
+    const unsigned long long n = w[3];
+    unsigned long long* cand = w + 4 + 3 * kCentreBins;
+    for (int k = 0; k < 3; ++k) {
+        unsigned long long mean = 32768ull;
+        if (n) { mean = (w[k] + n / 2) / n; if (mean > 65535ull) mean = 65535ull; }
+        const unsigned long long* h = w + 4 + k * kCentreBins;
+        unsigned long long run = 0, best = 0; uint32_t bestStart = 0;
+        for (uint32_t b = 0; b < kCentreBins; ++b) {
+            run += h[b];
+            if (b >= kCentreWindow) run -= h[b - kCentreWindow];
+            if (b + 1 >= kCentreWindow && run > best) { best = run; bestStart = b + 1 - kCentreWindow; }      /* ties: the lowest window */
+        }
+        cand[2 * k] = mean;
+        cand[2 * k + 1] = best ? (unsigned long long)(bestStart * 128u + 2048u) : mean;
+    }
+}
+/* outward movement of a plane q stored as a half float about c, in grid steps */
+__device__ __forceinline__ uint32_t plane_slack_lo(uint32_t q, uint32_t c) { const int32_t v = (int32_t)q - (int32_t)c; return v >= 0 ? (uint32_t)v - rtr_f16_mag_down((uint32_t)v) : rtr_f16_mag_up((uint32_t)(-v)) - (uint32_t)(-v); }
+__device__ __forceinline__ uint32_t plane_slack_hi(uint32_t q, uint32_t c) { const int32_t v = (int32_t)q - (int32_t)c; return v >= 0 ? rtr_f16_mag_up((uint32_t)v) - (uint32_t)v : (uint32_t)(-v) - rtr_f16_mag_down((uint32_t)(-v)); }
+__global__ __launch_bounds__(kB) void k_wide_centre_cost(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
+                                                         unsigned long long* __restrict__ w) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    const unsigned long long* cand = w + 4 + 3 * kCentreBins;
+    LeafBox lb[2];
+    const int nl = leaf_boxes(i, numNodes, nodes, parent, lb);
+    unsigned long long cost[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < nl; ++j)
+        for (int k = 0; k < 3; ++k) {
+            const int a = (k + 1) % 3, b = (k + 2) % 3;
+            const unsigned long long area = (((unsigned long long)(lb[j].hi[a] - lb[j].lo[a]) * (lb[j].hi[b] - lb[j].lo[b])) >> 8) + 1ull;
+            const uint32_t ext = lb[j].hi[k] - lb[j].lo[k] + 1u;
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t cc = (uint32_t)cand[2 * k + c];
+                const uint32_t slack = plane_slack_lo(lb[j].lo[k], cc) + plane_slack_hi(lb[j].hi[k], cc);
+                uint32_t rel = (slack << 8) / ext;                /* relative inflation in 1/256, capped at the box's own extent */
+                if (rel > 256u) rel = 256u;
+                cost[2 * k + c] += area * rel;
+            }
+        }
+    for (int q = 0; q < 6; ++q) { const unsigned long long t = wave_total(cost[q]); if ((threadIdx.x & 63u) == 0 && t) atomicAdd(w + 4 + 3 * kCentreBins + 6 + q, t); }
+}
+__global__ void k_wide_centre_set(const unsigned long long* __restrict__ w, RtrBvhGrid* grid) {
+    const unsigned long long* cand = w + 4 + 3 * kCentreBins;
+    const unsigned long long* cost = cand + 6;
+    uint32_t c[3];
+    for (int k = 0; k < 3; ++k) c[k] = (uint32_t)((cost[2 * k + 1] * 4ull <= cost[2 * k]) ? cand[2 * k + 1] : cand[2 * k]);
+    grid->wideCentreXY = c[0] | (c[1] << 16);
+    grid->wideCentreZ = c[2];
 }
 
 /* 4-wide view of the tree for the any-hit kernel (rtr_kernels.hip, k_shadow_trace4): entry n starts from the two children of
@@ -323,6 +426,7 @@ __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint
     for (int k = 12; k < 16; ++k) o[k] = 0x80000000u;
     if (!parent || parent[i] != -2) {
         const float sx = grid->scale[0], sy = grid->scale[1], sz = grid->scale[2];
+        const int32_t cx = (int32_t)(grid->wideCentreXY & 0xffffu), cy = (int32_t)(grid->wideCentreXY >> 16), cz = (int32_t)(grid->wideCentreZ & 0xffffu);
         /* an entry = (owner node, side); its three plane words and its code come from the owner */
         uint32_t own[4]; int side[4]; int k = 2;
         own[0] = own[1] = i; side[0] = 0; side[1] = 1;
@@ -349,12 +453,12 @@ __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint
         for (int j = 0; j < k; ++j) {
             uint32_t wmin, wmax, wz; int32_t code;
             words(own[j], side[j], wmin, wmax, wz, code);
-            /* planes leave here as HALF FLOATS: the offset from the centre of the scene grid (q - 32768), rounded outward to 11 significant
+            /* planes leave here as HALF FLOATS: the offset from the scene's wide centre (q - c), rounded outward to 11 significant
              * bits, so the kernel's slab test needs no conversion (one v_fma_mix_f32 per plane).  Exact within 2048 steps of the centre,
              * 2^-11 of the distance from it beyond: +0.7 % node visits, +6 % triangle tests on the bench frame (profiles/r02/wide_sim_f16.log)
              * for 12 % fewer vector instructions per visit */
-            const int32_t xmin = (int32_t)(wmin & 0xffffu) - 32768, ymin = (int32_t)(wmin >> 16) - 32768, zmin = (int32_t)(wz & 0xffffu) - 32768;
-            const int32_t xmax = (int32_t)(wmax & 0xffffu) - 32768, ymax = (int32_t)(wmax >> 16) - 32768, zmax = (int32_t)(wz >> 16) - 32768;
+            const int32_t xmin = (int32_t)(wmin & 0xffffu) - cx, ymin = (int32_t)(wmin >> 16) - cy, zmin = (int32_t)(wz & 0xffffu) - cz;
+            const int32_t xmax = (int32_t)(wmax & 0xffffu) - cx, ymax = (int32_t)(wmax >> 16) - cy, zmax = (int32_t)(wz >> 16) - cz;
             o[j * 3] = rtr_f16_floor_bits(xmin) | (rtr_f16_floor_bits(ymin) << 16);
             o[j * 3 + 1] = rtr_f16_ceil_bits(xmax) | (rtr_f16_ceil_bits(ymax) << 16);
             o[j * 3 + 2] = rtr_f16_floor_bits(zmin) | (rtr_f16_ceil_bits(zmax) << 16);
@@ -416,7 +520,13 @@ hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDevic
     return hipGetLastError();
 }
 
-hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, const RtrBvhGrid* grid, uint4* wide, hipStream_t s) {
+hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, RtrBvhGrid* grid, uint4* wide, unsigned long long* sums4, hipStream_t s) {
+    BV_TRY(hipMemsetAsync(sums4, 0, kCentreWords * sizeof(unsigned long long), s));
+    const dim3 gn((numNodes + kB - 1) / kB);
+    hipLaunchKernelGGL(k_wide_centre_sum, gn, dim3(kB), 0, s, numNodes, nodes, parentOrNull, sums4);
+    hipLaunchKernelGGL(k_wide_centre_candidates, dim3(1), dim3(1), 0, s, sums4);
+    hipLaunchKernelGGL(k_wide_centre_cost, gn, dim3(kB), 0, s, numNodes, nodes, parentOrNull, sums4);
+    hipLaunchKernelGGL(k_wide_centre_set, dim3(1), dim3(1), 0, s, sums4, grid);
     hipLaunchKernelGGL(k_wide_nodes, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, nodes, parentOrNull, grid, wide);
     return hipGetLastError();
 }
@@ -425,6 +535,8 @@ hipError_t bvh_permute_wide(const uint4* in, uint32_t numNodes, const uint32_t* 
     hipLaunchKernelGGL(k_permute_wide, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, in, remap, out);
     return hipGetLastError();
 }
+
+size_t bvh_wide_scratch_words() { return kCentreWords; }
 
 size_t bvh_sort_temp_bytes(uint32_t numPrims) {
     size_t bytes = 0;

@@ -411,7 +411,7 @@ constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
  * (1.86 -> 1.80 ms), but a big workgroup frees its LDS only when its last wave retires, which is when the other frames' kernels
  * can start: with four frames in flight 11.57 G rays/s became 11.1 (512 lanes) and 10.3 (1024) — profiles/r02/trace_block_size.log. */
 constexpr int kTraceBlock = RTR_TRACE_BLOCK;
-constexpr uint32_t kTopNodes = (RTR_WIDE_STACK < 13 ? 40u + (13u - RTR_WIDE_STACK) * 16u : 40u) * (RTR_TRACE_BLOCK / 256);   /* a stack entry less = 1 KiB = 16 records more */
+constexpr uint32_t kTopNodes = 40u * (RTR_TRACE_BLOCK / 256);
 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
@@ -624,16 +624,24 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
             int32_t next = e3 ? c3 : (e2 ? c2 : (e1 ? c1 : c0));
             const bool any = h0 | h1 | h2 | h3;
             /* the stack pointer is the LDS address of the top entry, so a push is a store and an add.  A visit pushes at most three
-             * entries and the kernel reserves three guard entries above the STACK it may use: the bound is checked once, after the
-             * pushes, by a branch the whole wave takes or skips (a ray that went past it is abandoned to the tail kernel; what it
-             * wrote into the guard entries is its own) */
-            if (h0 & (e1 | e2 | e3)) { sp[kTraceBlock] = c0; sp += kTraceBlock; }
-            if (h1 & !(e1 & !e2 & !e3)) { sp[kTraceBlock] = c1; sp += kTraceBlock; }
-            if (h2 & !(e2 & !e3)) { sp[kTraceBlock] = c2; sp += kTraceBlock; }
-            if (h3 & !e3) { sp[kTraceBlock] = c3; sp += kTraceBlock; }
-            const bool over = sp > lds + STACK * kTraceBlock;       /* taken before the pop: popping the empty stack leaves sp below its base */
-            if (!any) { next = top; sp -= kTraceBlock; }             /* nothing hit: pop (slot 0 holds kDone) */
-            if (__ballot(over) != 0ull) {
+             * entries: while every lane of the wave has three free (one comparison and a branch the whole wave takes or skips) the pushes
+             * need no bound; otherwise the visit runs its checked form, in which a lane whose stack is full is abandoned to the tail
+             * kernel.  All STACK entries are usable, none is a guard. */
+            const bool p0 = h0 & (e1 | e2 | e3), p1 = h1 & !(e1 & !e2 & !e3), p2 = h2 & !(e2 & !e3), p3 = h3 & !e3;
+            int32_t* const full = lds + STACK * kTraceBlock;
+            if (__ballot(sp > full - 3 * kTraceBlock) == 0ull) {
+                if (p0) { sp[kTraceBlock] = c0; sp += kTraceBlock; }
+                if (p1) { sp[kTraceBlock] = c1; sp += kTraceBlock; }
+                if (p2) { sp[kTraceBlock] = c2; sp += kTraceBlock; }
+                if (p3) { sp[kTraceBlock] = c3; sp += kTraceBlock; }
+                if (!any) { next = top; sp -= kTraceBlock; }    /* nothing hit: pop (slot 0 holds kDone) */
+            } else {
+                bool over = false;
+                if (p0) { if (sp < full) { sp[kTraceBlock] = c0; sp += kTraceBlock; } else over = true; }
+                if (p1) { if (sp < full) { sp[kTraceBlock] = c1; sp += kTraceBlock; } else over = true; }
+                if (p2) { if (sp < full) { sp[kTraceBlock] = c2; sp += kTraceBlock; } else over = true; }
+                if (p3) { if (sp < full) { sp[kTraceBlock] = c3; sp += kTraceBlock; } else over = true; }
+                if (!any) { next = top; sp -= kTraceBlock; }
                 if (over) { res = 2u; next = kDone; }           /* needs more than the LDS stack: the tail kernel redoes this ray */
             }
             cur = next;
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                                                               uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
                                                               const uint2* __restrict__ lists, uint32_t listStride, Counters* stats,
                                                               unsigned long long* __restrict__ clk) {
-    __shared__ int32_t s_stack[(STACK + 1 + 3) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good; three guard entries above it (inner_nodes4) */
+    __shared__ int32_t s_stack[(STACK + 1) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                             vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                         } else {
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
-                            rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);      /* gb about the grid centre: the records' planes are offsets from it */
+                            rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);      /* gb about the scene's wide centre: the records' planes are offsets from it */
                             cur = 0; sp = lds; res = 0u;
                         }
                     }

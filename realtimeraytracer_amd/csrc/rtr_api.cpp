@@ -93,6 +93,7 @@ struct rtr_scene {
     DevBuf<uint4> nodes;                 /* RtrBvhNode, 2 x uint4 each */
     DevBuf<float4> nodesF;               /* rtr::BvhNodeF, 4 x float4 each: device build / refit only */
     DevBuf<RtrBvhGrid> grid;
+    DevBuf<unsigned long long> wideSums;     /* scratch of bvh_make_wide */
     DevBuf<uint4> nodes4tmp;             /* the 4-wide entries in BVH2-id order, before the breadth-first permutation */
     DevBuf<uint32_t> wideRemap;
     uint32_t wideReached = 0;            /* entries the 4-wide tree reaches (they come first in nodes4) */
@@ -393,9 +394,9 @@ static int make_light_tris(rtr_scene* s) {
 
 static int make_wide_nodes(rtr_scene* s) {
     const uint32_t n = (uint32_t)s->hostNodes.size();
-    if (!s->nodes4.p) { HIP_TRY(s->nodes4.alloc((size_t)n * 4)); HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); }
+    if (!s->nodes4.p) { HIP_TRY(s->nodes4.alloc((size_t)n * 4)); HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); HIP_TRY(s->wideSums.alloc(rtrdev::bvh_wide_scratch_words())); }
     hipStream_t st = s->ctx->stream;
-    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4tmp.p, st);
+    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4tmp.p, s->wideSums.p, st);
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node build: %s", hipGetErrorString(e));
     /* breadth-first order of the 4-wide tree (child codes = the 4th 16 bytes of every entry), so its top levels are the first
      * entries: k_shadow_trace4 keeps those in LDS.  Entries the 4-wide tree does not reach keep the ids after them. */
@@ -416,6 +417,7 @@ static int make_wide_nodes(rtr_scene* s) {
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node order: %s", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(st));
     s->wideReached = (uint32_t)order.size();
+    HIP_TRY(hipMemcpy(&s->stats.grid, s->grid.p, sizeof(RtrBvhGrid), hipMemcpyDeviceToHost));     /* the wide centre was set on the device */
     s->stats.numWideNodes = s->wideReached; s->stats.wideLayoutVersion = RTR_WIDE_LAYOUT_VERSION;
     return RTR_OK;
 }
