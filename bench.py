@@ -401,7 +401,7 @@ def main():
                 # the ceiling that binds: one SIMD issues one vector instruction at a time; SQ_ACTIVE_INST_VALU counts, in units of 4
                 # cycles, the time SIMDs spent issuing them
                 "bound": "valu_issue",
-                "kernel": "k_shadow_trace4<13, true, false>: any-hit traversal of the shadow-ray queue, revision " + rev,
+                "kernel": "k_shadow_trace4<16, true, false>: any-hit traversal of the shadow-ray queue, revision " + rev,
                 "achieved": round(busy, 1) if busy else None, "peak": round(launch_cycles, 1) if launch_cycles else None,
                 "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch)",
                 "frac": round(busy / launch_cycles, 4) if (busy and launch_cycles) else None,

@@ -7,7 +7,7 @@ import sys
 
 src, key, rev, rays = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 pmc = json.load(open(src))
-name = [k for k in pmc if "k_shadow_trace4<13, true, false>" in k or "k_shadow_trace4<13, false, false>" in k]
+name = [k for k in pmc if "k_shadow_trace4<16, true, false>" in k or "k_shadow_trace4<16, false, false>" in k]
 k = pmc[name[0]]
 queue_bytes = rays * 32                          # the ray queue: a wide coalesced stream, which FETCH_SIZE tallies at 1/2 (guide; calibrated in profiles/r01/fetch_calibration.txt)
 fetch_kb, write_kb = k["FETCH_SIZE"], k["WRITE_SIZE"]
