@@ -1029,8 +1029,18 @@ __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const fl
 /* ---- wavefront stage 4: resolve (shade with looked-up visibility, tonemap, store) ------------- */
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs ra, FrameOut fo, const float4* hitTuvp,
-                                                    const uint32_t* hitCustom, const uint8_t* vis, Counters* stats) {
-    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+                                                    const uint32_t* hitCustom, const uint8_t* vis, Counters* stats, uint32_t rowWaves) {
+    /* which pixel slot this lane resolves.  Upstream a wave is one 8x8 tile (slot q = tile * 64 + row-in-tile * 8 + column-in-tile).
+     * rowWaves (set when the tile rows are whole groups of eight tiles): a pair of workgroups takes eight tiles side by side, and a
+     * wave is one 64-pixel ROW of them, so every image store of a wave is one contiguous 256-B run of a framebuffer row (and 1 KiB
+     * of the float HDR buffer) instead of eight 32-B pieces; its hit-record loads are eight 128-B runs instead of one 1-KiB run.
+     * Off by default (RTR_RESOLVE_ROW_WAVES=1 turns it on): the stores are 8 MB of a frame's traffic, while a 64x1 strip shades less
+     * coherently than an 8x8 tile — 0.246 -> 0.274 ms, 11.61 -> 11.47 G rays/s (profiles/r02/resolve_row_waves.log). */
+    uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (rowWaves) {
+        const uint32_t row = (threadIdx.x >> 6) + 4u * (blockIdx.x & 1u), col = threadIdx.x & 63u;
+        q = (blockIdx.x >> 1) * (2u * kBlock) + (col >> 3) * 64u + row * 8u + (col & 7u);
+    }
     uint32_t px, lrow, py;
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
@@ -1188,8 +1198,10 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
     else hipLaunchKernelGGL((k_shadow_tail<false>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
     if (ev) hipEventRecord(ev[3], s);
-    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
-    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats);
+    static const uint32_t kRowWaves = env_u32("RTR_RESOLVE_ROW_WAVES", 0u, 0u, 1u);
+    const uint32_t rowWaves = (kRowWaves && ra.tilesPerRow % 8u == 0u && blocks % 2u == 0u) ? 1u : 0u;
+    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats, rowWaves);
+    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats, rowWaves);
     if (ev) hipEventRecord(ev[4], s);
     return hipGetLastError();
 }
