@@ -410,6 +410,8 @@ def main():
                                          if kern_iso else "HIP events on the launch stream over the timed region"),
                 "in_flight_event_bracket_ms": round(bracket_ms, 4) if kern_iso else None,
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
+                # the same stamps from the timed region, where four frames share the GPU: the clock the chip sustains under that load
+                "clock_mhz_in_flight": round(sorted(clocks)[len(clocks) // 2], 1) if clocks else None,
                 "clock_source": "s_memtime / s_memrealtime stamps around the launch's persistent loop (lane 0 of the first workgroup of each XCD, median), same launches as avg_launch_ms",
                 "simds": num_simds,
                 "valu_wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]) if pmc else None,

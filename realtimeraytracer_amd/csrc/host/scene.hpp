@@ -278,12 +278,16 @@ struct SceneInfo : RtrSceneInfo {                                   // scene_inf
 
 namespace std {
 template <>
-struct hash<scene::geometry::Vertex> {                              // vertex.cppm:29-52
+struct hash<scene::geometry::Vertex> {                              // the de-duplication key of vertex.cppm:29-52 (any hash will do)
     size_t operator()(const scene::geometry::Vertex& v) const noexcept {
+        // FNV-1a over the bit patterns of the eight floats (-0.0 folded onto 0.0 so that equal vertices hash alike)
         const float f[8] = {v.position.x, v.position.y, v.position.z, v.normal.x, v.normal.y, v.normal.z, v.uv.x, v.uv.y};
-        size_t seed = std::hash<float>{}(f[0]);
-        for (int i = 1; i < 8; ++i) seed ^= std::hash<float>{}(f[i]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-        return seed;
+        uint64_t h = 1469598103934665603ull;
+        for (float x : f) {
+            uint32_t bits; const float y = x == 0.0f ? 0.0f : x; std::memcpy(&bits, &y, sizeof bits);
+            for (int b = 0; b < 4; ++b) { h ^= (bits >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
+        }
+        return (size_t)h;
     }
 };
 }  // namespace std
