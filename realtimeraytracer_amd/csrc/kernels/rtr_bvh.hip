@@ -413,7 +413,7 @@ __global__ void k_wide_centre_set(const unsigned long long* __restrict__ w, RtrB
 /* 4-wide view of the tree for the any-hit kernel (rtr_kernels.hip, k_shadow_trace4): entry n starts from the two children of
  * BVH2 node n and, while a slot is free, opens the inner entry with the largest box into its own two children; boxes are
  * copied from the BVH2 nodes that own them and child codes keep BVH2 node ids, so entry 0 roots a complete 4-wide tree.
- * Word layout (16 words = RtrWideNode): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16) as half floats about the grid centre,
+ * Word layout (16 words = RtrWideNode): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16) as half floats about the scene's wide centre (RtrBvhGrid::wideCentreXY / Z),
  * then the four child codes; an empty slot has the code 0x80000000 and an inside-out infinite box. */
 __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
                                                    const RtrBvhGrid* __restrict__ grid, uint4* __restrict__ wide) {

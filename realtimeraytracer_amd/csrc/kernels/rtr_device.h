@@ -186,7 +186,7 @@ __device__ __forceinline__ bool slab_oct<8>(uint32_t wmin, uint32_t wmax, uint32
 
 /* Slab test of one slot of an RtrWideNode: the same three words, but the planes are HALF FLOATS — offsets from the centre of the scene
  * grid in grid steps, rounded outward when the record was made — so t = fma(plane, ga, gbc) is one v_fma_mix_f32 per plane with no
- * conversion (gbc: gb taken about the grid centre, rtr_ray_grid_centre).  OCT as in slab_oct. */
+ * conversion (gbc: gb taken about the scene's wide centre, rtr_ray_grid_centre).  OCT as in slab_oct. */
 template <int OCT>
 __device__ __forceinline__ bool slab_wide(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gbc, float tmin, float tmax, float& t_entry) {
     typedef _Float16 rtr_h2 __attribute__((ext_vector_type(2)));

@@ -6,17 +6,20 @@
  * Two pipelines over the same device functions (rtr_device.h):
  *   megakernel : one lane per pixel does everything (simple, divergent) — the first-slice path
  *                and the fallback when the wavefront scratch would be too large.
- *   wavefront  : k_primary -> k_shadow_gen -> k_shadow_trace -> k_resolve.  The shadow rays of all
- *                pixels are compacted into one dense queue with a wave-level ballot
- *                (mbcnt prefix + one atomic per wave), so the any-hit traversal kernel runs with full
- *                waves of coherent rays instead of idling lanes inside the shading loops.
+ *   wavefront  : k_primary (+ tail) -> k_shadow_gen[_oct] -> k_shadow_trace4 (+ k_shadow_tail) -> k_resolve.  The shadow rays
+ *                of all pixels are compacted into one dense queue with a wave-level ballot (mbcnt prefix + one atomic per
+ *                workgroup), binned by direction octant for long queues, and drained by persistent waves that refill their
+ *                idle lanes by ballot — so the any-hit traversal runs with full waves of coherent rays instead of idling
+ *                lanes inside the shading loops.  Camera rays walk the BVH2 (RtrBvhNode), shadow rays the 4-wide view of the
+ *                same tree (RtrWideNode).
  *
  * Launch shape: 256-thread workgroups (4 waves), one 8x8 pixel tile per wave in the canonical
  * tile order of rtr_device.h; grids are >> 256 workgroups at 1080p (8100 for the per-pixel
  * kernels) so all 8 XCDs fill; consecutive workgroups (round-robin over XCDs) take consecutive
  * tiles, so each XCD's L2 sees an interleaved slice of every band and the top of the BVH is
  * resident in all eight L2s.
- * No MFMA: the path is pointer-chasing + divergence bound (BASELINE.json north_star).
+ * No MFMA: the path is pointer-chasing + divergence bound (BASELINE.json north_star); what binds the dominant kernel is vector-
+ * instruction issue with the L1's tag look-ups right behind.
  */
 #include "rtr_kernels.h"
 
