@@ -20,8 +20,10 @@ reach the fabric), so the block reports the ceiling that binds — SIMD issue cy
 of the launch, with the launch duration (HIP events on the launch stream) and the shader clock (s_memtime
 over s_memrealtime stamps inside the launch) measured live, lane utilisation from the kernel's counting
 form run in this process, and the counter totals of the committed rocprofv3 passes of the same command
-(profiles/r02/pmc_roofline.json, tagged with the kernel revision) — and, beside it, the HBM and L2
-fractions and the algorithmic byte rate.  `cpu_baseline` is the CPU oracle (a scalar C++ port, oracle/)
+(profiles/r02/pmc_roofline.json, tagged with the kernel revision) — and, beside it, the second unit that is
+nearly full (L1 tag look-ups per L1 per clock), the HBM and L2 fractions and the algorithmic byte rate.
+`presented_frame` (N = 1) times the frame the reference presents: five images at 4 spp with the shipped LTC
+tables, four a-trous rounds, combine.  `cpu_baseline` is the CPU oracle (a scalar C++ port, oracle/)
 timed on the host cores on a bounded sample of the same workload — reported, not a target.
 """
 import argparse
