@@ -1,0 +1,59 @@
+"""bench.py is what the driver runs: its one JSON line must keep the contract (metric / value / roofline / cpu_baseline ...), the
+presented-frame object, the real-asset option and the N > 1 code path (one rank through librtr_mgpu.so and real RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from realtimeraytracer_amd import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, env=None, timeout=600):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_line_keeps_the_contract(scene_cache):
+    d = _bench(["--steps", "12", "--warmup", "2", "--width", "640", "--height", "360", "--present-frames", "2", "--verify"],
+               env={"RTR_SCENE_CACHE": str(scene_cache)})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "presented_frame"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 100 and abs(d["ms_per_step"] * d["value"] * 1e3 / d["config"]["rays_per_frame"] - 1.0) < 0.02
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "clock_mhz", "lane_util", "per_ray", "kernel"):
+        assert k in r, k
+    assert r["bound"] == "valu_issue" and r["avg_launch_ms"] > 0 and 1500 < r["clock_mhz"] < 2600
+    assert r["frac"] is None or 0 < r["frac"] <= 1.0          # counters are committed for the default workload only (pmc_note says so otherwise)
+    assert 0 < r["lane_util"]["node_loop"] <= 1 and 0 < r["lane_util"]["triangle_loop"] <= 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"] and c["single_thread"]["cores"] == 1
+    assert d["verify"]["pixels_differing_vs_oracle"] == 0
+    p = d["presented_frame"]
+    assert p["spp"] == 4 and p["images"] == 5 and p["denoise_iterations"] == 4 and p["ms_per_frame"] > 0
+
+
+def test_bench_renders_a_real_asset(scene_cache):
+    obj, _ = scenes.write_cornell(scene_cache)
+    d = _bench(["--obj", obj, "--obj-view", "0.0,0.0,-1.9", "--steps", "6", "--warmup", "2", "--width", "320", "--height", "184", "--no-cpu-baseline", "--isolated-frames", "2"])
+    assert d["data"].startswith("file ") and d["config"]["workload"].startswith("obj:") and d["value"] > 0
+    assert d["config"]["primary_rays_per_frame"] == 320 * 184 and d["config"]["rays_per_frame"] > 320 * 184       # something was hit and lit
+
+
+def test_bench_multi_rank_path_with_one_rank_through_rccl(scene_cache):
+    d = _bench(["--steps", "10", "--warmup", "2", "--width", "640", "--height", "360", "--isolated-frames", "2"],
+               env={"RTR_BENCH_FORCE_DIST": "1", "RTR_SCENE_CACHE": str(scene_cache), "MASTER_PORT": "29577"})
+    assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0 and "librtr_mgpu.so" in d["verify"]["gather"]
+    assert d["cpu_baseline"] is None and d["presented_frame"] is None and d["value"] > 0
