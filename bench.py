@@ -9,8 +9,12 @@ band-sharded over the ranks (strong scaling), gathered to rank 0 with one RCCL g
 de-interleaved there; all of that is inside the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # N > 1, started plainly: ONE process drives the N devices through
+                                                           # librtr_mgpu.so (rtr_mgpu_create: ncclCommInitAll, a host thread per rank)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # one process per GPU (rtr_mgpu_create_rank), as the driver launches it
+    python bench.py --gpus N --launcher torchrun           # the same, with bench.py starting torch.distributed.run itself as a child
+    python bench.py --gpus N --print-launch                # only say how this invocation would run (no GPU touched)
 
 Rank 0 prints ONE JSON line.  `value` = all rays traced per second (primary + shadow, exact count
 from the kernels' own counters in an untimed stats pass), whole job.  `roofline` is for the dominant
@@ -39,6 +43,183 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0   # same guide: measured streaming copy (SURVEY 8d asks for the fraction of this as well)
 L2_PEAK_GBS = 34500.0    # same guide: L2 aggregate, 8 XCDs
+
+
+def default_frames_in_flight(n_gpus):
+    """Frames kept in flight per rank.  4 fills one MI355X with whole frames (flat from 2 to 8); a 1/4 or 1/8 shard is too small for
+    any of its kernels to fill the GPU, and eight of them on eight hardware queues do better than four on four
+    (profiles/r01/sweep_hw_queues_one_rank_of_8.log: 0.398 against 0.421 ms per frame for one rank of 8)."""
+    return 8 if n_gpus >= 4 else 4
+
+
+def launch_plan(args, env, argv):
+    """How this invocation runs — decided before torch or any HIP library is imported, testable without a GPU (--print-launch).
+    mode: 'single' (N = 1), 'rank' (this process is one rank of a torch.distributed.run job), 'inproc' (N > 1 started plainly: one
+    process drives the N devices through librtr_mgpu.so), 'torchrun-child' (N > 1 started plainly with --launcher torchrun)."""
+    n = args.gpus
+    fif = args.frames_in_flight or default_frames_in_flight(n)
+    # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 8 frames in flight every frame's stream gets its own
+    env_defaults = {"GPU_MAX_HW_QUEUES": "8"} if fif >= 8 else {}
+    base = {"n_gpus": n, "frames_in_flight": fif, "env_defaults": env_defaults}
+    if n < 1:
+        return dict(base, mode="error", why=f"--gpus {n}")
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != n:
+            return dict(base, mode="error", why=f"--gpus {n} but WORLD_SIZE={ws}: under torch.distributed.run start one process per GPU (--nproc-per-node {n})")
+        return dict(base, mode="rank" if n > 1 else "single", world=n, library_entry="rtr_mgpu_create_rank" if n > 1 else None)
+    if n == 1 and env.get("RTR_BENCH_FORCE_INPROC") != "1":     # (forced: a one-GPU rehearsal of the in-process N > 1 path, one rank through real RCCL)
+        return dict(base, mode="single", world=1, library_entry=None)
+    if args.launcher == "torchrun" and n > 1:
+        child = [a for a in argv if a not in ("--print-launch",)]
+        for i, a in enumerate(child):               # the child must not start a grandchild
+            if a == "--launcher":
+                del child[i:i + 2]
+                break
+        child = [a for a in child if not a.startswith("--launcher=")]
+        port = env.get("MASTER_PORT")
+        if not port:                                # a free port for the rendezvous on 127.0.0.1
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = str(so.getsockname()[1])
+        return dict(base, mode="torchrun-child", world=n, library_entry="rtr_mgpu_create_rank",
+                    argv=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                          "--master-port", port, os.path.join(ROOT, "bench.py")] + child)
+    return dict(base, mode="inproc", world=n, library_entry="rtr_mgpu_create", devices=list(range(n)))
+
+
+def build_setup(args, scenes, np):
+    """the workload: a procedural BASELINE scene, or a real asset (--obj)"""
+    W, H = args.width, args.height
+    if args.obj:
+        vs = np.array([[float(t) for t in ln.split()[1:4]] for ln in open(args.obj, errors="replace") if ln.startswith("v ")], dtype=np.float64)
+        if len(vs) == 0:
+            raise SystemExit(f"bench.py: {args.obj} has no vertices")
+        lo, hi = vs.min(0), vs.max(0)
+        c, e = (lo + hi) / 2, np.maximum(hi - lo, 1e-6)
+        view = np.array([float(t) for t in args.obj_view.split(",")])
+        cam = tuple(float(x) for x in (c + view * e))
+        side = float(0.25 * max(e[0], e[2]))
+        light = (12.0, (1.0, 0.95, 0.9), (float(c[0]), float(hi[1] - 0.02 * e[1]), float(c[2])), (side, side, 1.0), (90.0, 0.0, 0.0))
+        setup = scenes.custom_obj(args.obj, os.path.dirname(os.path.abspath(args.obj)), cam, tuple(float(x) for x in c), fov_y=60.0, width=W, height=H, lights=[light])
+        args.workload = "obj:" + os.path.basename(args.obj)
+        return setup
+    return getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
+
+
+def run_inproc(args, K, plan):
+    """N > 1 from ONE process: what a C++ application would do with include/rtr_mgpu.h.  rtr_mgpu_create makes the communicator
+    (ncclCommInitAll) and a host thread per rank; every step enqueues the frame's N shards, the grouped send / recv to rank 0 on the
+    communication streams and k_deinterleave, into one of the frame slots; the timed region is bracketed by a join of every slot of
+    every rank and a device synchronise of every GPU, on one clock."""
+    import numpy as np
+    import torch
+
+    from realtimeraytracer_amd import _abi as A
+    from realtimeraytracer_amd import api, mgpu, scenes
+
+    N, W, H, S = args.gpus, args.width, args.height, args.spp
+    os.environ.setdefault("RTR_SCENE_CACHE", os.path.join("/tmp", "rtr_scene_cache_rank0"))
+    nbuf = plan["frames_in_flight"]
+    # the library says what is wrong when the devices are not there ("8 devices requested, 1 present"): no check of our own before it
+    try:
+        mg = mgpu.MultiGpu(devices=plan["devices"], frames_in_flight=nbuf)
+    except RuntimeError as e:
+        raise SystemExit(f"bench.py: {e}")
+    setup = build_setup(args, scenes, np)
+    mg.scene_create(setup.desc)
+    images = A.IMAGES_FRAMEBUFFER | (A.IMG_BIT(A.IMAGE_HDR) if K > 1 else 0)
+
+    def params(collect=0, shard_index=0, shard_count=1, j=0):
+        return api.make_params(W, H, spp=S, shadow_rays=args.shadow_rays, images=images, band_rows=args.band_rows, shard_index=shard_index,
+                               shard_count=shard_count, accumulate=1 if j > 0 else 0, accumulated_frames=j, collect_stats=collect, pipeline=args.pipeline)
+
+    # untimed: exact ray counts of the whole frame (they do not depend on how the frame is cut), on device 0 with a scene of its own
+    ctx = api.Context(0)
+    scene = api.Scene(ctx, setup.desc)
+    sstats = scene.stats()
+    whole = api.Frame(ctx, W, H, images)
+    api.render(scene, setup.camera, setup.scene_info(0), params(collect=1), whole)
+    fs = whole.stats()
+    rays_per_frame, primary_per_frame = int(fs.numRays) * K, int(fs.numPrimaryRays) * K
+
+    p_run = [params(0, j=j) for j in range(K)]
+    kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
+    inflight = [False] * nbuf
+
+    def collect(b):
+        if not inflight[b]:
+            return
+        mg.wait(b)
+        inflight[b] = False
+        st = mg.frame_stats(b, 0)
+        kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
+        kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
+
+    def step(i):
+        b = i % nbuf
+        collect(b)                                      # frame i - nbuf: done long ago unless the host runs ahead
+        for j in range(K):
+            mg.render_async(b, setup.camera, setup.scene_info(j if K > 1 else i), p_run[j], exchange=(j == K - 1))
+        inflight[b] = True
+
+    def drain():
+        for b in range(nbuf):
+            collect(b)
+
+    def sync_all():
+        for d in plan["devices"]:
+            torch.cuda.synchronize(d)
+
+    for b in range(nbuf):                               # set-up, not warm-up: every slot allocates on its first render
+        step(b)
+    drain()
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    kern.update({k: 0.0 for k in kern}); kern["n"] = 0
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    drain()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    # the assembled frame of the last step against the same frame rendered unsharded on device 0
+    last_i = args.warmup + args.steps - 1
+    for j in range(K):
+        api.render(scene, setup.camera, setup.scene_info(j if K > 1 else last_i), params(0, j=j), whole)
+    bad = int((mg.download(last_i % nbuf) != whole.download()).sum())
+    info = mg.info
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    n = max(kern["n"], 1)
+    out = {
+        "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S, K) == (1920, 1080, 1, 1) else f"Mrays/sec at {W}x{H} {S}spp" + (f" x{K} frames accumulated in HDR" if K > 1 else ""),
+        "value": round(rays_per_frame * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / K, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("file " + args.obj) if args.obj else "synthetic",
+        "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
+                               f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{N}",
+                   "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame, "pipeline": "wavefront" if fs.pipelineUsed == 2 else "megakernel",
+                   "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries), "build_ms": round(float(sstats.buildMs), 1)}},
+        "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
+        "frames_in_flight": nbuf,
+        "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
+        "kernels_scope": "rank 0's shard; HIP-event brackets with the other frames' kernels sharing the GPU",
+        # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
+        "rccl": {"nranks": int(info.nranks), "nlocal": int(info.nlocal), "version": int(info.rcclVersion), "launch": "one process, rtr_mgpu_create (ncclCommInitAll, a host thread per rank)",
+                 "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
+                 "env": plan["env_defaults"]},
+        "verify": {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i},
+        "roofline": None, "roofline_note": "the roofline block is reported for the one-GPU run of the same workload (N = 1 line)",
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+    mg.close()
+    if bad:
+        raise SystemExit(f"bench.py: {bad} pixels of the assembled frame differ from the unsharded frame")
 
 
 def main():
@@ -79,6 +260,12 @@ def main():
                          "an OBJ file with its MTL / textures beside it; the camera looks at the centre of its bounds from --obj-view, one area light "
                          "hangs under the top of the bounds")
     ap.add_argument("--obj-view", default="-0.45,0.15,0.05", help="camera position as fractions of the bounds' extent from the centre (x,y,z)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "inproc", "torchrun"],
+                    help="how an N > 1 run that was started plainly (no WORLD_SIZE in the environment) gets its ranks: 'inproc' (= auto) "
+                         "drives all N devices from this process through rtr_mgpu_create; 'torchrun' starts "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, before this process has "
+                         "touched the GPU, and relays its JSON line and return code")
+    ap.add_argument("--print-launch", action="store_true", help="print, as one JSON line, how this invocation would be run, and exit")
     args = ap.parse_args()
 
     if args.config == 1:
@@ -93,10 +280,23 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run (see docstring)")
+    plan = launch_plan(args, os.environ, sys.argv[1:])
+    if args.print_launch:
+        print(json.dumps(plan), flush=True)
+        return
+    if plan["mode"] == "error":
+        raise SystemExit("bench.py: " + plan["why"])
+    for k, v in plan["env_defaults"].items():          # before any HIP library is loaded
+        os.environ.setdefault(k, v)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if plan["mode"] == "torchrun-child":
+        # nothing in this process has touched the GPU (torch is not even imported yet): start the ranks as a child, relay
+        import subprocess
+        r = subprocess.run(plan["argv"], cwd=ROOT)
+        raise SystemExit(r.returncode)
+    if plan["mode"] == "inproc":
+        return run_inproc(args, K, plan)
+    world = plan["world"]
     os.environ.setdefault("RTR_SCENE_CACHE", os.path.join("/tmp", f"rtr_scene_cache_rank{rank}"))
 
     import numpy as np
@@ -124,20 +324,7 @@ def main():
             dist.init_process_group(backend="gloo")
 
     W, H, S = args.width, args.height, args.spp
-    if args.obj:
-        vs = np.array([[float(t) for t in ln.split()[1:4]] for ln in open(args.obj, errors="replace") if ln.startswith("v ")], dtype=np.float64)
-        if len(vs) == 0:
-            raise SystemExit(f"bench.py: {args.obj} has no vertices")
-        lo, hi = vs.min(0), vs.max(0)
-        c, e = (lo + hi) / 2, np.maximum(hi - lo, 1e-6)
-        view = np.array([float(t) for t in args.obj_view.split(",")])
-        cam = tuple(float(x) for x in (c + view * e))
-        side = float(0.25 * max(e[0], e[2]))
-        light = (12.0, (1.0, 0.95, 0.9), (float(c[0]), float(hi[1] - 0.02 * e[1]), float(c[2])), (side, side, 1.0), (90.0, 0.0, 0.0))
-        setup = scenes.custom_obj(args.obj, os.path.dirname(os.path.abspath(args.obj)), cam, tuple(float(x) for x in c), fov_y=60.0, width=W, height=H, lights=[light])
-        args.workload = "obj:" + os.path.basename(args.obj)
-    else:
-        setup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
+    setup = build_setup(args, scenes, np)
     emu = args.emulate_rank_of if (world == 1 and args.emulate_rank_of > 1) else 0
     nshards = emu if emu else world
     # Several frames are kept in flight on separate streams (one context each, ONE shared scene): the tails of one
@@ -146,7 +333,7 @@ def main():
     # 1/8-frame shard no single kernel can fill the GPU (259 k primary rays for 524 k lane slots), so it is where the
     # strong scaling comes from (one rank of 8: 0.82 -> 0.44 ms per frame).  Frames are independent, so results are
     # unchanged.  Per-kernel durations are taken from a one-frame-at-a-time pass after the timed region (see below).
-    nbuf = args.frames_in_flight or 4
+    nbuf = plan["frames_in_flight"]
     ctxs = [api.Context(local_rank) for _ in range(nbuf)]
     streams = [torch.cuda.Stream(device=device) for _ in range(nbuf)]
     for c, st_ in zip(ctxs, streams):
@@ -517,6 +704,11 @@ def main():
         bad = int((assembled != whole.download()).sum())
         out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i,
                          "gather": "librtr_mgpu.so: grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave" if use_lib else "torch.distributed gather (rehearsal backend)"}
+        if use_lib:
+            out["rccl"] = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion),
+                           "launch": "one process per GPU under torch.distributed.run, rtr_mgpu_create_rank (ncclCommInitRank; the id travels through a broadcast)",
+                           "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
+                           "env": plan["env_defaults"]}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -122,7 +122,7 @@ typedef struct rtr_scene_stats {
     float    boxPad;
     float    _pad;
     RtrBvhGrid grid;          /* the 16-bit planes of the exported nodes live on this grid (rewritten by a refit) */
-    uint32_t numWideNodes;    /* RtrWideNode records of the wide view (rtr_scene_export_wide); 0 from rtr_host_build_bvh */
+    uint32_t numWideNodes;    /* RtrWideNode records of the wide view (rtr_scene_export_wide, rtr_host_build_bvh_wide); 0 from rtr_host_build_bvh */
     uint32_t wideLayoutVersion;
     uint32_t _pad2[2];
 } rtr_scene_stats;
@@ -199,6 +199,12 @@ int  rtr_ctx_device_name(rtr_ctx* ctx, char* buf, size_t bytes);
 /* replaces createSceneFromObjectsAndLights' GPU half (src/app/setup/create_scene.cppm:48-160):
  * validates, flattens instances to world space, builds the BVH on the host, uploads. */
 int  rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* desc, rtr_scene** out);
+/* The same scene once more — on another context, usually another device — WITHOUT building its tree again: `built` is a scene
+ * made from the same `desc` (same arrays, same buildFlags) whose host-side copy of the tree is uploaded as it is.  What
+ * librtr_mgpu.so replicates the scene with: one build per node instead of one per GPU.  The reference builds its acceleration
+ * structure once, on its one device (src/vulkan/raytracing/blas.cppm:75-167); this is that build shared by N devices.
+ * RTR_ERR_INVALID_ARGUMENT if `built` does not match `desc` (triangle count). */
+int  rtr_scene_create_like(rtr_ctx* ctx, const rtr_scene_desc* desc, const rtr_scene* built, rtr_scene** out);
 void rtr_scene_destroy(rtr_scene* scene);
 int  rtr_scene_get_stats(const rtr_scene* scene, rtr_scene_stats* out);
 /* Copy out the device BVH arrays (test / oracle hook; sizes and the plane grid from rtr_scene_get_stats). */
@@ -213,6 +219,13 @@ int  rtr_scene_export_wide(const rtr_scene* scene, RtrWideNode* nodes, size_t no
  * in `stats`.  Used by the CPU-side tests (BVH invariants, oracle BVH-vs-brute-force). */
 int  rtr_host_build_bvh(const rtr_scene_desc* desc, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes,
                         RtrBvhTri* tris, size_t triBytes);
+/* The same build, plus the 4-wide view rtr_scene_create would put on the device for it: the host restatement of the kernels that
+ * make it (the wide centre, the records the builder's cost-driven collapse chose, breadth-first order) — byte-identical to
+ * rtr_scene_export_wide of a scene made from `desc` (checked in the GPU tests).  stats->numWideNodes / wideLayoutVersion and the
+ * wide centre in stats->grid are filled; call with all arrays NULL for the counts.  No device needed: CPU-only tests walk the wide
+ * view with the oracle, and tree experiments price a builder change by the oracle's visit counters before any GPU time is spent. */
+int  rtr_host_build_bvh_wide(const rtr_scene_desc* desc, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes,
+                             RtrBvhTri* tris, size_t triBytes, RtrWideNode* wide, size_t wideBytes);
 /* Limits of the 32-bit record offsets the traversal kernels use: RTR_OK if a scene of numTriangles triangles and numNodes BVH nodes
  * can be addressed (triangle records and 4-wide records each below 2 GiB: at most 44 739 242 triangles, 33 554 431 nodes; and the
  * 2^28 of the leaf encoding), else RTR_ERR_INVALID_ARGUMENT with the reason in rtr_last_error().  rtr_scene_create applies it

@@ -73,9 +73,63 @@ typedef struct rtr_mgpu_info {
     int firstRank;       /* rank of local rank 0 */
     int framesInFlight;
     int selfExchange;    /* 1: a one-rank communicator still sends its shard to itself through RCCL (RTR_MGPU_SELF_EXCHANGE=1; test hook) */
-    int _pad[3];
+    int aborted;         /* 1: a rank failed after the exchange was posted or the watchdog fired; the communicators were aborted */
+    int rcclVersion;     /* ncclGetVersion of the library that is actually loaded */
+    int timeoutMs;
 } rtr_mgpu_info;
 int  rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out);
+
+/* ---- The exchange, as data ------------------------------------------------------------------------------------------------------
+ * What one rank does for one frame slot, in stream order, as a list of operations.  rtr_mgpu_render_async() EXECUTES this list
+ * (csrc/mgpu/rtr_mgpu.cpp: enqueue() is a switch over it) — it is not a description kept beside the code — so the byte offsets,
+ * lengths, peers and event edges of the N > 1 exchange can be checked for every rank of every communicator size without a GPU
+ * (tests/test_mgpu_plan.py), and a multi-process CPU test can carry the same list out over another transport
+ * (tests/test_distributed.py runs it over gloo send / recv with the oracle's shards).  Needs no device, no communicator.
+ *
+ *   stream   which of the rank's two streams the operation is enqueued on
+ *   peer     RECV: the rank the bytes come from; SEND: the rank they go to; RENDER: shardIndex (= rank); others -1
+ *   offset   RENDER: byte offset of the render target inside buffer `buffer`;  RECV: byte offset in the gather buffer the shard
+ *            lands at (= shardBytes * peer);  SEND: byte offset in the local shard (0)
+ *   bytes    RENDER / RECV / SEND: shardBytes = rtr_shard_rows(height, bandRows, nranks) * width * 4;
+ *            DEINTERLEAVE: width * height * 4 (the assembled frame)
+ *   buffer   which buffer offset / bytes refer to
+ *   event    WAIT / RECORD: which of the slot's two events */
+typedef enum rtr_mgpu_op_kind {
+    RTR_MGPU_OP_WAIT = 1,          /* stream waits for `event` (skipped the first time a slot is used: nothing to wait for) */
+    RTR_MGPU_OP_RENDER = 2,        /* rtr_render_async of shard `peer` of nranks into `buffer` + `offset` */
+    RTR_MGPU_OP_RECORD = 3,        /* record `event` on `stream` */
+    RTR_MGPU_OP_GROUP_START = 4,   /* ncclGroupStart */
+    RTR_MGPU_OP_RECV = 5,          /* ncclRecv(gather + offset, bytes, from peer) */
+    RTR_MGPU_OP_SEND = 6,          /* ncclSend(local + offset, bytes, to peer) */
+    RTR_MGPU_OP_GROUP_END = 7,     /* ncclGroupEnd */
+    RTR_MGPU_OP_DEINTERLEAVE = 8   /* rank 0: gather buffer (nranks shards) -> assembled frame (k_deinterleave) */
+} rtr_mgpu_op_kind;
+typedef enum rtr_mgpu_stream { RTR_MGPU_STREAM_RENDER = 0, RTR_MGPU_STREAM_COMM = 1 } rtr_mgpu_stream;
+typedef enum rtr_mgpu_buffer { RTR_MGPU_BUF_NONE = 0, RTR_MGPU_BUF_LOCAL = 1, RTR_MGPU_BUF_GATHER = 2, RTR_MGPU_BUF_SELF_SRC = 3, RTR_MGPU_BUF_FULL = 4 } rtr_mgpu_buffer;
+typedef enum rtr_mgpu_event { RTR_MGPU_EV_NONE = 0, RTR_MGPU_EV_RENDER_DONE = 1, RTR_MGPU_EV_COMM_DONE = 2 } rtr_mgpu_event;
+typedef struct rtr_mgpu_op {
+    int32_t  kind;       /* rtr_mgpu_op_kind */
+    int32_t  stream;     /* rtr_mgpu_stream */
+    int32_t  peer;
+    int32_t  buffer;     /* rtr_mgpu_buffer */
+    int32_t  event;      /* rtr_mgpu_event */
+    int32_t  _pad;
+    uint64_t offset;
+    uint64_t bytes;
+} rtr_mgpu_op;
+#define RTR_MGPU_PLAN_MAX_OPS 32     /* 8 + (nranks - 1) operations on rank 0; nranks <= RTR_MGPU_MAX_RANKS */
+#define RTR_MGPU_MAX_RANKS 16
+/* Fills ops[0 .. *numOps) for `rank` of `nranks`.  flags: RTR_MGPU_NO_EXCHANGE (render only); selfExchange != 0 with nranks == 1:
+ * the one rank sends its shard to itself through the communicator (test hook).  RTR_ERR_INVALID_ARGUMENT on a bad rank / extent or
+ * when maxOps is too small. */
+int  rtr_mgpu_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange,
+                   rtr_mgpu_op* ops, int maxOps, int* numOps);
+
+/* Watchdog of rtr_mgpu_wait: a slot whose exchange has not finished after this many milliseconds is given up — every local
+ * communicator is aborted (ncclCommAbort releases peers blocked in a send / recv that will never be matched), the handle refuses
+ * further renders and rtr_mgpu_wait returns RTR_ERR_HIP with the stage it was waiting in.  Default 120000, from the environment
+ * variable RTR_MGPU_TIMEOUT_MS at creation; 0 = wait for ever. */
+int  rtr_mgpu_set_timeout_ms(rtr_mgpu* m, uint32_t ms);
 
 const char* rtr_mgpu_last_error(void);
 

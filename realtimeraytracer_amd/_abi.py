@@ -133,11 +133,13 @@ RTR_SYMBOLS = {
     "rtr_ctx_get_stream": (C.c_int, [VP, P(VP)]),
     "rtr_ctx_device_name": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
     "rtr_scene_create": (C.c_int, [VP, P(rtr_scene_desc), P(VP)]),
+    "rtr_scene_create_like": (C.c_int, [VP, P(rtr_scene_desc), VP, P(VP)]),
     "rtr_scene_destroy": (None, [VP]),
     "rtr_scene_get_stats": (C.c_int, [VP, P(rtr_scene_stats)]),
     "rtr_scene_export_bvh": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_scene_export_wide": (C.c_int, [VP, VP, C.c_size_t]),
     "rtr_host_build_bvh": (C.c_int, [P(rtr_scene_desc), P(rtr_scene_stats), VP, C.c_size_t, VP, C.c_size_t]),
+    "rtr_host_build_bvh_wide": (C.c_int, [P(rtr_scene_desc), P(rtr_scene_stats), VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t]),
     "rtr_scene_update_lights": (C.c_int, [VP, P(RtrAreaLightInfo), u32]),
     "rtr_scene_update_instances": (C.c_int, [VP, P(RtrInstance), u32, P(RtrAreaLightInfo), u32]),
     "rtr_frame_create": (C.c_int, [VP, u32, u32, u32, P(VP)]),
@@ -203,7 +205,21 @@ RTRH_SYMBOLS = {
 
 class rtr_mgpu_info(C.Structure):
     _fields_ = [("nranks", C.c_int), ("nlocal", C.c_int), ("firstRank", C.c_int), ("framesInFlight", C.c_int),
-                ("selfExchange", C.c_int), ("_pad", C.c_int * 3)]
+                ("selfExchange", C.c_int), ("aborted", C.c_int), ("rcclVersion", C.c_int), ("timeoutMs", C.c_int)]
+
+
+class rtr_mgpu_op(C.Structure):
+    """one operation of rtr_mgpu_plan (include/rtr_mgpu.h)"""
+    _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("peer", C.c_int32), ("buffer", C.c_int32), ("event", C.c_int32),
+                ("_pad", C.c_int32), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+MGPU_OP_WAIT, MGPU_OP_RENDER, MGPU_OP_RECORD, MGPU_OP_GROUP_START, MGPU_OP_RECV, MGPU_OP_SEND, MGPU_OP_GROUP_END, MGPU_OP_DEINTERLEAVE = range(1, 9)
+MGPU_STREAM_RENDER, MGPU_STREAM_COMM = 0, 1
+MGPU_BUF_NONE, MGPU_BUF_LOCAL, MGPU_BUF_GATHER, MGPU_BUF_SELF_SRC, MGPU_BUF_FULL = range(5)
+MGPU_EV_NONE, MGPU_EV_RENDER_DONE, MGPU_EV_COMM_DONE = range(3)
+MGPU_PLAN_MAX_OPS = 32
+MGPU_MAX_RANKS = 16
 
 
 MGPU_ID_BYTES = 128
@@ -225,6 +241,8 @@ MGPU_SYMBOLS = {
     "rtr_mgpu_shard_download": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_size_t]),
     "rtr_mgpu_frame_stats": (C.c_int, [VP, C.c_int, C.c_int, P(rtr_frame_stats)]),
     "rtr_mgpu_get_info": (C.c_int, [VP, P(rtr_mgpu_info)]),
+    "rtr_mgpu_plan": (C.c_int, [C.c_int, C.c_int, u32, u32, u32, C.c_int, C.c_int, P(rtr_mgpu_op), C.c_int, P(C.c_int)]),
+    "rtr_mgpu_set_timeout_ms": (C.c_int, [VP, u32]),
     "rtr_mgpu_last_error": (C.c_char_p, []),
 }
 

@@ -50,13 +50,18 @@ class Context:
 class BvhExport(tuple):
     """(nodes, tris, grid) of rtr_scene_export_bvh, with the 4-wide view of rtr_scene_export_wide as .wide"""
     wide = None
+    stats = None
 
 
 class Scene:
-    def __init__(self, ctx, desc):
+    def __init__(self, ctx, desc, like=None):
+        """like: a Scene made from the same description whose tree is uploaded instead of built again (rtr_scene_create_like)"""
         self.ctx, self.lib = ctx, ctx.lib
         self.h = A.VP()
-        _check(self.lib.rtr_scene_create(ctx.h, C.byref(desc), C.byref(self.h)), "rtr_scene_create")
+        if like is None:
+            _check(self.lib.rtr_scene_create(ctx.h, C.byref(desc), C.byref(self.h)), "rtr_scene_create")
+        else:
+            _check(self.lib.rtr_scene_create_like(ctx.h, C.byref(desc), like.h, C.byref(self.h)), "rtr_scene_create_like")
 
     def stats(self):
         s = A.rtr_scene_stats()
@@ -181,3 +186,19 @@ def host_build_bvh(desc):
     tris = (A.RtrBvhTri * max(st.numTriangles, 1))()
     _check(lib.rtr_host_build_bvh(C.byref(desc), C.byref(st), nodes, C.sizeof(nodes), tris, C.sizeof(tris)), "rtr_host_build_bvh")
     return st, nodes, tris
+
+
+def host_build_bvh_wide(desc):
+    """rtr_host_build_bvh_wide: the build plus the 4-wide view the device would hold for it -> BvhExport (nodes, tris, grid) with
+    .wide and .stats; what the oracle needs to walk a shadow ray the way k_shadow_trace4 does, on a CPU-only box."""
+    lib = A.hip_lib()
+    st = A.rtr_scene_stats()
+    _check(lib.rtr_host_build_bvh_wide(C.byref(desc), C.byref(st), None, 0, None, 0, None, 0), "rtr_host_build_bvh_wide")
+    nodes = (A.RtrBvhNode * st.numNodes)()
+    tris = (A.RtrBvhTri * max(st.numTriangles, 1))()
+    wide = (A.RtrWideNode * st.numWideNodes)()
+    _check(lib.rtr_host_build_bvh_wide(C.byref(desc), C.byref(st), nodes, C.sizeof(nodes), tris, C.sizeof(tris), wide, C.sizeof(wide)), "rtr_host_build_bvh_wide")
+    out = BvhExport((nodes, tris, st.grid))
+    out.wide = wide
+    out.stats = st
+    return out

@@ -46,7 +46,8 @@ hipError_t bvh_refit(const BvhInputs& in, uint32_t numPrims, uint32_t numNodes, 
  * parentOrNull: the refit parent array (entries outside the tree are skipped) or null. */
 /* sets grid->wideCentreXY / Z (k_wide_centre_*; sums4 = bvh_wide_scratch_words() x u64 of scratch) and writes the 4-wide records about it */
 size_t bvh_wide_scratch_words();
-hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, RtrBvhGrid* grid, uint4* wide, unsigned long long* sums4, hipStream_t s);
+/* shapeOrNull: per BVH2 node, which entries its wide record opens (bvh_build.h collapse_wide); null = the greedy rule */
+hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, RtrBvhGrid* grid, const uint8_t* shapeOrNull, uint4* wide, unsigned long long* sums4, hipStream_t s);
 /* out[remap[i]] = in[i] with inner child codes renumbered through remap (a permutation of 0..numNodes-1, remap[0] == 0) */
 hipError_t bvh_permute_wide(const uint4* in, uint32_t numNodes, const uint32_t* remap, uint4* out, hipStream_t stream);
 

@@ -416,7 +416,7 @@ __global__ void k_wide_centre_set(const unsigned long long* __restrict__ w, RtrB
  * Word layout (16 words = RtrWideNode): per child (xmin|ymin<<16) (xmax|ymax<<16) (zmin|zmax<<16) as half floats about the scene's wide centre (RtrBvhGrid::wideCentreXY / Z),
  * then the four child codes; an empty slot has the code 0x80000000 and an inside-out infinite box. */
 __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint4* __restrict__ nodes, const int32_t* __restrict__ parent,
-                                                   const RtrBvhGrid* __restrict__ grid, uint4* __restrict__ wide) {
+                                                   const RtrBvhGrid* __restrict__ grid, const uint8_t* __restrict__ shape, uint4* __restrict__ wide) {
     const uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i >= numNodes) return;
     uint32_t o[16];
@@ -439,6 +439,20 @@ __global__ __launch_bounds__(kB) void k_wide_nodes(uint32_t numNodes, const uint
             const float dz = (float)((wz >> 16) - (wz & 0xffffu)) * sz;
             return dx * dy + dy * dz + dz * dx;
         };
+        if (shape) {
+            /* the host builder chose, by cost, which entries this record opens (bvh_build.cpp collapse_wide): open1 | open2 << 2,
+             * each the slot to open + 1 (0 = none); an open replaces the entry by its left child and appends its right child */
+            const uint32_t sh = shape[i];
+            for (int step = 0; step < 2; ++step) {
+                const uint32_t o = (sh >> (2 * step)) & 3u;
+                if (o == 0u || (int)o > k) break;
+                uint32_t wmin, wmax, wz; int32_t code;
+                words(own[o - 1u], side[o - 1u], wmin, wmax, wz, code);
+                if (code < 0 || (uint32_t)code >= numNodes) break;
+                own[o - 1u] = (uint32_t)code; side[o - 1u] = 0;
+                own[k] = (uint32_t)code; side[k] = 1; ++k;
+            }
+        } else
         while (k < 4) {
             int best = -1; float bestA = -1.0f; int32_t bestCode = 0;
             for (int j = 0; j < k; ++j) {
@@ -520,14 +534,14 @@ hipError_t bvh_build_lbvh(const BvhInputs& in, uint32_t numPrims, const BvhDevic
     return hipGetLastError();
 }
 
-hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, RtrBvhGrid* grid, uint4* wide, unsigned long long* sums4, hipStream_t s) {
+hipError_t bvh_make_wide(const uint4* nodes, uint32_t numNodes, const int32_t* parentOrNull, RtrBvhGrid* grid, const uint8_t* shapeOrNull, uint4* wide, unsigned long long* sums4, hipStream_t s) {
     BV_TRY(hipMemsetAsync(sums4, 0, kCentreWords * sizeof(unsigned long long), s));
     const dim3 gn((numNodes + kB - 1) / kB);
     hipLaunchKernelGGL(k_wide_centre_sum, gn, dim3(kB), 0, s, numNodes, nodes, parentOrNull, sums4);
     hipLaunchKernelGGL(k_wide_centre_candidates, dim3(1), dim3(1), 0, s, sums4);
     hipLaunchKernelGGL(k_wide_centre_cost, gn, dim3(kB), 0, s, numNodes, nodes, parentOrNull, sums4);
     hipLaunchKernelGGL(k_wide_centre_set, dim3(1), dim3(1), 0, s, sums4, grid);
-    hipLaunchKernelGGL(k_wide_nodes, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, nodes, parentOrNull, grid, wide);
+    hipLaunchKernelGGL(k_wide_nodes, dim3((numNodes + kB - 1) / kB), dim3(kB), 0, s, numNodes, nodes, parentOrNull, grid, shapeOrNull, wide);
     return hipGetLastError();
 }
 

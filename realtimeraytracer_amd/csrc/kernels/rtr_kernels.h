@@ -8,7 +8,7 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
-#define RTR_ANYHIT_KERNEL_REVISION "r02.5"
+#define RTR_ANYHIT_KERNEL_REVISION "r03.1"
 
 constexpr uint32_t kQueueRegions = 8;                       /* one batch cursor per XCD: eight times the atomic rate of one counter */
 constexpr uint32_t kQueueLists = kQueueRegions * kQueueRegions;        /* batch lists of the binned queue: (direction octant, consumer XCD) */

@@ -59,7 +59,12 @@ struct CountPolicy {
 struct EmitPolicy {
     static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;     /* keeps the access a ds_read/ds_write, not a flat_load */
-    float4* queue; lds_word waveOffset; uint32_t base; uint32_t slot;
+    /* slot: where this query's visibility byte lives.  The bytes are laid out in PLANES — query j of pixel-sample k at
+     * j * slotStride + k (slotStride = all pixel-sample slots of the frame) — so the 64 results a traversal wave holds (the same
+     * query of 64 neighbouring pixels) are 64 consecutive bytes, whole 32-B sectors written by one wave from one XCD.  Pixel-major
+     * (k * maxRays + j) had every byte of a sector written by another wave, mostly on another XCD, at another time: 522 MB of HBM
+     * writes for 24.8 MB of payload (profiles/r02/pmc_roofline.json). */
+    float4* queue; lds_word waveOffset; uint32_t base; uint32_t slot, slotStride;
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -68,15 +73,15 @@ struct EmitPolicy {
         const size_t idx = (size_t)(base + off + prefix) * 2;
         queue[idx] = make_float4(o.x, o.y, o.z, tmax);
         queue[idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
-        ++slot;
+        slot += slotStride;
         return false;
     }
 };
 
 struct LookupPolicy {
     static constexpr bool kShade = true;
-    const uint8_t* vis; uint32_t slot;
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { return vis[slot++] != 0; }
+    const uint8_t* vis; uint32_t slot, slotStride;
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { const bool occ = vis[slot] != 0; slot += slotStride; return occ; }
 };
 
 /* The same two phases with the queue binned by direction octant (k_shadow_gen_oct): a workgroup's chunk of the queue is laid
@@ -101,7 +106,7 @@ struct CountOctPolicy {
 struct EmitOctPolicy {
     static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;
-    float4* queue; lds_word run; uint32_t slot;         /* run[o]: next queue index of this wave's part of the octant-o run */
+    float4* queue; lds_word run; uint32_t slot, slotStride;         /* run[o]: next queue index of this wave's part of the octant-o run; slot / slotStride as in EmitPolicy */
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw) {
         const uint32_t oct = raw_octant(raw);
         unsigned long long rem = __ballot(1);
@@ -118,7 +123,7 @@ struct EmitOctPolicy {
             }
             rem &= ~mo;
         }
-        ++slot;
+        slot += slotStride;
         return false;
     }
 };
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, Render
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * planeStride + q;
-        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)(k * ra.maxRaysPerSample)};
+        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k, planeStride * ra.spp};
         if (single) {
             if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc,
     if (!live || mine == 0) return;
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * planeStride + q;
-        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)(k * ra.maxRaysPerSample)};
+        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, planeStride * ra.spp};
         if (single) {
             if (surf0) light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
@@ -1058,7 +1063,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs r
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
         const rtr_v3 dir = primary_dir(ra, px, py, i);
-        LookupPolicy pol{vis, (uint32_t)(k * ra.maxRaysPerSample)};
+        LookupPolicy pol{vis, (uint32_t)k, gridDim.x * kBlock * ra.spp};
         shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
     write_pixel(ra, fo, (size_t)lrow * ra.width + px, acc);

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -90,6 +92,9 @@ struct Rank {
     ncclComm_t comm = nullptr;
     Slot slots[RTR_MGPU_MAX_SLOTS];
     std::unique_ptr<Worker> worker;
+    /* what this rank's worker is doing right now (a string literal): the watchdog of rtr_mgpu_wait names it when it gives up, so a
+     * hang says where it is */
+    std::atomic<const char*> stage{"idle"};
 };
 
 #define W_HIP(expr)  do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return RTR_ERR_HIP; } } while (0)
@@ -101,6 +106,8 @@ struct Rank {
 struct rtr_mgpu {
     int nranks = 0, framesInFlight = 1;
     bool selfExchange = false;
+    bool aborted = false;                           /* the communicators were aborted: the handle only waits for / frees things now */
+    uint32_t timeoutMs = 120000;
     std::vector<std::unique_ptr<Rank>> ranks;       /* the local ones */
 };
 
@@ -119,92 +126,192 @@ void release_slot(Rank& r, Slot& s) {
     s.evRender = nullptr; s.evComm = nullptr; s.width = s.height = s.rows = s.bandRows = s.images = 0; s.commPending = false;
 }
 
-/* (re)creates the slot's frame and, on rank 0, the gather / full-frame buffers for this extent */
-int prepare_slot(rtr_mgpu* m, Rank& r, Slot& s, const rtr_render_params& p, std::string& err) {
+bool slot_matches(const rtr_mgpu* m, const Slot& s, const rtr_render_params& p) {
     const uint32_t band = p.bandRows ? p.bandRows : 8u;
     const uint32_t rows = rtr_shard_rows(p.height, band, (uint32_t)m->nranks);
     const uint32_t images = RTR_IMAGES_FRAMEBUFFER | (p.images & RTR_IMG_BIT(RTR_IMAGE_HDR));
-    if (s.frame && s.width == p.width && s.height == p.height && s.rows == rows && s.bandRows == band && s.images == images) return RTR_OK;
-    release_slot(r, s);
+    return s.frame && s.width == p.width && s.height == p.height && s.rows == rows && s.bandRows == band && s.images == images;
+}
+
+/* (re)creates the slot's frame and, on rank 0, the gather / full-frame buffers for this extent.  Everything of a frame that can
+ * fail for lack of memory happens here, BEFORE any rank posts a send or a receive (rtr_mgpu_render_async joins this phase on all
+ * local ranks first): a rank that fails later than that would leave its peers' receives unmatched. */
+int prepare_slot(rtr_mgpu* m, Rank& r, Slot& s, const rtr_render_params& p, std::string& err) {
+    if (slot_matches(m, s, p)) return RTR_OK;
+    const uint32_t band = p.bandRows ? p.bandRows : 8u;
+    const uint32_t rows = rtr_shard_rows(p.height, band, (uint32_t)m->nranks);
+    const uint32_t images = RTR_IMAGES_FRAMEBUFFER | (p.images & RTR_IMG_BIT(RTR_IMAGE_HDR));
+    r.stage = "prepare_slot";
+    /* the slot's previous frame may still be running (its join only covered the host-side enqueue) */
     W_HIP(hipSetDevice(r.device));
-    W_RTR(rtr_frame_create(r.ctx[&s - r.slots], p.width, rows, images, &s.frame));
+    const int sl = (int)(&s - r.slots);
+    W_HIP(hipStreamSynchronize(r.renderStream[sl]));
+    W_HIP(hipStreamSynchronize(r.commStream));
+    release_slot(r, s);
+    W_RTR(rtr_frame_create(r.ctx[sl], p.width, rows, images, &s.frame));
     W_HIP(hipEventCreateWithFlags(&s.evRender, hipEventDisableTiming));
     W_HIP(hipEventCreateWithFlags(&s.evComm, hipEventDisableTiming));
     const size_t shardBytes = (size_t)rows * p.width * 4;
     if (r.rank == 0) {
         W_HIP(hipMalloc((void**)&s.gathered, shardBytes * (size_t)m->nranks));
-        W_HIP(hipMemset(s.gathered, 0, shardBytes * (size_t)m->nranks));
+        W_HIP(hipMemsetAsync(s.gathered, 0, shardBytes * (size_t)m->nranks, r.commStream));
         W_HIP(hipMalloc((void**)&s.full, (size_t)p.width * p.height * 4));
         if (m->selfExchange && m->nranks == 1) {
             W_HIP(hipMalloc((void**)&s.selfSrc, shardBytes));
-            W_HIP(hipMemset(s.selfSrc, 0, shardBytes));
+            W_HIP(hipMemsetAsync(s.selfSrc, 0, shardBytes, r.commStream));
             W_RTR(rtr_frame_bind_external(s.frame, RTR_IMAGE_SHADOWED, s.selfSrc, shardBytes));
         } else {
             /* rank 0 renders straight into its place in the gather buffer: no copy of its own shard */
             W_RTR(rtr_frame_bind_external(s.frame, RTR_IMAGE_SHADOWED, s.gathered, shardBytes));
         }
+        W_HIP(hipStreamSynchronize(r.commStream));
     }
     size_t bytes = 0;
     W_RTR(rtr_frame_device_ptr(s.frame, RTR_IMAGE_SHADOWED, &s.local, &bytes));
     s.width = p.width; s.height = p.height; s.rows = rows; s.bandRows = band; s.images = images;
+    r.stage = "idle";
     return RTR_OK;
 }
 
+/* The plan (include/rtr_mgpu.h): what `rank` of `nranks` enqueues for one frame, in order. */
+int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, std::vector<rtr_mgpu_op>& ops) {
+    if (nranks < 1 || nranks > RTR_MGPU_MAX_RANKS || rank < 0 || rank >= nranks || width == 0 || height == 0) return RTR_ERR_INVALID_ARGUMENT;
+    if (bandRows == 0) bandRows = 8;
+    const uint64_t shardBytes = (uint64_t)rtr_shard_rows(height, bandRows, (uint32_t)nranks) * width * 4u;
+    const bool self = selfExchange && nranks == 1;
+    auto op = [&](int kind, int stream, int peer, int buffer, int event, uint64_t offset, uint64_t bytes) {
+        rtr_mgpu_op o; memset(&o, 0, sizeof o);
+        o.kind = kind; o.stream = stream; o.peer = peer; o.buffer = buffer; o.event = event; o.offset = offset; o.bytes = bytes;
+        ops.push_back(o);
+    };
+    ops.clear();
+    /* the slot's previous exchange must be done with the buffers this render overwrites */
+    op(RTR_MGPU_OP_WAIT, RTR_MGPU_STREAM_RENDER, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
+    /* rank 0 renders straight into its place (shard 0) of the gather buffer */
+    op(RTR_MGPU_OP_RENDER, RTR_MGPU_STREAM_RENDER, rank, rank == 0 ? (self ? RTR_MGPU_BUF_SELF_SRC : RTR_MGPU_BUF_GATHER) : RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
+    if (flags & RTR_MGPU_NO_EXCHANGE) return RTR_OK;
+    op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_RENDER, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_RENDER_DONE, 0, 0);
+    op(RTR_MGPU_OP_WAIT, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_RENDER_DONE, 0, 0);
+    /* the one exchange step: every other rank's shard -> rank 0 (xGMI: one direct link per peer), grouped so that RCCL posts all
+     * of a rank's transfers together — a send and a receive that depend on each other and sit one behind the other on a stream
+     * never complete */
+    if (nranks > 1 || self) {
+        op(RTR_MGPU_OP_GROUP_START, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
+        if (self) {
+            op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, 0, RTR_MGPU_BUF_SELF_SRC, RTR_MGPU_EV_NONE, 0, shardBytes);
+            op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, 0, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, 0, shardBytes);
+        } else if (rank == 0) {
+            for (int src = 1; src < nranks; ++src) op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, src, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, shardBytes * (uint64_t)src, shardBytes);
+        } else {
+            op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, 0, RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
+        }
+        op(RTR_MGPU_OP_GROUP_END, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
+    }
+    if (rank == 0) op(RTR_MGPU_OP_DEINTERLEAVE, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_FULL, RTR_MGPU_EV_NONE, 0, (uint64_t)width * height * 4u);     /* one rank: a plain copy */
+    op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
+    return RTR_OK;
+}
+
+/* Carries the plan out on this rank's streams.  The slot is prepared (prepare_slot) before this runs. */
 int enqueue(rtr_mgpu* m, Rank& r, int slot, RtrCameraData cam, RtrSceneInfo info, rtr_render_params p, int flags, std::string& err) {
     W_HIP(hipSetDevice(r.device));
     if (!r.scene) { err = "no scene: call rtr_mgpu_scene_create first"; return RTR_ERR_INVALID_ARGUMENT; }
     Slot& s = r.slots[slot];
-    int rc = prepare_slot(m, r, s, p, err);
-    if (rc != RTR_OK) return rc;
-    /* the previous exchange of this slot must have finished with the buffers the new render overwrites */
-    hipStream_t renderStream = r.renderStream[slot];
-    if (s.commPending) W_HIP(hipStreamWaitEvent(renderStream, s.evComm, 0));
-    p.shardIndex = (uint32_t)r.rank; p.shardCount = (uint32_t)m->nranks;
-    p.images = s.images; p.collectStats = 0;
-    if (!(s.images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { p.accumulate = 0; p.accumulatedFrames = 0; }
-    W_RTR(rtr_render_async(r.scene, &cam, &info, &p, s.frame));
-    if (flags & RTR_MGPU_NO_EXCHANGE) return RTR_OK;          /* an accumulation step: the exchange follows the last frame of the sum */
-    W_HIP(hipEventRecord(s.evRender, renderStream));
-    W_HIP(hipStreamWaitEvent(r.commStream, s.evRender, 0));
-    const size_t shardBytes = (size_t)s.rows * s.width * 4;
-    /* the one exchange step: every other rank's shard -> rank 0, on the communication stream (xGMI: one direct link per peer) */
-    if (m->nranks > 1) {
-        W_NCCL(ncclGroupStart());
-        if (r.rank == 0) {
-            for (int src = 1; src < m->nranks; ++src)
-                W_NCCL(ncclRecv(reinterpret_cast<char*>(s.gathered) + shardBytes * (size_t)src, shardBytes, ncclUint8, src, r.comm, r.commStream));
-        } else {
-            W_NCCL(ncclSend(s.local, shardBytes, ncclUint8, 0, r.comm, r.commStream));
+    if (!slot_matches(m, s, p)) { err = "internal: slot not prepared for this extent"; return RTR_ERR_INVALID_ARGUMENT; }
+    std::vector<rtr_mgpu_op> ops;
+    if (make_plan(r.rank, m->nranks, p.width, p.height, p.bandRows, flags, m->selfExchange ? 1 : 0, ops) != RTR_OK) { err = "internal: no plan for this rank / extent"; return RTR_ERR_INVALID_ARGUMENT; }
+    auto buffer = [&](int which) -> char* {
+        switch (which) {
+            case RTR_MGPU_BUF_LOCAL: return static_cast<char*>(s.local);
+            case RTR_MGPU_BUF_GATHER: return reinterpret_cast<char*>(s.gathered);
+            case RTR_MGPU_BUF_SELF_SRC: return reinterpret_cast<char*>(s.selfSrc);
+            case RTR_MGPU_BUF_FULL: return reinterpret_cast<char*>(s.full);
+            default: return nullptr;
         }
-        W_NCCL(ncclGroupEnd());
-    } else if (m->selfExchange) {
-        W_NCCL(ncclGroupStart());
-        W_NCCL(ncclSend(s.selfSrc, shardBytes, ncclUint8, 0, r.comm, r.commStream));
-        W_NCCL(ncclRecv(s.gathered, shardBytes, ncclUint8, 0, r.comm, r.commStream));
-        W_NCCL(ncclGroupEnd());
+    };
+    bool inGroup = false;
+    int rc = RTR_OK;
+    for (const rtr_mgpu_op& o : ops) {
+        hipStream_t st = o.stream == RTR_MGPU_STREAM_RENDER ? r.renderStream[slot] : r.commStream;
+        hipEvent_t ev = o.event == RTR_MGPU_EV_RENDER_DONE ? s.evRender : s.evComm;
+        hipError_t he = hipSuccess; ncclResult_t ne = ncclSuccess;
+        switch (o.kind) {
+            case RTR_MGPU_OP_WAIT:
+                r.stage = "hipStreamWaitEvent";
+                if (o.event == RTR_MGPU_EV_COMM_DONE && !s.commPending) break;       /* first use of the slot */
+                he = hipStreamWaitEvent(st, ev, 0);
+                break;
+            case RTR_MGPU_OP_RENDER: {
+                r.stage = "rtr_render_async";
+                if (buffer(o.buffer) + o.offset != static_cast<char*>(s.local)) { err = "internal: the frame is not bound to the buffer the plan renders into"; rc = RTR_ERR_INVALID_ARGUMENT; break; }
+                p.shardIndex = (uint32_t)o.peer; p.shardCount = (uint32_t)m->nranks;
+                p.images = s.images; p.collectStats = 0;
+                if (!(s.images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { p.accumulate = 0; p.accumulatedFrames = 0; }
+                rc = rtr_render_async(r.scene, &cam, &info, &p, s.frame);
+                if (rc != RTR_OK) err = std::string("rtr_render_async: ") + rtr_last_error();
+                break;
+            }
+            case RTR_MGPU_OP_RECORD:
+                r.stage = "hipEventRecord";
+                he = hipEventRecord(ev, st);
+                if (he == hipSuccess && o.event == RTR_MGPU_EV_COMM_DONE) s.commPending = true;
+                break;
+            case RTR_MGPU_OP_GROUP_START: r.stage = "ncclGroupStart"; ne = ncclGroupStart(); inGroup = ne == ncclSuccess; break;
+            case RTR_MGPU_OP_RECV: r.stage = "ncclRecv"; ne = ncclRecv(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); break;
+            case RTR_MGPU_OP_SEND: r.stage = "ncclSend"; ne = ncclSend(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); break;
+            case RTR_MGPU_OP_GROUP_END: r.stage = "ncclGroupEnd"; inGroup = false; ne = ncclGroupEnd(); break;
+            case RTR_MGPU_OP_DEINTERLEAVE:
+                r.stage = "rtr_deinterleave_bands";
+                rc = rtr_deinterleave_bands(r.commCtx, s.gathered, s.full, s.width, s.height, s.bandRows, (uint32_t)m->nranks);
+                if (rc != RTR_OK) err = std::string("rtr_deinterleave_bands: ") + rtr_last_error();
+                break;
+            default: err = "internal: unknown operation in the plan"; rc = RTR_ERR_INVALID_ARGUMENT; break;
+        }
+        if (he != hipSuccess) { err = std::string(r.stage.load()) + ": " + hipGetErrorString(he); rc = RTR_ERR_HIP; }
+        if (ne != ncclSuccess) { err = std::string(r.stage.load()) + ": " + ncclGetErrorString(ne); rc = RTR_ERR_HIP; }
+        if (rc != RTR_OK) {
+            if (inGroup) (void)ncclGroupEnd();     /* never leave this thread inside a group */
+            return rc;                              /* the caller aborts the communicators: peers may already have posted their half */
+        }
     }
-    if (r.rank == 0) W_RTR(rtr_deinterleave_bands(r.commCtx, s.gathered, s.full, s.width, s.height, s.bandRows, (uint32_t)m->nranks));   /* one rank: a plain copy */
-    W_HIP(hipEventRecord(s.evComm, r.commStream));
-    s.commPending = true;
+    r.stage = "idle";
     return RTR_OK;
 }
 
+void destroy_rank(Rank& r) {
+    r.worker.reset();                                   /* joins the thread */
+    (void)hipSetDevice(r.device);
+    if (r.commStream) (void)hipStreamSynchronize(r.commStream);
+    for (int sl = 0; sl < RTR_MGPU_MAX_SLOTS; ++sl) if (r.renderStream[sl]) (void)hipStreamSynchronize(r.renderStream[sl]);
+    for (int s = 0; s < RTR_MGPU_MAX_SLOTS; ++s) release_slot(r, r.slots[s]);
+    if (r.scene) { rtr_scene_destroy(r.scene); r.scene = nullptr; }
+    if (r.comm) { (void)ncclCommDestroy(r.comm); r.comm = nullptr; }
+    if (r.commCtx) { rtr_ctx_destroy(r.commCtx); r.commCtx = nullptr; }
+    for (int sl = 0; sl < RTR_MGPU_MAX_SLOTS; ++sl) if (r.ctx[sl]) { rtr_ctx_destroy(r.ctx[sl]); r.ctx[sl] = nullptr; }
+}
+
+/* takes ownership of `comm` whatever happens */
 int make_rank(rtr_mgpu* m, int rank, int device, ncclComm_t comm) {
     std::unique_ptr<Rank> r(new Rank());
     r->rank = rank; r->device = device; r->comm = comm;
     int rc = RTR_OK;
-    for (int sl = 0; sl < m->framesInFlight; ++sl) {
+    for (int sl = 0; sl < m->framesInFlight && rc == RTR_OK; ++sl) {
         rc = rtr_ctx_create(device, &r->ctx[sl]);
-        if (rc != RTR_OK) return fail(rc, "rank %d: rtr_ctx_create(%d): %s", rank, device, rtr_last_error());
+        if (rc != RTR_OK) { rc = fail(rc, "rank %d: rtr_ctx_create(%d): %s", rank, device, rtr_last_error()); break; }
         void* st = nullptr;
-        if (rtr_ctx_get_stream(r->ctx[sl], &st) != RTR_OK) return fail(RTR_ERR_HIP, "rank %d: rtr_ctx_get_stream: %s", rank, rtr_last_error());
+        if (rtr_ctx_get_stream(r->ctx[sl], &st) != RTR_OK) { rc = fail(RTR_ERR_HIP, "rank %d: rtr_ctx_get_stream: %s", rank, rtr_last_error()); break; }
         r->renderStream[sl] = (hipStream_t)st;
     }
-    rc = rtr_ctx_create(device, &r->commCtx);
-    if (rc != RTR_OK) return fail(rc, "rank %d: rtr_ctx_create(%d): %s", rank, device, rtr_last_error());
-    void* s1 = nullptr;
-    if (rtr_ctx_get_stream(r->commCtx, &s1) != RTR_OK) return fail(RTR_ERR_HIP, "rank %d: rtr_ctx_get_stream: %s", rank, rtr_last_error());
-    r->commStream = (hipStream_t)s1;
+    if (rc == RTR_OK) {
+        rc = rtr_ctx_create(device, &r->commCtx);
+        if (rc != RTR_OK) rc = fail(rc, "rank %d: rtr_ctx_create(%d): %s", rank, device, rtr_last_error());
+    }
+    if (rc == RTR_OK) {
+        void* s1 = nullptr;
+        if (rtr_ctx_get_stream(r->commCtx, &s1) != RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: rtr_ctx_get_stream: %s", rank, rtr_last_error());
+        r->commStream = (hipStream_t)s1;
+    }
+    if (rc != RTR_OK) { const std::string keep = g_err; destroy_rank(*r); g_err = keep; return rc; }
     r->worker.reset(new Worker());
     m->ranks.push_back(std::move(r));
     return RTR_OK;
@@ -213,6 +320,40 @@ int make_rank(rtr_mgpu* m, int rank, int device, ncclComm_t comm) {
 int check_slots(int framesInFlight) {
     if (framesInFlight < 1 || framesInFlight > RTR_MGPU_MAX_SLOTS) return fail(RTR_ERR_INVALID_ARGUMENT, "framesInFlight %d not in [1, %d]", framesInFlight, RTR_MGPU_MAX_SLOTS);
     return RTR_OK;
+}
+
+void read_env(rtr_mgpu* m) {
+    const char* se = getenv("RTR_MGPU_SELF_EXCHANGE");
+    m->selfExchange = se && se[0] == '1';
+    if (const char* t = getenv("RTR_MGPU_TIMEOUT_MS")) m->timeoutMs = (uint32_t)strtoul(t, nullptr, 10);
+}
+
+/* Gives the communicators up: peers blocked in a send / receive that will never be matched are released (ncclCommAbort may be
+ * called while another thread is blocked inside a call on the same communicator).  The handle only waits and frees from here on. */
+void abort_all(rtr_mgpu* m) {
+    if (m->aborted) return;
+    m->aborted = true;
+    for (auto& rp : m->ranks) if (rp->comm) { (void)ncclCommAbort(rp->comm); rp->comm = nullptr; }
+}
+
+std::string stages(const rtr_mgpu* m) {
+    std::string out;
+    for (auto& rp : m->ranks) { if (!out.empty()) out += ", "; out += "rank " + std::to_string(rp->rank) + ": " + rp->stage.load(); }
+    return out;
+}
+
+/* Joins a host-side job with the watchdog.  false = it did not come back in time (the communicators are aborted). */
+bool join_job(rtr_mgpu* m, std::future<int>& f, int* rc) {
+    if (m->timeoutMs == 0) { *rc = f.get(); return true; }
+    if (f.wait_for(std::chrono::milliseconds(m->timeoutMs)) != std::future_status::ready) {
+        const std::string where = stages(m);
+        abort_all(m);                                  /* releases a worker blocked inside RCCL */
+        (void)f.wait_for(std::chrono::milliseconds(5000));
+        *rc = fail(RTR_ERR_HIP, "watchdog: a rank's enqueue did not return within %u ms (%s); communicators aborted", m->timeoutMs, where.c_str());
+        return false;
+    }
+    *rc = f.get();
+    return true;
 }
 
 }  // namespace
@@ -231,13 +372,27 @@ int rtr_mgpu_unique_id(void* id) {
     return RTR_OK;
 }
 
+int rtr_mgpu_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange,
+                  rtr_mgpu_op* ops, int maxOps, int* numOps) {
+    if (!ops || !numOps || maxOps < 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: null argument");
+    std::vector<rtr_mgpu_op> v;
+    if (make_plan(rank, nranks, width, height, bandRows, flags, selfExchange, v) != RTR_OK)
+        return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: rank %d of %d (at most %d), frame %ux%u", rank, nranks, RTR_MGPU_MAX_RANKS, width, height);
+    if ((int)v.size() > maxOps) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: %zu operations, room for %d", v.size(), maxOps);
+    memcpy(ops, v.data(), v.size() * sizeof(rtr_mgpu_op));
+    *numOps = (int)v.size();
+    return RTR_OK;
+}
+
 int rtr_mgpu_create(const int* devices, int n, int framesInFlight, rtr_mgpu** out) {
     if (!devices || n < 1 || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: bad argument");
     *out = nullptr;
     int rc = check_slots(framesInFlight);
     if (rc != RTR_OK) return rc;
+    if (n > RTR_MGPU_MAX_RANKS) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, at most %d ranks", n, RTR_MGPU_MAX_RANKS);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RTR_ERR_NO_DEVICE, "rtr_mgpu_create: no HIP device; this library has no CPU fallback");
+    if (n > count) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, %d present", n, count);
     for (int i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= count) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: device %d not in [0,%d)", devices[i], count);
         for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: device %d listed twice (one rank per GPU)", devices[i]);
@@ -247,18 +402,23 @@ int rtr_mgpu_create(const int* devices, int n, int framesInFlight, rtr_mgpu** ou
     if (r != ncclSuccess) return fail(RTR_ERR_HIP, "ncclCommInitAll(%d devices): %s", n, ncclGetErrorString(r));
     rtr_mgpu* m = new rtr_mgpu();
     m->nranks = n; m->framesInFlight = framesInFlight;
-    const char* se = getenv("RTR_MGPU_SELF_EXCHANGE");
-    m->selfExchange = se && se[0] == '1';
+    read_env(m);
     for (int i = 0; i < n; ++i) {
-        rc = make_rank(m, i, devices[i], comms[(size_t)i]);
-        if (rc != RTR_OK) { for (int j = i + 1; j < n; ++j) (void)ncclCommDestroy(comms[(size_t)j]); rtr_mgpu_destroy(m); return rc; }
+        rc = make_rank(m, i, devices[i], comms[(size_t)i]);          /* owns comms[i] from here, also when it fails */
+        if (rc != RTR_OK) {
+            const std::string keep = g_err;
+            for (int j = i + 1; j < n; ++j) (void)ncclCommDestroy(comms[(size_t)j]);
+            rtr_mgpu_destroy(m);
+            g_err = keep;
+            return rc;
+        }
     }
     *out = m;
     return RTR_OK;
 }
 
 int rtr_mgpu_create_rank(int device, int rank, int nranks, const void* id, int framesInFlight, rtr_mgpu** out) {
-    if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create_rank: bad argument");
+    if (!id || !out || nranks < 1 || nranks > RTR_MGPU_MAX_RANKS || rank < 0 || rank >= nranks) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create_rank: bad argument");
     *out = nullptr;
     int rc = check_slots(framesInFlight);
     if (rc != RTR_OK) return rc;
@@ -272,30 +432,26 @@ int rtr_mgpu_create_rank(int device, int rank, int nranks, const void* id, int f
     if (r != ncclSuccess) return fail(RTR_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));
     rtr_mgpu* m = new rtr_mgpu();
     m->nranks = nranks; m->framesInFlight = framesInFlight;
-    const char* se = getenv("RTR_MGPU_SELF_EXCHANGE");
-    m->selfExchange = se && se[0] == '1';
+    read_env(m);
     rc = make_rank(m, rank, device, comm);
-    if (rc != RTR_OK) { rtr_mgpu_destroy(m); return rc; }
+    if (rc != RTR_OK) { const std::string keep = g_err; rtr_mgpu_destroy(m); g_err = keep; return rc; }
     *out = m;
     return RTR_OK;
 }
 
 void rtr_mgpu_destroy(rtr_mgpu* m) {
     if (!m) return;
-    for (auto& rp : m->ranks) {
-        Rank& r = *rp;
-        for (int s = 0; s < RTR_MGPU_MAX_SLOTS; ++s) if (r.slots[s].inFlight) { (void)r.slots[s].pending.get(); r.slots[s].inFlight = false; }
-        r.worker.reset();                                   /* joins the thread */
-        (void)hipSetDevice(r.device);
-        if (r.commStream) (void)hipStreamSynchronize(r.commStream);
-        for (int sl = 0; sl < RTR_MGPU_MAX_SLOTS; ++sl) if (r.renderStream[sl]) (void)hipStreamSynchronize(r.renderStream[sl]);
-        for (int s = 0; s < RTR_MGPU_MAX_SLOTS; ++s) release_slot(r, r.slots[s]);
-        if (r.scene) rtr_scene_destroy(r.scene);
-        if (r.comm) (void)ncclCommDestroy(r.comm);
-        if (r.commCtx) rtr_ctx_destroy(r.commCtx);
-        for (int sl = 0; sl < RTR_MGPU_MAX_SLOTS; ++sl) if (r.ctx[sl]) rtr_ctx_destroy(r.ctx[sl]);
-    }
+    for (auto& rp : m->ranks)
+        for (int s = 0; s < RTR_MGPU_MAX_SLOTS; ++s)
+            if (rp->slots[s].inFlight) { int rc = 0; (void)join_job(m, rp->slots[s].pending, &rc); rp->slots[s].inFlight = false; }
+    for (auto& rp : m->ranks) destroy_rank(*rp);
     delete m;
+}
+
+int rtr_mgpu_set_timeout_ms(rtr_mgpu* m, uint32_t ms) {
+    if (!m) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_set_timeout_ms: null");
+    m->timeoutMs = ms;
+    return RTR_OK;
 }
 
 int rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out) {
@@ -303,35 +459,80 @@ int rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out) {
     memset(out, 0, sizeof *out);
     out->nranks = m->nranks; out->nlocal = (int)m->ranks.size(); out->firstRank = m->ranks.empty() ? 0 : m->ranks[0]->rank;
     out->framesInFlight = m->framesInFlight; out->selfExchange = m->selfExchange ? 1 : 0;
+    out->aborted = m->aborted ? 1 : 0; out->timeoutMs = (int)m->timeoutMs;
+    int v = 0; if (ncclGetVersion(&v) == ncclSuccess) out->rcclVersion = v;
     return RTR_OK;
 }
 
 int rtr_mgpu_scene_create(rtr_mgpu* m, const rtr_scene_desc* desc) {
     if (!m || !desc) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_scene_create: null argument");
-    /* one build per device, concurrently, each on its rank's thread (the host BVH build is the long part) */
+    if (m->aborted) return fail(RTR_ERR_HIP, "rtr_mgpu_scene_create: the communicators were aborted; destroy the handle");
+    /* the tree is built ONCE, by the first local rank; the others upload that build (rtr_scene_create_like) side by side, each on
+     * its own thread and device */
+    Rank* first = m->ranks[0].get();
+    int rc = RTR_OK;
+    {
+        std::future<int> f = first->worker->submit([first, desc](std::string& err) -> int {
+            first->stage = "rtr_scene_create";
+            W_HIP(hipSetDevice(first->device));
+            if (first->scene) { rtr_scene_destroy(first->scene); first->scene = nullptr; }
+            W_RTR(rtr_scene_create(first->ctx[0], desc, &first->scene));       /* frames of the other slots' contexts render it too (read-only) */
+            first->stage = "idle";
+            return RTR_OK;
+        });
+        const int c = f.get();
+        if (c != RTR_OK) return fail(c, "rank %d: %s", first->rank, first->worker->error().c_str());
+    }
     std::vector<std::future<int>> fs;
-    for (auto& rp : m->ranks) {
-        Rank* r = rp.get();
-        fs.push_back(r->worker->submit([r, desc](std::string& err) -> int {
+    for (size_t i = 1; i < m->ranks.size(); ++i) {
+        Rank* r = m->ranks[i].get();
+        const rtr_scene* built = first->scene;
+        fs.push_back(r->worker->submit([r, desc, built](std::string& err) -> int {
+            r->stage = "rtr_scene_create_like";
             W_HIP(hipSetDevice(r->device));
             if (r->scene) { rtr_scene_destroy(r->scene); r->scene = nullptr; }
-            W_RTR(rtr_scene_create(r->ctx[0], desc, &r->scene));       /* frames of the other slots' contexts render it too (read-only) */
+            W_RTR(rtr_scene_create_like(r->ctx[0], desc, built, &r->scene));
+            r->stage = "idle";
             return RTR_OK;
         }));
     }
-    int rc = RTR_OK; size_t i = 0;
+    size_t i = 1;
     for (auto& f : fs) { const int c = f.get(); if (c != RTR_OK && rc == RTR_OK) rc = fail(c, "rank %d: %s", m->ranks[i]->rank, m->ranks[i]->worker->error().c_str()); ++i; }
     return rc;
 }
 
 int rtr_mgpu_render_async(rtr_mgpu* m, int slot, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, int flags) {
     if (!m || !cam || !info || !p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: null argument");
+    if (m->aborted) return fail(RTR_ERR_HIP, "rtr_mgpu_render_async: the communicators were aborted after an earlier failure; destroy the handle");
     if (slot < 0 || slot >= m->framesInFlight) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: slot %d not in [0,%d)", slot, m->framesInFlight);
     if (p->width == 0 || p->height == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: empty frame");
     if (p->images & ~(RTR_IMAGES_FRAMEBUFFER | RTR_IMG_BIT(RTR_IMAGE_HDR))) return fail(RTR_ERR_UNSUPPORTED, "rtr_mgpu_render_async: only the RGBA8 framebuffer (RTR_IMAGE_SHADOWED) is gathered; RTR_IMAGE_HDR may be added for accumulation");
     if (p->accumulate && !(p->images & RTR_IMG_BIT(RTR_IMAGE_HDR))) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: accumulate needs RTR_IMAGE_HDR in params->images");
-    /* consecutive calls on a slot are ordered by its render stream; only an exchange in flight forbids the next call */
-    for (auto& rp : m->ranks) if (rp->slots[slot].inFlight) { const int c = rp->slots[slot].pending.get(); rp->slots[slot].inFlight = false; if (c != RTR_OK) return fail(c, "rank %d: %s", rp->rank, rp->worker->error().c_str()); }
+    for (auto& rp : m->ranks) if (!rp->scene) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: no scene: call rtr_mgpu_scene_create first");
+    /* consecutive calls on a slot are ordered by its render stream; only an enqueue still running on a worker forbids the next call */
+    for (auto& rp : m->ranks) if (rp->slots[slot].inFlight) {
+        int c = RTR_OK;
+        const bool back = join_job(m, rp->slots[slot].pending, &c);
+        rp->slots[slot].inFlight = false;
+        if (!back) return c;
+        if (c != RTR_OK) { const std::string msg = rp->worker->error(); abort_all(m); return fail(c, "rank %d: %s (communicators aborted)", rp->rank, msg.c_str()); }
+    }
+    /* Phase 1 — everything that can fail for lack of memory, on every local rank, joined BEFORE any rank posts a transfer: a rank
+     * that dropped out after its peers had posted theirs would leave them waiting for ever.  In steady state (the slot already has
+     * this extent) this is a comparison on the caller's thread. */
+    bool prepared = true;
+    for (auto& rp : m->ranks) prepared = prepared && slot_matches(m, rp->slots[slot], *p);
+    if (!prepared) {
+        std::vector<std::future<int>> fs;
+        for (auto& rp : m->ranks) {
+            Rank* r = rp.get(); const rtr_render_params pp = *p;
+            fs.push_back(r->worker->submit([m, r, slot, pp](std::string& err) -> int { return prepare_slot(m, *r, r->slots[slot], pp, err); }));
+        }
+        int rc = RTR_OK; size_t i = 0;
+        for (auto& f : fs) { const int c = f.get(); if (c != RTR_OK && rc == RTR_OK) rc = fail(c, "rank %d: %s", m->ranks[i]->rank, m->ranks[i]->worker->error().c_str()); ++i; }
+        if (rc != RTR_OK) return rc;            /* nothing was posted: the handle stays usable */
+    }
+    /* Phase 2 — the plan, rank by rank, each on its own thread */
     for (auto& rp : m->ranks) {
         Rank* r = rp.get();
         const RtrCameraData c = *cam; const RtrSceneInfo si = *info; const rtr_render_params pp = *p;
@@ -345,14 +546,48 @@ int rtr_mgpu_wait(rtr_mgpu* m, int slot) {
     if (!m) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_wait: null");
     if (slot < 0 || slot >= m->framesInFlight) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_wait: slot %d not in [0,%d)", slot, m->framesInFlight);
     int rc = RTR_OK;
+    /* first every local rank's host-side enqueue ... */
+    std::vector<Rank*> waitFor;
     for (auto& rp : m->ranks) {
         Rank& r = *rp; Slot& s = r.slots[slot];
         if (!s.inFlight) continue;
-        const int c = s.pending.get();
+        int c = RTR_OK;
+        const bool back = join_job(m, s.pending, &c);
         s.inFlight = false;
+        if (!back) return c;
         if (c != RTR_OK) { if (rc == RTR_OK) rc = fail(c, "rank %d: %s", r.rank, r.worker->error().c_str()); continue; }
-        if (hipSetDevice(r.device) != hipSuccess || hipEventSynchronize(s.evComm) != hipSuccess) { if (rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: waiting for the exchange failed: %s", r.rank, hipGetErrorString(hipGetLastError())); continue; }
-        if (rtr_frame_wait(s.frame) != RTR_OK && rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: %s", r.rank, rtr_last_error());   /* the render is long done: this collects its per-kernel times */
+        waitFor.push_back(&r);
+    }
+    if (rc != RTR_OK) { const std::string keep = g_err; abort_all(m); g_err = keep + " (communicators aborted)"; return rc; }     /* a rank failed after phase 1: its peers' transfers can never be matched */
+    /* ... then the device side, under the watchdog */
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(m->timeoutMs);
+    for (Rank* rp : waitFor) {
+        Rank& r = *rp; Slot& s = r.slots[slot];
+        if (hipSetDevice(r.device) != hipSuccess) { if (rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: hipSetDevice failed", r.rank); continue; }
+        if (s.commPending) {
+            r.stage = "waiting for the exchange (evComm)";
+            hipError_t e = hipErrorNotReady;
+            if (m->timeoutMs == 0 || m->aborted) e = hipEventSynchronize(s.evComm);
+            else {
+                for (unsigned spin = 0;; ++spin) {
+                    e = hipEventQuery(s.evComm);
+                    if (e != hipErrorNotReady) break;
+                    if (spin > 2000u) {        /* ~ the first 50 us are a plain spin */
+                        if (std::chrono::steady_clock::now() > deadline) break;
+                        std::this_thread::yield();
+                    }
+                }
+            }
+            if (e == hipErrorNotReady) {
+                const std::string where = stages(m);
+                abort_all(m);
+                return fail(RTR_ERR_HIP, "watchdog: slot %d's exchange did not finish within %u ms (%s); communicators aborted", slot, m->timeoutMs, where.c_str());
+            }
+            if (e != hipSuccess) { if (rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: waiting for the exchange failed: %s", r.rank, hipGetErrorString(e)); continue; }
+        }
+        r.stage = "rtr_frame_wait";
+        if (rtr_frame_wait(s.frame) != RTR_OK && rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: %s", r.rank, rtr_last_error());   /* the render is long done (or was not exchanged): this collects its per-kernel times */
+        r.stage = "idle";
     }
     return rc;
 }
@@ -374,6 +609,8 @@ int rtr_mgpu_frame_device_ptr(rtr_mgpu* m, int slot, void** ptr, size_t* bytes) 
     Rank* r = rank0_of(m);
     if (!r) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_frame_device_ptr: rank 0 is not in this process");
     Slot& s = r->slots[slot];
+    /* a worker may be re-creating the slot's buffers right now */
+    if (s.inFlight) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_frame_device_ptr: slot %d is in flight; rtr_mgpu_wait it first", slot);
     if (!s.full) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_frame_device_ptr: slot %d has not been rendered", slot);
     *ptr = s.full; if (bytes) *bytes = (size_t)s.width * s.height * 4;
     return RTR_OK;
@@ -386,7 +623,6 @@ int rtr_mgpu_frame_download(rtr_mgpu* m, int slot, void* dst, size_t bytes) {
     if (rc != RTR_OK) return rc;
     if (bytes != need) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_frame_download: %zu bytes given, the frame is %zu", bytes, need);
     Rank* r = rank0_of(m);
-    if (r->slots[slot].inFlight) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_frame_download: slot %d is in flight; rtr_mgpu_wait it first", slot);
     if (hipSetDevice(r->device) != hipSuccess || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(RTR_ERR_HIP, "rtr_mgpu_frame_download: copy failed");
     return RTR_OK;
 }

@@ -96,6 +96,8 @@ struct rtr_scene {
     DevBuf<unsigned long long> wideSums;     /* scratch of bvh_make_wide */
     DevBuf<uint4> nodes4tmp;             /* the 4-wide entries in BVH2-id order, before the breadth-first permutation */
     DevBuf<uint32_t> wideRemap;
+    DevBuf<uint8_t> wideShape;           /* per BVH2 node: which entries its 4-wide record opens (host builder's cost-driven collapse); empty = greedy */
+    std::vector<uint8_t> hostWideShape;
     uint32_t wideReached = 0;            /* entries the 4-wide tree reaches (they come first in nodes4) */
     DevBuf<uint4> nodes4;                /* RtrWideNode: 4-wide view of the tree for the any-hit kernel, breadth-first order (kernels/rtr_bvh.hip) */
     DevBuf<float4> tris;
@@ -349,12 +351,26 @@ static void fill_stats(rtr_scene_stats& st, const rtr::BvhResult& bvh, uint32_t 
 }
 
 int rtr_host_build_bvh(const rtr_scene_desc* d, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes) {
+    return rtr_host_build_bvh_wide(d, stats, nodes, nodeBytes, tris, triBytes, nullptr, 0);
+}
+
+int rtr_host_build_bvh_wide(const rtr_scene_desc* d, rtr_scene_stats* stats, RtrBvhNode* nodes, size_t nodeBytes, RtrBvhTri* tris, size_t triBytes,
+                            RtrWideNode* wide, size_t wideBytes) {
     int rc = validate_desc(d);
     if (rc != RTR_OK) return rc;
     rtr::BvhResult bvh; std::vector<float> xf, nm; uint32_t stackEntries = 0; size_t numTris = 0;
     rc = flatten_and_build(d, bvh, xf, nm, &stackEntries, &numTris);
     if (rc != RTR_OK) return rc;
     if (stats) fill_stats(*stats, bvh, stackEntries, numTris);
+    if (wide || (stats && !nodes && !tris)) {
+        std::vector<RtrWideNode> w;
+        rtr::make_wide_host(bvh.nodes.data(), bvh.nodes.size(), bvh.wideShape.size() == bvh.nodes.size() ? bvh.wideShape.data() : nullptr, bvh.grid, w);
+        if (stats) { stats->grid = bvh.grid; stats->numWideNodes = (uint32_t)w.size(); stats->wideLayoutVersion = RTR_WIDE_LAYOUT_VERSION; }
+        if (wide) {
+            if (wideBytes != w.size() * sizeof(RtrWideNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_host_build_bvh_wide: wideBytes %zu != %zu", wideBytes, w.size() * sizeof(RtrWideNode));
+            memcpy(wide, w.data(), wideBytes);
+        }
+    }
     if (nodes) {
         if (nodeBytes != bvh.nodes.size() * sizeof(RtrBvhNode)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_host_build_bvh: nodeBytes %zu != %zu", nodeBytes, bvh.nodes.size() * sizeof(RtrBvhNode));
         memcpy(nodes, bvh.nodes.data(), nodeBytes);
@@ -396,7 +412,8 @@ static int make_wide_nodes(rtr_scene* s) {
     const uint32_t n = (uint32_t)s->hostNodes.size();
     if (!s->nodes4.p) { HIP_TRY(s->nodes4.alloc((size_t)n * 4)); HIP_TRY(s->nodes4tmp.alloc((size_t)n * 4)); HIP_TRY(s->wideRemap.alloc(n)); HIP_TRY(s->wideSums.alloc(rtrdev::bvh_wide_scratch_words())); }
     hipStream_t st = s->ctx->stream;
-    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->nodes4tmp.p, s->wideSums.p, st);
+    if (!s->hostWideShape.empty() && !s->wideShape.p) HIP_TRY(s->wideShape.upload(s->hostWideShape.data(), s->hostWideShape.size(), st));
+    hipError_t e = rtrdev::bvh_make_wide(s->nodes.p, n, s->refitReady ? s->parent.p : nullptr, s->grid.p, s->hostWideShape.size() == n ? s->wideShape.p : nullptr, s->nodes4tmp.p, s->wideSums.p, st);
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "4-wide node build: %s", hipGetErrorString(e));
     /* breadth-first order of the 4-wide tree (child codes = the 4th 16 bytes of every entry), so its top levels are the first
      * entries: k_shadow_trace4 keeps those in LDS.  Entries the 4-wide tree does not reach keep the ids after them. */
@@ -489,7 +506,16 @@ static void instance_tables(uint32_t numInstances, const RtrInstance* instances,
     }
 }
 
-int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
+static int scene_create_impl(rtr_ctx* ctx, const rtr_scene_desc* d, const rtr_scene* like, rtr_scene** out);
+
+int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) { return scene_create_impl(ctx, d, nullptr, out); }
+
+int rtr_scene_create_like(rtr_ctx* ctx, const rtr_scene_desc* d, const rtr_scene* built, rtr_scene** out) {
+    if (!built) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create_like: null scene to copy the tree from");
+    return scene_create_impl(ctx, d, built, out);
+}
+
+static int scene_create_impl(rtr_ctx* ctx, const rtr_scene_desc* d, const rtr_scene* like, rtr_scene** out) {
     if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: null ctx/out");
     if (ctx->destroyed) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create: the context has been destroyed");
     *out = nullptr;
@@ -503,9 +529,19 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
     rc = rtr_check_scene_limits(totalPrims, totalPrims ? totalPrims - 1 : 0);
     if (rc != RTR_OK) return rc;
     /* tiny scenes always take the host builder (the radix tree needs a root with more than one leaf's worth of primitives) */
-    const bool deviceBuild = d->buildFlags == RTR_BUILD_DEVICE_LBVH && totalPrims >= 16;
+    const bool deviceBuild = !like && d->buildFlags == RTR_BUILD_DEVICE_LBVH && totalPrims >= 16;
     rtr::BvhResult bvh; std::vector<float> xforms, nmats; uint32_t stackEntries = 0; size_t numTris = 0;
-    if (!deviceBuild) {
+    if (like) {
+        /* the tree of `like`, as its host copy holds it (nodes and records are kept in step with the device by every update) */
+        if (like->stats.numTriangles != totalPrims || like->hostNodes.empty() || like->hostTris.empty())
+            return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_scene_create_like: the built scene has %u triangles, this description %zu", like->stats.numTriangles, totalPrims);
+        bvh.nodes = like->hostNodes; bvh.tris = like->hostTris; bvh.grid = like->stats.grid; bvh.wideShape = like->hostWideShape;
+        bvh.maxDepth = like->stats.maxDepth; bvh.maxLeafSize = like->stats.maxLeafSize; bvh.sahCost = like->stats.sahCost; bvh.boxPad = like->stats.boxPad;
+        for (int k = 0; k < 3; ++k) { bvh.boundsMin[k] = like->stats.boundsMin[k]; bvh.boundsMax[k] = like->stats.boundsMax[k]; }
+        bvh.buildMs = 0.f;                                   /* nothing was built here */
+        stackEntries = like->stats.stackEntries; numTris = like->stats.numTriangles;
+        instance_tables(d->numInstances, d->instances, xforms, nmats);
+    } else if (!deviceBuild) {
         rc = flatten_and_build(d, bvh, xforms, nmats, &stackEntries, &numTris);
         if (rc != RTR_OK) return rc;
     } else {
@@ -572,6 +608,7 @@ int rtr_scene_create(rtr_ctx* ctx, const rtr_scene_desc* d, rtr_scene** out) {
         fill_stats(s->stats, bvh, stackEntries, numTris);
         s->hostNodes.swap(bvh.nodes);
         s->hostTris.swap(bvh.tris);
+        s->hostWideShape.swap(bvh.wideShape);
         s->numPrims = (uint32_t)s->hostTris.size(); s->numNodeSlots = (uint32_t)s->hostNodes.size();
     }
 

@@ -74,7 +74,7 @@ class MultiGpu:
             self._check(self.lib.rtr_mgpu_create(arr, len(devices), frames_in_flight, C.byref(self.h)), "rtr_mgpu_create")
         self.info = A.rtr_mgpu_info()
         self._check(self.lib.rtr_mgpu_get_info(self.h, C.byref(self.info)), "rtr_mgpu_get_info")
-        self._extent = None
+        self._extent = {}            # per slot: (height, width, band rows) of the last render
 
     @staticmethod
     def unique_id():
@@ -110,7 +110,7 @@ class MultiGpu:
     def render_async(self, slot, camera, scene_info, params, exchange=True):
         import ctypes as C
         self._check(self.lib.rtr_mgpu_render_async(self.h, slot, C.byref(camera), C.byref(scene_info), C.byref(params), 0 if exchange else 1), "rtr_mgpu_render_async")
-        self._extent = (params.height, params.width, params.bandRows or 8)
+        self._extent[slot] = (params.height, params.width, params.bandRows or 8)
 
     def wait(self, slot):
         self._check(self.lib.rtr_mgpu_wait(self.h, slot), "rtr_mgpu_wait")
@@ -120,13 +120,13 @@ class MultiGpu:
         self.wait(0)
 
     def download(self, slot=0):
-        H, W, _ = self._extent
+        H, W, _ = self._extent[slot]
         out = np.zeros((H, W), np.uint32)
         self._check(self.lib.rtr_mgpu_frame_download(self.h, slot, out.ctypes.data, out.nbytes), "rtr_mgpu_frame_download")
         return out
 
     def download_shard(self, slot=0, local_rank=0):
-        H, W, band = self._extent
+        H, W, band = self._extent[slot]
         out = np.zeros((shard_rows(H, band, self.info.nranks), W), np.uint32)
         self._check(self.lib.rtr_mgpu_shard_download(self.h, slot, local_rank, out.ctypes.data, out.nbytes), "rtr_mgpu_shard_download")
         return out

@@ -1,0 +1,131 @@
+"""Test infrastructure: carries out a rank's exchange plan (rtr_mgpu_plan, include/rtr_mgpu.h — the list of operations
+librtr_mgpu.so's enqueue() executes on the GPU) over another transport, so that the product's own offsets, lengths, peers and
+ordering are exercised with more than one rank on a machine without GPUs.
+
+  * `plan(rank, nranks, ...)`           the operations, straight from the library (no GPU needed to ask)
+  * `check_plans(plans, ...)`           the invariants every set of per-rank plans must satisfy
+  * `PlanRunner`                        executes one rank's plan: RENDER calls a caller-supplied shard renderer (the CPU oracle in
+                                        the tests), SEND / RECV go through torch.distributed point-to-point calls between
+                                        GROUP_START / GROUP_END, DEINTERLEAVE is the numpy restatement of k_deinterleave; stream
+                                        and event edges are checked for having been recorded before they are waited for
+Nothing here is on the product path."""
+import ctypes as C
+
+import numpy as np
+
+from realtimeraytracer_amd import _abi as A
+from realtimeraytracer_amd import mgpu
+
+
+def plan(rank, nranks, width, height, band_rows=8, flags=0, self_exchange=0):
+    lib = A.mgpu_lib()
+    ops = (A.rtr_mgpu_op * A.MGPU_PLAN_MAX_OPS)()
+    n = C.c_int(0)
+    rc = lib.rtr_mgpu_plan(rank, nranks, width, height, band_rows, flags, self_exchange, ops, A.MGPU_PLAN_MAX_OPS, C.byref(n))
+    if rc != 0:
+        raise ValueError(f"rtr_mgpu_plan failed ({rc}): {lib.rtr_mgpu_last_error().decode()}")
+    return [dict(kind=o.kind, stream=o.stream, peer=o.peer, buffer=o.buffer, event=o.event, offset=int(o.offset), bytes=int(o.bytes)) for o in ops[:n.value]]
+
+
+def check_plans(plans, width, height, band_rows=8):
+    """plans[r] = plan of rank r of len(plans).  Raises AssertionError naming the broken invariant."""
+    n = len(plans)
+    shard = mgpu.shard_rows(height, band_rows, n) * width * 4
+    sends, recvs = [], []
+    for r, ops in enumerate(plans):
+        kinds = [o["kind"] for o in ops]
+        # slot reuse: the render waits for the slot's previous exchange before it overwrites the buffers
+        assert ops[0]["kind"] == A.MGPU_OP_WAIT and ops[0]["stream"] == A.MGPU_STREAM_RENDER and ops[0]["event"] == A.MGPU_EV_COMM_DONE, (r, "first op")
+        ren = ops[1]
+        assert ren["kind"] == A.MGPU_OP_RENDER and ren["stream"] == A.MGPU_STREAM_RENDER and ren["peer"] == r and ren["bytes"] == shard and ren["offset"] == 0, (r, "render")
+        # rank 0 renders straight into shard 0 of the gather buffer; the others into their own shard
+        assert ren["buffer"] == (A.MGPU_BUF_GATHER if r == 0 else A.MGPU_BUF_LOCAL), (r, "render target")
+        assert kinds.count(A.MGPU_OP_RENDER) == 1
+        # the communication stream waits for the render before anything is sent
+        i_rec = next(i for i, o in enumerate(ops) if o["kind"] == A.MGPU_OP_RECORD and o["event"] == A.MGPU_EV_RENDER_DONE)
+        i_wait = next(i for i, o in enumerate(ops) if o["kind"] == A.MGPU_OP_WAIT and o["event"] == A.MGPU_EV_RENDER_DONE)
+        assert ops[i_rec]["stream"] == A.MGPU_STREAM_RENDER and ops[i_wait]["stream"] == A.MGPU_STREAM_COMM and 1 < i_rec < i_wait, (r, "render -> comm edge")
+        xfer = [i for i, o in enumerate(ops) if o["kind"] in (A.MGPU_OP_SEND, A.MGPU_OP_RECV)]
+        if n > 1:
+            gs, ge = kinds.index(A.MGPU_OP_GROUP_START), kinds.index(A.MGPU_OP_GROUP_END)
+            assert kinds.count(A.MGPU_OP_GROUP_START) == 1 and kinds.count(A.MGPU_OP_GROUP_END) == 1
+            assert i_wait < gs < min(xfer) and max(xfer) < ge, (r, "every transfer inside the one group, after the wait")
+        else:
+            assert not xfer and A.MGPU_OP_GROUP_START not in kinds
+        for i in xfer:
+            o = ops[i]
+            assert o["stream"] == A.MGPU_STREAM_COMM and o["bytes"] == shard
+            if o["kind"] == A.MGPU_OP_SEND:
+                assert r != 0 and o["peer"] == 0 and o["buffer"] == A.MGPU_BUF_LOCAL and o["offset"] == 0, (r, "send")
+                sends.append((r, o["peer"], o["bytes"]))
+            else:
+                assert r == 0 and o["buffer"] == A.MGPU_BUF_GATHER and o["offset"] == shard * o["peer"], (r, "recv offset = shardBytes * src")
+                recvs.append((o["peer"], r, o["bytes"]))
+        de = [i for i, k in enumerate(kinds) if k == A.MGPU_OP_DEINTERLEAVE]
+        if r == 0:
+            assert len(de) == 1 and ops[de[0]]["bytes"] == width * height * 4 and ops[de[0]]["buffer"] == A.MGPU_BUF_FULL and ops[de[0]]["stream"] == A.MGPU_STREAM_COMM
+            assert de[0] > (max(xfer) + 1 if xfer else i_wait), (r, "de-interleave after the group")
+        else:
+            assert not de
+        last = ops[-1]
+        assert last["kind"] == A.MGPU_OP_RECORD and last["event"] == A.MGPU_EV_COMM_DONE and last["stream"] == A.MGPU_STREAM_COMM, (r, "last op records the exchange")
+    # every send has its receive and the other way round; rank 0's buffer is covered exactly once
+    assert sorted(sends) == sorted(recvs), ("sends and receives do not pair up", sends, recvs)
+    assert sorted(src for src, _, _ in recvs) == list(range(1, n)), "one shard from every other rank"
+    covered = sorted([0] + [shard * src for src, _, _ in recvs])
+    assert covered == [shard * i for i in range(n)], "every shard lands once, at shardBytes * src"
+
+
+class PlanRunner:
+    """One rank's plan carried out on CPU.  `render_shard(shard_index, shard_count) -> uint32 array (rows x width)`."""
+
+    def __init__(self, rank, nranks, width, height, band_rows, render_shard, dist=None):
+        self.rank, self.n, self.W, self.H, self.band = rank, nranks, width, height, band_rows
+        self.render_shard, self.dist = render_shard, dist
+        rows = mgpu.shard_rows(height, band_rows, nranks)
+        self.shard_bytes = rows * width * 4
+        self.buf = {A.MGPU_BUF_LOCAL: np.zeros(self.shard_bytes, np.uint8)}
+        if rank == 0:
+            self.buf[A.MGPU_BUF_GATHER] = np.zeros(self.shard_bytes * nranks, np.uint8)
+            self.buf[A.MGPU_BUF_FULL] = np.zeros(width * height * 4, np.uint8)
+            self.buf[A.MGPU_BUF_LOCAL] = self.buf[A.MGPU_BUF_GATHER][:self.shard_bytes]     # rank 0's frame is bound to shard 0 of the gather buffer
+        self.recorded = set()
+        self.uses = 0
+
+    def run(self, ops):
+        import torch
+        group, in_group = [], False
+        for o in ops:
+            k = o["kind"]
+            if k == A.MGPU_OP_WAIT:
+                if o["event"] == A.MGPU_EV_COMM_DONE and self.uses == 0:
+                    continue                                   # first use of the slot: nothing recorded yet
+                assert o["event"] in self.recorded, ("waits for an event nobody recorded", o)
+            elif k == A.MGPU_OP_RECORD:
+                self.recorded.add(o["event"])
+            elif k == A.MGPU_OP_RENDER:
+                img = np.ascontiguousarray(self.render_shard(o["peer"], self.n)).view(np.uint8).reshape(-1)
+                assert img.size == o["bytes"], ("shard size", img.size, o["bytes"])
+                self.buf[o["buffer"]][o["offset"]:o["offset"] + o["bytes"]] = img
+            elif k == A.MGPU_OP_GROUP_START:
+                in_group = True
+            elif k in (A.MGPU_OP_SEND, A.MGPU_OP_RECV):
+                assert in_group, "a transfer outside a group"
+                view = torch.from_numpy(self.buf[o["buffer"]][o["offset"]:o["offset"] + o["bytes"]])
+                group.append((k, view, o["peer"]))
+            elif k == A.MGPU_OP_GROUP_END:
+                in_group = False
+                works = [(self.dist.isend(v, dst=p) if kk == A.MGPU_OP_SEND else self.dist.irecv(v, src=p)) for kk, v, p in group]
+                for w in works:
+                    w.wait()
+                group = []
+            elif k == A.MGPU_OP_DEINTERLEAVE:
+                rows = self.shard_bytes // (self.W * 4)
+                g = self.buf[A.MGPU_BUF_GATHER].view(np.uint32).reshape(self.n, rows, self.W)
+                self.buf[A.MGPU_BUF_FULL][:] = mgpu.assemble_numpy(g, self.H, self.band).view(np.uint8).reshape(-1)
+            else:
+                raise AssertionError(("unknown operation", o))
+        self.uses += 1
+
+    def full(self):
+        return self.buf[A.MGPU_BUF_FULL].view(np.uint32).reshape(self.H, self.W)

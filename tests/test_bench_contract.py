@@ -57,3 +57,27 @@ def test_bench_multi_rank_path_with_one_rank_through_rccl(scene_cache):
                env={"RTR_BENCH_FORCE_DIST": "1", "RTR_SCENE_CACHE": str(scene_cache), "MASTER_PORT": "29577"})
     assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0 and "librtr_mgpu.so" in d["verify"]["gather"]
     assert d["cpu_baseline"] is None and d["presented_frame"] is None and d["value"] > 0
+    assert d["rccl"]["nranks"] == 1 and d["rccl"]["nlocal"] == 1 and d["rccl"]["version"] > 20000 and "rtr_mgpu_create_rank" in d["rccl"]["launch"]
+
+
+def test_bench_in_process_multi_gpu_path_with_one_rank(scene_cache):
+    """`python bench.py --gpus N` started plainly drives the N devices from one process through rtr_mgpu_create; here that code path
+    with N = 1 (RTR_BENCH_FORCE_INPROC) and the shard sent to itself through RCCL."""
+    d = _bench(["--steps", "10", "--warmup", "2", "--width", "640", "--height", "360"],
+               env={"RTR_BENCH_FORCE_INPROC": "1", "RTR_MGPU_SELF_EXCHANGE": "1", "RTR_SCENE_CACHE": str(scene_cache)})
+    assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0 and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["rccl"]["nranks"] == 1 and d["rccl"]["nlocal"] == 1 and "rtr_mgpu_create " in d["rccl"]["launch"] + " "
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+
+
+def test_bench_more_gpus_than_present_fails_from_the_library(scene_cache):
+    """`python bench.py --gpus N` with N > the devices of the box: rc != 0 and the library's own message, not a launcher's."""
+    import torch
+    have = torch.cuda.device_count()
+    want = have + 1
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_SCENE_CACHE=str(scene_cache))
+    e.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2", "--warmup", "1"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert f"{want} devices requested, {have} present" in r.stderr + r.stdout, r.stderr[-2000:]

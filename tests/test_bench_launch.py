@@ -1,0 +1,59 @@
+"""How `bench.py --gpus N` gets its ranks (bench.py: launch_plan), without a GPU: started plainly, N > 1 runs in ONE process through
+rtr_mgpu_create; under torch.distributed.run every process is one rank; --launcher torchrun starts that launcher as a child with
+the same arguments.  --print-launch prints the decision and touches nothing."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plan(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTR_BENCH_FORCE_INPROC")):
+    e = {k: v for k, v in os.environ.items() if k not in drop}
+    e.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--print-launch"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_one_gpu_is_a_single_process():
+    d = _plan([])
+    assert d["mode"] == "single" and d["n_gpus"] == 1 and d["frames_in_flight"] == 4 and d["env_defaults"] == {}
+
+
+def test_started_plainly_n_gpus_run_in_one_process_through_the_library():
+    for n in (2, 4, 8):
+        d = _plan(["--gpus", str(n), "--steps", "5"])
+        assert d["mode"] == "inproc" and d["library_entry"] == "rtr_mgpu_create" and d["devices"] == list(range(n)) and d["world"] == n
+    # the N >= 4 settings live in bench.py, not in the caller's environment
+    assert _plan(["--gpus", "8"])["frames_in_flight"] == 8 and _plan(["--gpus", "8"])["env_defaults"] == {"GPU_MAX_HW_QUEUES": "8"}
+    assert _plan(["--gpus", "2"])["frames_in_flight"] == 4 and _plan(["--gpus", "8", "--frames-in-flight", "2"])["frames_in_flight"] == 2
+
+
+def test_under_torch_distributed_run_every_process_is_one_rank():
+    d = _plan(["--gpus", "4"], {"WORLD_SIZE": "4", "RANK": "2", "LOCAL_RANK": "2"})
+    assert d["mode"] == "rank" and d["library_entry"] == "rtr_mgpu_create_rank" and d["world"] == 4
+    d = _plan(["--gpus", "8"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert d["mode"] == "error" and "WORLD_SIZE=4" in d["why"]
+
+
+def test_torchrun_launcher_spawns_a_child_with_the_same_arguments():
+    d = _plan(["--gpus", "4", "--steps", "7", "--warmup", "2", "--launcher", "torchrun"])
+    assert d["mode"] == "torchrun-child"
+    a = d["argv"]
+    assert a[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in a and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(a[a.index("--master-port") + 1]) > 0
+    tail = a[a.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "2"]          # no --launcher: the ranks must not start grandchildren
+
+
+def test_plain_multi_gpu_start_without_a_gpu_fails_loudly_from_the_library():
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        return        # on a GPU box tests/test_bench_contract.py covers this invocation
+    assert r.returncode != 0 and "rtr_mgpu_create" in r.stderr and "no CPU fallback" in r.stderr

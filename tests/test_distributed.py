@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 (and 3) `gloo` process groups run the band sharding + the one gather step +
-the de-interleave, with the CPU oracle standing in for the renderer; the assembled frame must be bit-identical
-to the unsharded frame."""
+"""N>1 path on CPU: world_size-2 (and 3) `gloo` process groups carry out librtr_mgpu.so's OWN exchange plan (rtr_mgpu_plan — the
+operation list its enqueue() executes on the GPU: which rank sends what to whom, at which byte offset, grouped, behind which event)
+over gloo point-to-point calls, with the CPU oracle standing in for the renderer and a numpy restatement of k_deinterleave; the
+assembled frame must be bit-identical to the unsharded frame.  Two frames through the same slot, so the
+slot-reuse edge is walked too."""
 import os
 import socket
 import sys
@@ -49,25 +51,33 @@ def _free_port():
 def _worker(rank, world, port, cache, out_path):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RTR_SCENE_CACHE": cache})
     sys.path.insert(0, ROOT)
-    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     from realtimeraytracer_amd import _abi as A
     from realtimeraytracer_amd import api, scenes
     from oracle import oracle_py as O
+    import plan_exec as PE
     dist.init_process_group("gloo", rank=rank, world_size=world)
     W, H = 96, 52                                   # ragged: 6.5 bands -> padding rows on some ranks
     s = scenes.cornell_box(W, H)
     st, nodes, tris = api.host_build_bvh(s.desc)
-    p = api.make_params(W, H, spp=2, shard_index=rank, shard_count=world)
-    r = O.render(s.desc, s.camera, s.scene_info(1), p, bvh=(nodes, tris, st.grid), threads=2)
-    local = torch.from_numpy(r.images[A.IMAGE_SHADOWED].view(np.int32).copy())
-    gathered = mgpu.gather_to_root(dist, local, world, rank)
+    frame_no = [1]
+
+    def render_shard(index, count):                 # what RTR_MGPU_OP_RENDER stands for, by the oracle
+        p = api.make_params(W, H, spp=2, shard_index=index, shard_count=count)
+        return O.render(s.desc, s.camera, s.scene_info(frame_no[0]), p, bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
+    runner = PE.PlanRunner(rank, world, W, H, 8, render_shard, dist)
+    ops = PE.plan(rank, world, W, H, 8)             # this rank's operations, from the library
+    diffs = []
+    for f in (1, 2):                                # the second frame re-uses the slot: its first WAIT now has an event to wait for
+        frame_no[0] = f
+        runner.run(ops)
+        if rank == 0:
+            ref = O.render(s.desc, s.camera, s.scene_info(f), api.make_params(W, H, spp=2), bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
+            diffs.append(int((runner.full() != ref[:H]).sum()))
+        dist.barrier()
     if rank == 0:
-        full = mgpu.assemble_numpy(gathered.numpy().view(np.uint32), H, 8)
-        p1 = api.make_params(W, H, spp=2)
-        ref = O.render(s.desc, s.camera, s.scene_info(1), p1, bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
-        np.save(out_path, np.array([int((full != ref[:H]).sum()), full.shape[0], full.shape[1]]))
-    dist.barrier()
+        np.save(out_path, np.array(diffs + [H, W]))
     dist.destroy_process_group()
 
 
@@ -76,6 +86,6 @@ def test_sharded_frame_equals_single_frame_gloo(world, tmp_path, scene_cache):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.npy")
     mp.spawn(_worker, args=(world, _free_port(), scene_cache, out), nprocs=world, join=True)
-    diff, h, w = np.load(out)
+    d1, d2, h, w = np.load(out)
     assert (h, w) == (52, 96)
-    assert diff == 0, f"{diff} pixels differ between the gathered sharded frame and the single frame"
+    assert d1 == 0 and d2 == 0, f"{d1} / {d2} pixels differ between the frame assembled by the library's exchange plan and the single frame"

@@ -232,3 +232,21 @@ def test_wide_centre_follows_the_flat_ground_of_a_small_object_scene(gpu_ctx, or
     assert np.array_equal(f.download(), ref.images[A.IMAGE_SHADOWED])
     st = f.stats()
     assert (st.numShadowNodeVisits, st.numShadowTriTests) == (ref.stats.numShadowNodeVisits, ref.stats.numShadowTriTests)
+
+
+@pytest.mark.parametrize("which", ["cornell", "bunny", "sponza"])
+@pytest.mark.parametrize("collapse", ["cost", "greedy"])
+def test_device_wide_view_equals_its_host_restatement(gpu_ctx, scene_cache, which, collapse, monkeypatch):
+    """The records the any-hit kernel walks (k_wide_centre_* + k_wide_nodes following the host builder's shapes, or the greedy rule +
+    the breadth-first order) byte for byte against bvh_build.cpp's make_wide_host (rtr_host_build_bvh_wide), wide centre included —
+    what lets CPU-only runs price a tree change with the oracle's counters (profiles/experiments/tree_lab.py)."""
+    monkeypatch.setenv("RTR_BVH_WIDE_GREEDY", "1" if collapse == "greedy" else "0")
+    s = {"cornell": lambda: scenes.cornell_box(64, 64), "bunny": lambda: scenes.bunny_class(64, 64), "sponza": lambda: scenes.sponza_class(64, 64)}[which]()
+    scene = api.Scene(gpu_ctx, s.desc)
+    dev = scene.export_bvh()
+    host = api.host_build_bvh_wide(s.desc)
+    assert bytes(dev[0]) == bytes(host[0]) and bytes(dev[1]) == bytes(host[1])
+    g, h = scene.stats().grid, host.stats.grid
+    assert (g.wideCentreXY, g.wideCentreZ) == (h.wideCentreXY, h.wideCentreZ)
+    assert scene.stats().numWideNodes == host.stats.numWideNodes
+    assert bytes(dev.wide) == bytes(host.wide)

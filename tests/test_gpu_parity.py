@@ -648,33 +648,71 @@ def test_d6_occluded_sample_with_overflowing_contribution(gpu_ctx, oracle, scene
     _assert_same(f2.download(A.IMAGE_UNSHADOWED), ref2.images[A.IMAGE_UNSHADOWED], "D6 scene, unshadowed image")
 
 
+def _run_staged_child(code, env, timeout):
+    """A child process whose script announces every library call before making it (STAGE lines, flushed): when the child hangs, the
+    timeout says where it stopped instead of nothing (round 2's 240-s hang left only RCCL's banner on stdout)."""
+    import subprocess, sys
+    try:
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, (bytes, type(None))) else e.stdout
+        stages = [ln for ln in (out or "").splitlines() if ln.startswith("STAGE")]
+        raise AssertionError(f"child timed out after {timeout} s; last stage announced: {stages[-1] if stages else 'none'}\n" + (out or "")[-1500:])
+    return r
+
+
 def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
     """include/rtr_mgpu.h: the sharded frame behind the C ABI, ONE process driving every GPU of the box (1 on the test box) through a
     real RCCL communicator.  With one rank RTR_MGPU_SELF_EXCHANGE=1 makes the shard travel through grouped ncclSend / ncclRecv
     all the same, so communicator, communication stream, events, gather buffer and k_deinterleave are exercised; two frame slots
-    are kept in flight.  Assembled frame == unsharded frame == oracle, 0 pixels."""
-    import subprocess, sys, textwrap
+    are kept in flight.  Assembled frame == unsharded frame == oracle, 0 pixels.  The library's watchdog is set below the test's own
+    timeout, so a stuck exchange comes back as an error that names the stage."""
+    import textwrap
     # its own process: RCCL initialises its own state, and a failure (or a hang, hence the timeout) must not take the suite down
     code = textwrap.dedent("""
         import os, sys
         sys.path.insert(0, os.getcwd())
+        def stage(s): print("STAGE", s, flush=True)
+        stage("imports")
         import numpy as np, torch
         from realtimeraytracer_amd import _abi as A, api, mgpu, scenes
         from oracle import oracle_py as O
         n = torch.cuda.device_count()
         W, H = 640, 360
         s = scenes.cornell_box(W, H)
+        stage("rtr_mgpu_create")
         m = mgpu.MultiGpu(devices=list(range(n)), frames_in_flight=2)
         assert m.info.nranks == n and m.info.nlocal == n and m.info.selfExchange == (1 if os.environ.get("RTR_MGPU_SELF_EXCHANGE") == "1" else 0)
+        assert m.info.aborted == 0 and m.info.timeoutMs == 60000 and m.info.rcclVersion > 20000
+        stage("rtr_mgpu_scene_create")
         m.scene_create(s.desc)
         p = api.make_params(W, H, spp=2)
+        stage("rtr_mgpu_render_async slot 0")
         m.render_async(0, s.camera, s.scene_info(0), p)
+        stage("rtr_mgpu_render_async slot 1")
         m.render_async(1, s.camera, s.scene_info(1), p)          # second slot in flight behind the first
-        m.wait(0); m.wait(1)
+        stage("rtr_mgpu_wait slot 0")
+        m.wait(0)
+        stage("rtr_mgpu_wait slot 1")
+        m.wait(1)
+        stage("rtr_mgpu_frame_download")
         got0, got1 = m.download(0), m.download(1)
+        stage("rtr_mgpu_render_async slot 0 again")
         m.render_async(0, s.camera, s.scene_info(2), p)          # slot reuse: ordered behind its previous exchange by an event
+        try:
+            m.frame_device_ptr(0)
+            raise SystemExit("rtr_mgpu_frame_device_ptr answered for a slot in flight")
+        except RuntimeError as e:
+            assert "in flight" in str(e)
+        stage("rtr_mgpu_wait slot 0 again")
         m.wait(0)
         got2 = m.download(0)
+        stage("another extent through the same slot")
+        p2 = api.make_params(320, 184, spp=1)
+        m.render_async(1, s.camera, s.scene_info(0), p2)         # the slot is re-created (phase 1 on every rank, joined) before anything is posted
+        m.wait(1)
+        small = m.download(1)
+        stage("reference renders")
         ctx = api.Context(0)
         scene = api.Scene(ctx, s.desc)
         frame = api.Frame(ctx, W, H)
@@ -685,11 +723,37 @@ def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
             assert int((got != whole).sum()) == 0, ("assembled vs unsharded", f, int((got != whole).sum()))
             ref = O.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, threads=8)
             assert int((got != ref.images[A.IMAGE_SHADOWED]).sum()) == 0, ("assembled vs oracle", f)
+        frame2 = api.Frame(ctx, 320, 184)
+        api.render(scene, s.camera, s.scene_info(0), p2, frame2)
+        assert int((small != frame2.download()).sum()) == 0, "assembled vs unsharded, second extent"
         shard = m.download_shard(0, 0)
         assert shard.shape == (api.shard_rows(H, 8, n), W)
+        stage("rtr_mgpu_destroy")
         m.close()
         print("MGPU_OK", n)
     """)
-    env = dict(os.environ, RTR_MGPU_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    env = dict(os.environ, RTR_MGPU_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_MGPU_TIMEOUT_MS="60000")
+    r = _run_staged_child(code, env, 240)
     assert r.returncode == 0 and "MGPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_scene_create_like_uploads_the_tree_without_building_it(gpu_ctx, scene_cache):
+    """rtr_scene_create_like: the replica renders the same bytes, reports the same tree and did not spend a build (what
+    rtr_mgpu_scene_create replicates the scene with); a description of another size is refused."""
+    s = scenes.bunny_class(320, 184)
+    a = api.Scene(gpu_ctx, s.desc)
+    ctx2 = api.Context(0)
+    b = api.Scene(ctx2, s.desc, like=a)
+    sa, sb = a.stats(), b.stats()
+    assert (sa.numTriangles, sa.numNodes, sa.maxDepth, sa.stackEntries, sa.numWideNodes) == (sb.numTriangles, sb.numNodes, sb.maxDepth, sb.stackEntries, sb.numWideNodes)
+    assert sb.buildMs == 0.0 and sa.buildMs > 0.0
+    assert bytes(a.export_bvh()[0]) == bytes(b.export_bvh()[0])
+    p = api.make_params(320, 184, spp=1, collect_stats=1)
+    fa, fb = api.Frame(gpu_ctx, 320, 184), api.Frame(ctx2, 320, 184)
+    api.render(a, s.camera, s.scene_info(3), p, fa)
+    api.render(b, s.camera, s.scene_info(3), p, fb)
+    _assert_same(fa.download(), fb.download(), "scene made by rtr_scene_create_like")
+    assert fa.stats().numShadowNodeVisits == fb.stats().numShadowNodeVisits
+    other = scenes.cornell_box(64, 64)
+    with pytest.raises(api.RtrError):
+        api.Scene(ctx2, other.desc, like=a)

@@ -1,0 +1,106 @@
+"""The exchange of librtr_mgpu.so with more than one rank in it, on a CPU-only box: rtr_mgpu_plan() returns the list of operations
+enqueue() executes for a rank (it IS that code path: csrc/mgpu/rtr_mgpu.cpp walks the same list), so a wrong offset, a missing
+receive, an ungrouped transfer or a missing event edge in the library turns these red.  N = 1 ... 16, ragged extents, both flags."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from realtimeraytracer_amd import _abi as A
+from realtimeraytracer_amd import mgpu
+
+import plan_exec as PE
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 16])
+@pytest.mark.parametrize("extent", [(1920, 1080, 8), (96, 52, 8), (7, 7, 8), (3840, 2160, 16), (640, 360, 24)])
+def test_plans_pair_up_and_cover_the_gather_buffer(n, extent):
+    W, H, band = extent
+    plans = [PE.plan(r, n, W, H, band) for r in range(n)]
+    PE.check_plans(plans, W, H, band)
+    assert all(len(p) <= A.MGPU_PLAN_MAX_OPS for p in plans)
+    # the operation count of rank 0 is what RTR_MGPU_PLAN_MAX_OPS documents: 8 + (n - 1) with an exchange, 6 for one rank
+    assert len(plans[0]) == (8 + (n - 1) if n > 1 else 6)
+
+
+def test_checker_catches_a_wrong_offset_a_missing_receive_and_an_ungrouped_send():
+    W, H, band, n = 96, 52, 8, 4
+    good = [PE.plan(r, n, W, H, band) for r in range(n)]
+    PE.check_plans(good, W, H, band)
+
+    def mutated(fn):
+        plans = [[dict(o) for o in p] for p in good]
+        fn(plans)
+        return plans
+    recv = [i for i, o in enumerate(good[0]) if o["kind"] == A.MGPU_OP_RECV]
+
+    def wrong_offset(p): p[0][recv[1]]["offset"] += 4
+    def missing_recv(p): del p[0][recv[2]]
+    def ungrouped(p): p[2][:] = [o for o in p[2] if o["kind"] not in (A.MGPU_OP_GROUP_START, A.MGPU_OP_GROUP_END)]
+    def no_render_edge(p): p[1][:] = [o for o in p[1] if not (o["kind"] == A.MGPU_OP_WAIT and o["event"] == A.MGPU_EV_RENDER_DONE)]
+    def no_slot_guard(p): del p[3][0]
+    def swapped_peer(p): p[0][recv[0]]["peer"], p[0][recv[1]]["peer"] = p[0][recv[1]]["peer"], p[0][recv[0]]["peer"]
+    for fn in (wrong_offset, missing_recv, ungrouped, no_render_edge, no_slot_guard, swapped_peer):
+        with pytest.raises((AssertionError, ValueError, StopIteration)):
+            PE.check_plans(mutated(fn), W, H, band)
+
+
+def test_no_exchange_flag_renders_only_and_self_exchange_is_grouped():
+    ops = PE.plan(2, 4, 640, 360, 8, flags=A.MGPU_NO_EXCHANGE)
+    assert [o["kind"] for o in ops] == [A.MGPU_OP_WAIT, A.MGPU_OP_RENDER]
+    ops = PE.plan(0, 1, 640, 360, 8, self_exchange=1)
+    kinds = [o["kind"] for o in ops]
+    gs, ge = kinds.index(A.MGPU_OP_GROUP_START), kinds.index(A.MGPU_OP_GROUP_END)
+    inside = ops[gs + 1:ge]
+    # a rank's send to itself and the receive that matches it sit in ONE group: one behind the other on a stream they never complete
+    assert [o["kind"] for o in inside] == [A.MGPU_OP_SEND, A.MGPU_OP_RECV]
+    assert inside[0]["buffer"] == A.MGPU_BUF_SELF_SRC and inside[1]["buffer"] == A.MGPU_BUF_GATHER and inside[0]["bytes"] == inside[1]["bytes"] == 360 * 640 * 4
+    assert ops[1]["kind"] == A.MGPU_OP_RENDER and ops[1]["buffer"] == A.MGPU_BUF_SELF_SRC
+    # without the hook a one-rank communicator exchanges nothing
+    assert not [o for o in PE.plan(0, 1, 640, 360, 8) if o["kind"] in (A.MGPU_OP_SEND, A.MGPU_OP_RECV, A.MGPU_OP_GROUP_START)]
+
+
+def test_plan_refuses_bad_arguments():
+    lib = A.mgpu_lib()
+    ops = (A.rtr_mgpu_op * A.MGPU_PLAN_MAX_OPS)()
+    n = C.c_int(0)
+    for args in ((2, 2, 8, 8), (-1, 2, 8, 8), (0, 0, 8, 8), (0, A.MGPU_MAX_RANKS + 1, 8, 8), (0, 2, 0, 8), (0, 2, 8, 0)):
+        assert lib.rtr_mgpu_plan(args[0], args[1], args[2], args[3], 8, 0, 0, ops, A.MGPU_PLAN_MAX_OPS, C.byref(n)) == -1
+    assert lib.rtr_mgpu_plan(0, 8, 64, 64, 8, 0, 0, ops, 3, C.byref(n)) == -1      # no room
+    assert b"room for 3" in lib.rtr_mgpu_last_error()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8])
+def test_plans_executed_in_one_process_assemble_the_frame(n):
+    """All ranks' plans run against an in-memory mailbox standing in for the transport: a synthetic image whose pixel value encodes
+    (y, x) comes back assembled, twice (slot reuse waits for the previous exchange)."""
+    W, H, band = 40, 52, 8
+    truth = (np.arange(H, dtype=np.uint32)[:, None] << 16) | np.arange(W, dtype=np.uint32)[None, :]
+
+    def shard_of(idx, cnt):
+        ys = mgpu.global_rows_of_shard(H, band, cnt, idx)
+        out = np.zeros((len(ys), W), np.uint32)
+        out[ys >= 0] = truth[ys[ys >= 0]]
+        return out
+
+    class Mailbox:
+        def __init__(self): self.box = {}
+        class _W:
+            def __init__(self, fn): self.fn = fn
+            def wait(self): self.fn()
+    mail = {}
+
+    class Dist:
+        def __init__(self, me): self.me = me
+        def isend(self, v, dst):
+            mail[(self.me, dst)] = v.clone()
+            return Mailbox._W(lambda: None)
+        def irecv(self, v, src):
+            me = self.me
+            return Mailbox._W(lambda: v.copy_(mail.pop((src, me))))
+    runners = [PE.PlanRunner(r, n, W, H, band, shard_of, Dist(r)) for r in range(n)]
+    for _ in range(2):
+        for r in range(n - 1, -1, -1):          # senders first: the mailbox has no blocking
+            runners[r].run(PE.plan(r, n, W, H, band))
+        assert np.array_equal(runners[0].full(), truth)
+        assert not mail
