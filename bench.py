@@ -566,11 +566,14 @@ def main():
         bracket_ms = kern["shadow_trace"] / n                      # in-region HIP-event bracket
         trace_ms = kern_iso["shadow_trace"] if kern_iso else bracket_ms
         trace_bytes = fs.shadowTraceBytes                         # rank 0's launch
-        roofline = None
+        roofline, roofline2, frame_hbm = None, None, None
         if pipeline_used == 2 and trace_ms > 0:
             rev = A.hip_lib().rtr_kernel_revision().decode()
             pmc, pmc_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02", "pmc_roofline.json")
+            # The counter totals are NOT measured by this process (rocprofv3 has to wrap it): they are the committed passes of the same
+            # command (profiles/pmc_r03.sh -> profiles/r03/pmc_roofline.json) and are only used when they describe THIS run — same
+            # workload key, kernel revision, triangle count and queue length (= the shadow rays the counting form counted just now)
+            tpath = os.path.join(ROOT, "profiles", "r03", "pmc_roofline.json")
             key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
             try:
                 pmc = json.load(open(tpath)).get(key)
@@ -578,6 +581,9 @@ def main():
                     pmc_note = f"no committed counter passes for {key}"
                 elif pmc.get("kernel_revision") != rev:
                     pmc, pmc_note = None, f"committed counters are of kernel revision {pmc.get('kernel_revision')}, this library is {rev}"
+                elif pmc.get("triangles") != int(sstats.numTriangles) or pmc.get("rays_per_launch") != sched["shadow_rays"]:
+                    pmc, pmc_note = None, (f"committed counters are of a launch over {pmc.get('triangles')} triangles / {pmc.get('rays_per_launch')} queued rays, "
+                                           f"this run has {int(sstats.numTriangles)} / {sched['shadow_rays']}")
             except Exception as e:      # noqa: BLE001
                 pmc_note = f"{tpath}: {e}"
             ck = clocks_iso if (kern_iso and clocks_iso) else clocks
@@ -625,8 +631,28 @@ def main():
                 "algorithmic_bytes_per_launch": int(trace_bytes),
                 "algorithmic_gbps": round(trace_bytes / (trace_ms * 1e-3) / 1e9, 1),
                 "algorithmic_over_hbm_peak": round(trace_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "pmc_source": "profiles/r02/pmc_roofline.json" if pmc else None, "pmc_note": pmc_note,
+                "pmc_source": "profiles/r03/pmc_roofline.json" if pmc else None, "pmc_note": pmc_note,
+                "counters": ("achieved, traffic, l2_frac, l1_tag_lookups and valu_* are DERIVED FROM COMMITTED rocprofv3 counter passes of this command "
+                             "(checked against this run: workload, kernel revision, triangles, queue length); avg_launch_ms, clock_mhz, lane_util, per_ray, schedule "
+                             "and algorithmic_* are measured by this process") if pmc else None,
                 "layout": {"bvh": int(sstats.bvhLayoutVersion), "wide": int(sstats.wideLayoutVersion)}}
+            if pmc and pmc.get("kernels", {}).get("k_shadow_gen_oct") and kern_iso:
+                # the one kernel of the frame that IS bound by HBM: it writes the ray queue (32 B per ray) as fast as the memory takes it
+                g = pmc["kernels"]["k_shadow_gen_oct"]
+                gen_ms = kern_iso["shadow_gen"]
+                gbytes = g["read_bytes"] + g["write_bytes"]
+                roofline2 = {"bound": "hbm", "kernel": "k_shadow_gen_oct: shadow-ray generation into the queue binned by direction octant",
+                             "achieved": round(gbytes / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "frac_of_measured_copy_rate": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS, 4),
+                             "traffic": gbytes, "read_bytes": g["read_bytes"], "write_bytes": g["write_bytes"],
+                             "algorithmic_bytes_per_launch": int(20 * sched["shadow_rays"] + (20 + 16) * fs.numPrimaryRays),      # 20-B ray records + 16-B origins out, 20-B hit records in
+                             "avg_launch_ms": round(gen_ms, 4), "avg_launch_ms_source": "HIP events on the launch stream, frames rendered one at a time (this run)",
+                             "counters": "bytes from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; FETCH_SIZE's streamed part doubled, gfx950), duration from this run"}
+                fb = pmc.get("frame_hbm_bytes")
+                frame_hbm = {"bytes_per_frame": fb, "per_kernel": {kk: vv["read_bytes"] + vv["write_bytes"] for kk, vv in pmc["kernels"].items()},
+                             "gbps_at_ms_per_step": round(fb / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(fb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "scope": "sum of the frame's four kernels' HBM bytes (committed counter passes) over this run's frame time with frames in flight"} if fb else None
         elif trace_ms == 0 and kern["primary"] > 0:
             mk_ms = kern["primary"] / n
             achieved = fs.algorithmicBytes / (mk_ms * 1e-3) / 1e9
@@ -653,6 +679,8 @@ def main():
                                     "frames": args.isolated_frames, "scope": "rank 0's shard, no gather"} if iso_ms_per_frame else None,
             "algorithmic_gbps_all_kernels": round(counts[3].item() * K / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": roofline,
+            "roofline_secondary": roofline2,
+            "frame_hbm": frame_hbm,
             "presented_frame": presented,
         }
 

@@ -161,7 +161,7 @@ typedef struct rtr_frame_stats {
     /* the any-hit share of the above (work of the k_shadow_trace launch, the dominant kernel) */
     uint64_t numShadowNodeVisits;
     uint64_t numShadowTriTests;
-    uint64_t shadowTraceBytes; /* 64 N_node_shadow (RTR_WIDE_NODE_BYTES: 4-wide records visited; 32 in the megakernel, which walks the BVH2) + 48 N_tri_shadow + 32 N_shadow_rays (queue read) + N_shadow_rays (visibility write) */
+    uint64_t shadowTraceBytes; /* 64 N_node_shadow (RTR_WIDE_NODE_BYTES: 4-wide records visited; 32 in the megakernel, which walks the BVH2) + 48 N_tri_shadow + 37 N_shadow_rays (20-B queue record + the 16-B origin its pixel-sample's rays share + the visibility byte) */
     /* timings of the last render (HIP events on the render stream), milliseconds */
     float    totalMs;
     float    primaryMs;        /* k_primary (wavefront) or the whole megakernel */

@@ -722,7 +722,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.numShadowNodeVisits = tot.shadowNodes; st.numShadowTriTests = tot.shadowTris;
     st.numTexFetches = tot.texFetch; st.numAlphaTests = tot.alphaTests;
     const uint64_t shadowNodeBytes = sc.useWide ? RTR_WIDE_NODE_BYTES : RTR_BVH_NODE_BYTES;
-    st.shadowTraceBytes = shadowNodeBytes * tot.shadowNodes + 48 * tot.shadowTris + 33 * tot.shadow;
+    st.shadowTraceBytes = shadowNodeBytes * tot.shadowNodes + 48 * tot.shadowTris + 37 * tot.shadow;   /* per ray: 20-B queue record + 16-B origin of its pixel-sample + visibility byte */
     st.primaryTailRays = tot.primaryOverflow;
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;

@@ -1,23 +1,51 @@
 #!/usr/bin/env python3
-"""profiles/make_pmc_json.py <gpurun_out/prof_TAG/pmc.json> <workload key> <kernel revision> <rays per launch> > profiles/r02/pmc_roofline.json
-Turns the per-kernel counter means of profiles/pmc_r02.sh into the per-launch figures bench.py's roofline block reads, with the
-gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section) applied and spelled out."""
+"""profiles/make_pmc_json.py <gpurun_out/prof_TAG/pmc.json> <workload key> <kernel revision> <rays per launch> <pixel-samples> <triangles> > profiles/r03/pmc_roofline.json
+Turns the per-kernel counter means of profiles/pmc_r03.sh into the per-launch figures bench.py reads: the any-hit kernel's issue /
+L1 / HBM counters (its roofline block), and the HBM bytes of every kernel of the frame (roofline_secondary for the queue-build
+kernel, frame_hbm), with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section) applied and spelled out:
+FETCH_SIZE tallies a wide coalesced streaming read at 1/2 of its bytes, everything else at the bytes moved; WRITE_SIZE is exact."""
 import json
 import sys
 
-src, key, rev, rays = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+src, key, rev, rays, nps, ntri = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
 pmc = json.load(open(src))
-name = [k for k in pmc if "k_shadow_trace4<16, true, false>" in k or "k_shadow_trace4<16, false, false>" in k]
-k = pmc[name[0]]
-queue_bytes = rays * 32                          # the ray queue: a wide coalesced stream, which FETCH_SIZE tallies at 1/2 (guide; calibrated in profiles/r01/fetch_calibration.txt)
-fetch_kb, write_kb = k["FETCH_SIZE"], k["WRITE_SIZE"]
-rest_kb = fetch_kb - queue_bytes / 2 / 1024      # node / triangle lines that missed L2 + queue lines fetched twice: counted at the bytes moved
-read_bytes = queue_bytes + rest_kb * 1024
+
+
+def pick(*needles):
+    for k in pmc:
+        if all(n in k for n in needles) and ", true>" not in k.replace("<16, true, false>", "").replace("<16, false, false>", ""):
+            return k, pmc[k]
+    raise SystemExit(f"no kernel matching {needles} in {src}")
+
+
+name, k = pick("k_shadow_trace4<16, true, false>") if any("k_shadow_trace4<16, true, false>" in x for x in pmc) else pick("k_shadow_trace4<16, false, false>")
+
+
+def hbm(entry, stream_read_bytes):
+    """reads: the streamed part (known size) shows in FETCH_SIZE at half its bytes, the rest at the bytes moved; writes exact"""
+    fetch, write = entry.get("FETCH_SIZE", 0.0) * 1024, entry.get("WRITE_SIZE", 0.0) * 1024
+    rest = max(fetch - stream_read_bytes / 2, 0.0)
+    return {"read_bytes": int(stream_read_bytes + rest), "write_bytes": int(write), "FETCH_SIZE_KB": entry.get("FETCH_SIZE"), "WRITE_SIZE_KB": entry.get("WRITE_SIZE"),
+            "streamed_read_bytes": int(stream_read_bytes), "rocprof_avg_ms": entry.get("avg_ms"), "rocprof_calls": entry.get("calls")}
+
+
+queue_bytes, hit_bytes = rays * 20, nps * 20          # the queue's streamed part: 16-B (direction, tmax) + 4-B slot per ray; the 16-B origins are gathered through the caches
+kernels = {}
+for short, needles, stream in (("k_primary", ("k_primary<", "false"), 0), ("k_shadow_gen_oct", ("k_shadow_gen_oct",), hit_bytes),
+                               ("k_shadow_trace4", (name,), queue_bytes), ("k_resolve", ("k_resolve<false>",), hit_bytes)):
+    try:
+        kn, e = pick(*needles)
+    except SystemExit:
+        continue
+    kernels[short] = dict(hbm(e, stream), kernel=kn)
+frame_bytes = sum(v["read_bytes"] + v["write_bytes"] for v in kernels.values())
+t = kernels["k_shadow_trace4"]
 out = {
-    "_comment": "per-launch counters of the any-hit kernel from rocprofv3 --pmc passes (profiles/pmc_r02.sh: --kernel-trace only, one "
-                "pass per counter group, frames rendered one at a time); read by bench.py for its roofline block",
+    "_comment": "per-launch counters from rocprofv3 --pmc passes (profiles/pmc_r03.sh: --kernel-trace only, one counter group per pass, frames "
+                "rendered one at a time); read by bench.py for its roofline, roofline_secondary and frame_hbm blocks, which check workload, "
+                "kernel revision, triangle count and queue length against the run before using them",
     key: {
-        "kernel": name[0], "kernel_revision": rev, "rays_per_launch": rays,
+        "kernel": name, "kernel_revision": rev, "rays_per_launch": rays, "pixel_samples": nps, "triangles": ntri,
         "rocprof_avg_launch_ms": k["avg_ms"], "rocprof_calls": k["calls"],
         "SQ_WAVES": k["SQ_WAVES"], "SQ_WAVE_CYCLES_quad": k["SQ_WAVE_CYCLES"],
         "SQ_INSTS_VALU": k["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad": k["SQ_ACTIVE_INST_VALU"],
@@ -26,11 +54,14 @@ out = {
         "GRBM_GUI_ACTIVE_sum_over_xcds": k["GRBM_GUI_ACTIVE"],
         "TCP_TOTAL_CACHE_ACCESSES": k["TCP_TOTAL_CACHE_ACCESSES_sum"], "TCP_TCC_READ_REQ": k["TCP_TCC_READ_REQ_sum"],
         "TCC_HIT": k["TCC_HIT_sum"], "TCC_MISS": k["TCC_MISS_sum"],
-        "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-        "hbm_bytes_per_launch": int(read_bytes + write_kb * 1024),
-        "hbm_derivation": f"reads: ray queue {rays} x 32 B = {queue_bytes / 1e6:.1f} MB (a coalesced stream: FETCH_SIZE shows 1/2 of it = {queue_bytes / 2048:.0f} KB) "
-                          f"+ remaining {rest_kb:.0f} KB of node / triangle lines that missed L2 (counted at the bytes moved) = {read_bytes / 1e6:.1f} MB; "
-                          f"writes: WRITE_SIZE {write_kb:.0f} KB = {write_kb * 1024 / 1e6:.1f} MB (one visibility byte per ray, partial lines)",
+        "FETCH_SIZE_KB": k["FETCH_SIZE"], "WRITE_SIZE_KB": k["WRITE_SIZE"],
+        "hbm_bytes_per_launch": t["read_bytes"] + t["write_bytes"],
+        "hbm_derivation": f"reads: ray queue {rays} x 20 B = {queue_bytes / 1e6:.1f} MB (a coalesced stream: FETCH_SIZE shows 1/2 of it) + the remaining "
+                          f"{(t['read_bytes'] - queue_bytes) / 1e6:.1f} MB of node / triangle lines that missed L2 (counted at the bytes moved) = {t['read_bytes'] / 1e6:.1f} MB; "
+                          f"writes: WRITE_SIZE = {t['write_bytes'] / 1e6:.1f} MB for {rays / 1e6:.1f} MB of visibility bytes (query-major planes: a wave's 64 results are 64 consecutive bytes; "
+                          f"the lanes of a wave retire in several refill passes and every pass's bytes leave the L2 as 32-B sectors)",
+        "kernels": kernels,
+        "frame_hbm_bytes": frame_bytes,
         "derived": {
             "shader_cycles_per_wave": k["SQ_WAVE_CYCLES"] * 4 / k["SQ_WAVES"],
             "clock_mhz_from_wave_cycles": k["SQ_WAVE_CYCLES"] * 4 / k["SQ_WAVES"] / (k["avg_ms"] * 1e3),

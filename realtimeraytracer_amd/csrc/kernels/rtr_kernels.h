@@ -8,7 +8,7 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
-#define RTR_ANYHIT_KERNEL_REVISION "r03.1"
+#define RTR_ANYHIT_KERNEL_REVISION "r03.2"
 
 constexpr uint32_t kQueueRegions = 8;                       /* one batch cursor per XCD: eight times the atomic rate of one counter */
 constexpr uint32_t kQueueLists = kQueueRegions * kQueueRegions;        /* batch lists of the binned queue: (direction octant, consumer XCD) */
@@ -17,18 +17,35 @@ constexpr uint32_t kPrimaryCursors = kQueueListLens + kQueueLists;   /* kQueueRe
 constexpr uint32_t kQueueCtrlWords = kPrimaryCursors + 16 * kQueueRegions;
 static_assert(kQueueLists == 64, "k_shadow_gen_oct reserves the batch lists with one lane per list");
 
+constexpr size_t kSpillInts = (size_t)64 * 64 * 256;     /* full-depth stacks of the two redo kernels: 64 entries x (64 workgroups x 256 lanes) */
+
+/* The shadow-ray queue: 20 B per ray + 16 B per pixel-sample.  A pixel-sample's rays (up to 13 on the bench frame) all start at the
+ * same point, so the origin is stored once per pixel-sample and a ray record is its direction, its far limit and the index of its
+ * visibility byte; that index also names the pixel-sample (slot & slotMask: the planes of the visibility array are slotStride =
+ * a power of two apart).  32-B records with the origin in every ray made the queue 0.79 GB per 1080p frame, written by a kernel that
+ * is bound by exactly those writes. */
+struct RayQueue {
+    float4*   dt = nullptr;          /* per ray: direction xyz, tmax */
+    uint32_t* slot = nullptr;        /* per ray: visibility index = query * slotStride + pixel-sample */
+    float4*   origin = nullptr;      /* per pixel-sample: origin of its shadow rays (hit point + 0.01 normal) */
+    uint32_t  slotStride = 0;        /* power of two >= pixel-sample slots of the frame */
+    uint32_t  slotMask = 0;          /* slotStride - 1 */
+};
+
 /* Scratch of the wavefront (staged) pipeline, owned by an rtr_frame. */
+
 struct Workspace {
     float4*   hitTuvp = nullptr;     /* per (pixel,sample): t,u,v,bits(primitiveID) */
     uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
-    float4*   rayQueue = nullptr;    /* 2 x float4 per queued shadow ray: (o.xyz,tmax) (d.xyz,bits(slot)) */
-    uint8_t*  vis = nullptr;         /* per slot: 1 = occluded */
+    RayQueue  rayQueue;              /* the queued shadow rays */
+    uint8_t*  vis = nullptr;         /* per slot (query-major planes, rayQueue.slotStride apart): 1 = occluded */
     uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [16 + 16 r] batch cursor of queue region r (2-wide kernel, r < 8) or of batch list r = octant * 8 + xcd (64 B apart: a cursor is hammered by one XCD's waves), [kQueueListLens + r] length of list r, [kPrimaryCursors + 16 r] batch cursor of region r of the camera rays (k_primary_persist) */
     uint2*    batchLists = nullptr;  /* kQueueLists lists of listStride batches {first queue index, rays}: the queue binned by direction octant */
     uint32_t  listStride = 0;
-    uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail (capacity: one per slot) */
+    uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail: overflowCap entries; a count past the capacity makes k_shadow_tail redo the whole queue */
+    uint32_t  overflowCap = 0;
     unsigned long long* clk = nullptr;   /* 2 x kQueueRegions words: {shader-clock ticks, 100-MHz ticks} of the any-hit launch, one wave per XCD */
-    int32_t*  spill = nullptr;       /* traversal-stack overflow of k_shadow_trace: 48 entries x (2048 workgroups x 256 lanes) */
+    int32_t*  spill = nullptr;       /* full-depth traversal stacks of the two redo kernels: kSpillInts = 64 entries x (64 workgroups x 256 lanes) */
     size_t    capPixelSamples = 0;
     size_t    capRays = 0;
 };

@@ -39,6 +39,30 @@ struct InlinePolicy {
     }
 };
 
+/* The ray queue is written once and read once, 0.8 GB per 1080p frame.  READ past the caches (nt) it does not push the tree's lines
+ * out of the L1s and L2s on its way through: the any-hit kernel 1.74 -> 1.71 ms alone and the frame 2.305 -> 2.245 ms with four in
+ * flight.  WRITING it that way costs the queue-build kernel its write combining (0.238 -> 0.313 ms, 0.78 -> 0.99 GB of HBM writes), so
+ * only the loads are streamed (profiles/r03/ab_deferred_leaf_and_nt_queue.log, ab_nt_split.log). */
+typedef float rtr_f4 __attribute__((ext_vector_type(4)));
+/* one ray out of the queue: direction + far limit, visibility index, and the origin its pixel-sample's rays share */
+__device__ __forceinline__ void queue_load(const RayQueue& q, uint32_t ray, rtr_v3& o, rtr_v3& d, float& tmax, uint32_t& slot, uint32_t nt) {
+    float4 a;
+    if (nt) {
+        const rtr_f4 x = __builtin_nontemporal_load(reinterpret_cast<const rtr_f4*>(q.dt + ray));
+        a = make_float4(x.x, x.y, x.z, x.w);
+        slot = __builtin_nontemporal_load(q.slot + ray);
+    } else { a = q.dt[ray]; slot = q.slot[ray]; }
+    const float4 og = q.origin[slot & q.slotMask];
+    o = rtr_mk(og.x, og.y, og.z); d = rtr_mk(a.x, a.y, a.z); tmax = a.w;
+}
+__device__ __forceinline__ void queue_store(const RayQueue& q, size_t idx, rtr_v3 o, rtr_v3 d, float tmax, uint32_t slot, uint32_t nt) {
+    if (slot < q.slotStride) q.origin[slot] = make_float4(o.x, o.y, o.z, 0.f);          /* the pixel-sample's first query (query 0: slot = pixel-sample) */
+    if (nt) {
+        __builtin_nontemporal_store(rtr_f4{d.x, d.y, d.z, tmax}, reinterpret_cast<rtr_f4*>(q.dt + idx));
+        __builtin_nontemporal_store(slot, q.slot + idx);
+    } else { q.dt[idx] = make_float4(d.x, d.y, d.z, tmax); q.slot[idx] = slot; }
+}
+
 /* Wave-level active-ray compaction, two phases so the global queue sees ONE atomic per wave
  * (a single contended counter saturates near 88 atomics/us on this chip — with an atomic per
  * emission step k_shadow_gen spent 4.5 ms of a 12 ms frame on it):
@@ -64,16 +88,14 @@ struct EmitPolicy {
      * query of 64 neighbouring pixels) are 64 consecutive bytes, whole 32-B sectors written by one wave from one XCD.  Pixel-major
      * (k * maxRays + j) had every byte of a sector written by another wave, mostly on another XCD, at another time: 522 MB of HBM
      * writes for 24.8 MB of payload (profiles/r02/pmc_roofline.json). */
-    float4* queue; lds_word waveOffset; uint32_t base; uint32_t slot, slotStride;
+    RayQueue queue; lds_word waveOffset; uint32_t base; uint32_t slot;
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         const uint32_t off = *waveOffset;                      /* same LDS word for the whole wave: broadcast read */
         if (prefix == 0) *waveOffset = off + (uint32_t)__popcll(m);
-        const size_t idx = (size_t)(base + off + prefix) * 2;
-        queue[idx] = make_float4(o.x, o.y, o.z, tmax);
-        queue[idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
-        slot += slotStride;
+        queue_store(queue, (size_t)(base + off + prefix), o, d, tmax, slot, 0u);
+        slot += queue.slotStride;
         return false;
     }
 };
@@ -106,7 +128,7 @@ struct CountOctPolicy {
 struct EmitOctPolicy {
     static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;
-    float4* queue; lds_word run; uint32_t slot, slotStride;         /* run[o]: next queue index of this wave's part of the octant-o run; slot / slotStride as in EmitPolicy */
+    RayQueue queue; lds_word run; uint32_t slot, nt;         /* run[o]: next queue index of this wave's part of the octant-o run; slot as in EmitPolicy */
     __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw) {
         const uint32_t oct = raw_octant(raw);
         unsigned long long rem = __ballot(1);
@@ -117,13 +139,11 @@ struct EmitOctPolicy {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
                 const uint32_t pos = run[oo];
                 if (prefix == 0) run[oo] = pos + (uint32_t)__popcll(mo);
-                const size_t idx = (size_t)(pos + prefix) * 2;
-                queue[idx] = make_float4(o.x, o.y, o.z, tmax);
-                queue[idx + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
+                queue_store(queue, (size_t)(pos + prefix), o, d, tmax, slot, nt);
             }
             rem &= ~mo;
         }
-        slot += slotStride;
+        slot += queue.slotStride;
         return false;
     }
 };
@@ -240,7 +260,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
  * of the hit records k_primary wrote (its grid x 256). */
 constexpr uint32_t kGenBlock = 1024;
 __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, RenderArgs ra, const float4* hitTuvp,
-                                                          const uint32_t* hitCustom, float4* queue, uint32_t* count, uint32_t planeStride) {
+                                                          const uint32_t* hitCustom, RayQueue queue, uint32_t* count, uint32_t planeStride) {
     __shared__ uint32_t s_off[kGenBlock / 64], s_tot[kGenBlock / 64], s_base;
     const uint32_t q = blockIdx.x * kGenBlock + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6;
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, Render
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * planeStride + q;
-        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k, planeStride * ra.spp};
+        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k};
         if (single) {
             if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
@@ -306,8 +326,8 @@ constexpr uint32_t kGenOctBlock = 512;     /* two workgroups per CU, so one's re
 /* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
  * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
 __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc, RenderArgs ra, const float4* hitTuvp, const uint32_t* hitCustom,
-                                                              float4* queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
-                                                              uint32_t listStride, uint32_t kBatch) {
+                                                              RayQueue queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
+                                                              uint32_t listStride, uint32_t kBatch, uint32_t nt) {
     constexpr uint32_t kWaves = kGenOctBlock / 64;
     __shared__ uint32_t s_tot[kWaves][8], s_run[kWaves][8], s_first[8], s_len[8];
     const uint32_t q = blockIdx.x * kGenOctBlock + threadIdx.x;
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc,
     if (!live || mine == 0) return;
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (size_t)i * planeStride + q;
-        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, planeStride * ra.spp};
+        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, nt};
         if (single) {
             if (surf0) light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
@@ -426,10 +446,10 @@ constexpr int kTraceBlock = RTR_TRACE_BLOCK;
 constexpr uint32_t kTopNodes = 40u * (RTR_TRACE_BLOCK / 256);
 
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const float4* __restrict__ queue,
+__global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const RayQueue queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
-                                                              uint32_t kInnerMin, uint32_t* overflow) {
+                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t overflowCap) {
     __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (nIdle >= kRefill || nIdle == 64u) {
             if (cur == kDone && res != kResNone) {
-                if (res == 2u) overflow[1u + atomicAdd(overflow, 1u)] = rayIndex;      /* finished by k_shadow_tail */
+                if (res == 2u) { const uint32_t at = atomicAdd(overflow, 1u); if (at < overflowCap) overflow[1u + at] = rayIndex; }      /* finished by k_shadow_tail (a full list: it redoes the whole queue) */
                 else vis[slot] = (uint8_t)res;
                 res = kResNone;
             }
@@ -488,8 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const f
                     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (cur == kDone && prefix < avail) {
                         rayIndex = batchPos + prefix;
-                        const float4 a = queue[rayIndex * 2u], b = queue[rayIndex * 2u + 1u];
-                        o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
+                        queue_load(queue, rayIndex, o, d, tmax, slot, 0u);
                         if (!(tmax > tmin)) {
                             vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                         } else {
@@ -669,10 +688,10 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
  * form or the queue mode, so the counting form's numbers are the timed form's, and the oracle restates them), per-trip lane counts
  * of the two phases, and a shader-clock stamp pair per wave. */
 template <int STACK, bool LISTS, bool STATS>
-__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const float4* __restrict__ queue,
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const RayQueue queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
                                                               uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
-                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t octForms, uint32_t topCount,
+                                                              uint32_t kInnerMin, uint32_t* overflow, uint32_t overflowCap, uint32_t octForms, uint32_t topCount,
                                                               const uint2* __restrict__ lists, uint32_t listStride, Counters* stats,
                                                               unsigned long long* __restrict__ clk) {
     __shared__ int32_t s_stack[(STACK + 1) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good */
@@ -729,7 +748,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
         if (nIdle >= kRefill || nIdle == 64u) {
             if (STATS) ws.refills++;
             if (cur == kDone && res != kResNone) {
-                if (res == 2u) overflow[1u + atomicAdd(overflow, 1u)] = rayIndex;      /* finished by k_shadow_tail */
+                if (res == 2u) { const uint32_t at = atomicAdd(overflow, 1u); if (at < overflowCap) overflow[1u + at] = rayIndex; }      /* finished by k_shadow_tail (a full list: it redoes the whole queue) */
                 else vis[slot] = (uint8_t)res;
                 res = kResNone;
             }
@@ -771,8 +790,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (cur == kDone && prefix < avail) {
                         rayIndex = batchPos + prefix;
-                        const float4 a = queue[rayIndex * 2u], b = queue[rayIndex * 2u + 1u];
-                        o = rtr_mk(a.x, a.y, a.z); d = rtr_mk(b.x, b.y, b.z); tmax = a.w; slot = __float_as_uint(b.w);
+                        queue_load(queue, rayIndex, o, d, tmax, slot, octForms & 2u);
                         if (STATS) { st.rays++; st.shadow++; }
                         if (!(tmax > tmin)) {
                             vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
@@ -799,7 +817,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                 const uint32_t oct = (ga.x < 0.f ? 1u : 0u) | (ga.y < 0.f ? 2u : 0u) | (ga.z < 0.f ? 4u : 0u);
                 const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
                 const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
-                switch ((mixed || octForms == 0u) ? 8u : woct) {
+                switch ((mixed || (octForms & 1u) == 0u) ? 8u : woct) {
                     case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
                     case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
                     case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
@@ -1021,19 +1039,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
  * area): a 64-KiB LDS stack could not become resident next to another frame's persistent traversal kernel, so with frames
  * in flight this small launch used to wait for that kernel to drain and held up its own frame's resolve behind it. */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const float4* __restrict__ queue, const uint32_t* __restrict__ overflow,
-                                                        uint8_t* __restrict__ vis, int32_t* __restrict__ spill, Counters* stats) {
-    const uint32_t n = overflow[0];
+__global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const RayQueue queue, const uint32_t* __restrict__ overflow, uint32_t overflowCap,
+                                                        const uint32_t* __restrict__ count, uint8_t* __restrict__ vis, int32_t* __restrict__ spill, Counters* stats) {
+    uint32_t n = overflow[0];
     if (n == 0) return;
+    /* more abandoned rays than the list holds (its capacity is 1/16 of the queue's, at least a million): every ray of the queue is
+     * redone — the same bytes for the ones that had finished; the work counters then include their second walk */
+    const bool all = n > overflowCap;
+    if (all) n = *count;
     int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;          /* depth stride = every lane of the grid */
     LocalStats st;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += kTailBlocks * kBlock) {
-        const uint32_t r = overflow[1u + i];
-        const float4 a = queue[(size_t)r * 2], b = queue[(size_t)r * 2 + 1];
+        const uint32_t r = all ? i : overflow[1u + i];
+        rtr_v3 ro, rd; float rt; uint32_t rs;
+        queue_load(queue, r, ro, rd, rt, rs, 0u);
         HitRec h;
-        const bool occ = trace<true, STATS, kTailBlocks * kBlock>(sc, stack, rtr_mk(a.x, a.y, a.z), rtr_mk(b.x, b.y, b.z), 0.001f, a.w, h, st);
+        const bool occ = trace<true, STATS, kTailBlocks * kBlock>(sc, stack, ro, rd, 0.001f, rt, h, st);
         if (STATS) { st.rays--; st.shadow--; }              /* the ray itself was counted when the persistent kernel took it from the queue */
-        vis[__float_as_uint(b.w)] = occ ? 1 : 0;
+        vis[rs] = occ ? 1 : 0;
     }
     if (STATS) st.flush(stats);
 }
@@ -1041,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const fl
 /* ---- wavefront stage 4: resolve (shade with looked-up visibility, tonemap, store) ------------- */
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs ra, FrameOut fo, const float4* hitTuvp,
-                                                    const uint32_t* hitCustom, const uint8_t* vis, Counters* stats, uint32_t rowWaves) {
+                                                    const uint32_t* hitCustom, const uint8_t* vis, uint32_t slotStride, Counters* stats, uint32_t rowWaves) {
     /* which pixel slot this lane resolves.  Upstream a wave is one 8x8 tile (slot q = tile * 64 + row-in-tile * 8 + column-in-tile).
      * rowWaves (set when the tile rows are whole groups of eight tiles): a pair of workgroups takes eight tiles side by side, and a
      * wave is one 64-pixel ROW of them, so every image store of a wave is one contiguous 256-B run of a framebuffer row (and 1 KiB
@@ -1063,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs r
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
         const rtr_v3 dir = primary_dir(ra, px, py, i);
-        LookupPolicy pol{vis, (uint32_t)k, gridDim.x * kBlock * ra.spp};
+        LookupPolicy pol{vis, (uint32_t)k, slotStride};
         shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
     write_pixel(ra, fo, (size_t)lrow * ra.width + px, acc);
@@ -1172,7 +1195,8 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const bool binned = wide && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
                         (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
-    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch);
+    static const uint32_t kNtQueue = env_u32("RTR_QUEUE_NT", 1u, 0u, 3u);          /* bit 0: any-hit kernel reads the queue past the caches (default); bit 1: the queue-build kernel writes it so (slower, see queue_load) */
+    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
     else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
     /* persistent waves: as many workgroups as stay resident (17 KiB of LDS stack + 2.5 KiB of tree top per workgroup -> 8 per CU,
@@ -1191,7 +1215,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
     static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 28u, 0u, 63u);
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
-    static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u);
+    static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u) | ((kNtQueue & 1u) << 1);        /* bit 0: octant forms of the node loop; bit 1: the queue is read past the caches */
     static const uint32_t kTop = env_u32("RTR_TRACE_TOP_NODES", kTopNodes, 0u, kTopNodes);
     const uint32_t top = kTop < sc.numNodes4 ? kTop : sc.numNodes4;
     /* the 4-wide kernel's workgroups are kTraceBlock lanes: the same number of waves in fewer workgroups */
@@ -1199,21 +1223,21 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (tblocks4 == 0) tblocks4 = 1;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
-    } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow);
+    } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap);
     if (ev) hipEventRecord(ev[5], s);
-    if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
-    else hipLaunchKernelGGL((k_shadow_tail<false>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.vis, ws.spill, stats);
+    if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.overflowCap, ws.queueCount, ws.vis, ws.spill, stats);
+    else hipLaunchKernelGGL((k_shadow_tail<false>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.overflowCap, ws.queueCount, ws.vis, ws.spill, stats);
     if (ev) hipEventRecord(ev[3], s);
     static const uint32_t kRowWaves = env_u32("RTR_RESOLVE_ROW_WAVES", 0u, 0u, 1u);
     const uint32_t rowWaves = (kRowWaves && ra.tilesPerRow % 8u == 0u && blocks % 2u == 0u) ? 1u : 0u;
-    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats, rowWaves);
-    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, stats, rowWaves);
+    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
     if (ev) hipEventRecord(ev[4], s);
     return hipGetLastError();
 }

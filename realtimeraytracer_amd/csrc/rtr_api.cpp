@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -138,11 +139,14 @@ struct rtr_frame {
     uint32_t* ext[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf<float4> hdr;
     /* wavefront scratch */
-    DevBuf<float4> hitTuvp, rayQueue;
+    DevBuf<float4> hitTuvp, rayDT, rayOrigin;      /* hit records; per ray (direction, tmax); per pixel-sample the shadow rays' origin */
+    DevBuf<uint32_t> raySlot;                      /* per ray: index of its visibility byte */
+    uint32_t slotStride = 0;                       /* distance of the visibility planes: a power of two >= the pixel-sample slots */
     DevBuf<uint32_t> hitCustom, queueCount;
     DevBuf<uint8_t> vis;
     DevBuf<int32_t> spill;
     DevBuf<uint32_t> overflow;
+    uint32_t overflowCap = 0;
     DevBuf<uint2> batchLists;
     DevBuf<unsigned long long> clk;
     uint32_t listStride = 0;
@@ -923,7 +927,10 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     const uint64_t paddedPixels = (uint64_t)((rows + 7u) / 8u) * ra.tilesPerRow * 64u;
     const uint64_t blocks = (paddedPixels + 255u) / 256u;
     const uint64_t nPS = blocks * 256u * p.spp;
-    const uint64_t nSlots = nPS * maxRays;
+    const uint64_t nRays = nPS * maxRays;                    /* queue capacity: every pixel-sample issuing every query */
+    uint64_t slotStride = 256;                                /* the visibility planes are a power of two apart, so a slot names its pixel-sample with a mask */
+    while (slotStride < nPS) slotStride <<= 1;
+    const uint64_t nSlots = slotStride * maxRays;
     bool wave = p.pipeline != 1;
     if (wave && (nSlots >= (1ull << 31) || maxRays > 4096)) {
         if (p.pipeline == 2) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: wavefront scratch would need %llu visibility slots", (unsigned long long)nSlots);
@@ -937,18 +944,27 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     f->stats.localRows = rows; f->stats.localPixels = rows * p.width;
     hipError_t e;
     if (wave) {
-        if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); }
-        if (f->vis.n < nSlots) { HIP_TRY(f->vis.alloc(nSlots)); HIP_TRY(f->rayQueue.alloc(nSlots * 2)); HIP_TRY(f->overflow.alloc(nSlots + 1));
+        /* the list of rays left to the redo kernels: the camera rays' needs one entry per pixel-sample at most; the any-hit kernel's
+         * gets 1/16 of the queue (at least 2^20 entries) and k_shadow_tail redoes the whole queue should that ever overflow */
+        uint64_t ovCap = std::max<uint64_t>(std::max<uint64_t>(nPS, nRays / 16), 1ull << 20);
+        if (ovCap > nRays) ovCap = std::max<uint64_t>(nRays, nPS);
+        uint64_t ovUse = ovCap;                 /* what the any-hit kernel may use of it */
+        if (const char* e = getenv("RTR_TRACE_OVERFLOW_CAP")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v < ovCap) ovUse = v; }   /* test hook: a list short enough to overflow */
+        if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); HIP_TRY(f->rayOrigin.alloc(nPS)); }
+        if (f->vis.n < nSlots) HIP_TRY(f->vis.alloc(nSlots));
+        if (f->rayDT.n < nRays) { HIP_TRY(f->rayDT.alloc(nRays)); HIP_TRY(f->raySlot.alloc(nRays)); HIP_TRY(f->overflow.alloc(ovCap + 1)); f->overflowCap = (uint32_t)ovUse;
             /* batch lists of the binned queue (octant x consumer XCD): a run's batches are dealt round-robin to the eight lists of
              * its octant, so a list holds at most 1/8 of one batch per 64 rays (the smallest batch) + one per k_shadow_gen_oct workgroup */
-            f->listStride = (uint32_t)(nSlots / 64 / rtrdev::kQueueRegions + nPS / 256 + 16);
+            f->listStride = (uint32_t)(nRays / 64 / rtrdev::kQueueRegions + nPS / 256 + 16);
             HIP_TRY(f->batchLists.alloc((size_t)f->listStride * rtrdev::kQueueLists)); }
+        f->slotStride = (uint32_t)slotStride;
         if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(rtrdev::kQueueCtrlWords));
         if (!f->clk.p) { HIP_TRY(f->clk.alloc(2 * rtrdev::kQueueRegions)); HIP_TRY(hipMemsetAsync(f->clk.p, 0, 2 * rtrdev::kQueueRegions * sizeof(unsigned long long), st)); }
-        if (!f->spill.p) HIP_TRY(f->spill.alloc((size_t)48 * 2048 * 256));      /* (64 - 16) entries x the largest persistent grid */
+        if (!f->spill.p) HIP_TRY(f->spill.alloc(rtrdev::kSpillInts));      /* 64 entries x the redo kernels' grid */
         Workspace ws;
-        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.rayQueue = f->rayQueue.p; ws.vis = f->vis.p;
-        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nSlots; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride; ws.clk = f->clk.p;
+        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.vis = f->vis.p;
+        ws.rayQueue.dt = f->rayDT.p; ws.rayQueue.slot = f->raySlot.p; ws.rayQueue.origin = f->rayOrigin.p; ws.rayQueue.slotStride = f->slotStride; ws.rayQueue.slotMask = f->slotStride - 1u;
+        ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nRays; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.overflowCap = f->overflowCap; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride; ws.clk = f->clk.p;
         e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
     } else {
         (void)hipEventRecord(f->evMega[0], st);
@@ -1001,7 +1017,7 @@ int rtr_frame_wait(rtr_frame* f) {
         s.numShadowNodeVisits = h.shadowNodes; s.numShadowTriTests = h.shadowTris;
         s.numTexFetches = h.texFetch; s.numAlphaTests = h.alphaTests;
         const uint64_t shadowNodeBytes = f->pendingWave ? RTR_WIDE_NODE_BYTES : RTR_BVH_NODE_BYTES;     /* the megakernel walks the BVH2 for its shadow rays too */
-        s.shadowTraceBytes = shadowNodeBytes * h.shadowNodes + 48ull * h.shadowTris + 33ull * h.shadow;
+        s.shadowTraceBytes = shadowNodeBytes * h.shadowNodes + 48ull * h.shadowTris + 37ull * h.shadow;      /* per ray: 20 B of queue record + the 16-B origin of its pixel-sample + its visibility byte */
         s.shadowInnerIterations = h.innerIters; s.shadowInnerActiveLanes = h.innerLanes;
         s.shadowTriIterations = h.triIters; s.shadowTriActiveLanes = h.triLanes; s.shadowRefills = h.refills;
         if (f->overflow.p) { uint32_t ov = 0; HIP_TRY(hipMemcpy(&ov, f->overflow.p, sizeof ov, hipMemcpyDeviceToHost)); s.shadowTailRays = ov; }

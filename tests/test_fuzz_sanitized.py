@@ -47,6 +47,15 @@ def test_obj_ingest_under_sanitizers(tmp_path, scene_cache):
     assert "loaded" in r.stdout
 
 
+def test_tree_builder_under_sanitizers(tmp_path):
+    """bvh_build.cpp (binned SAH, insertion-based optimisation, cost-driven 4-wide collapse, host wide view) on random and degenerate
+    soups: every triangle in exactly one leaf of both views, boxes the right way round, depth within the stacks' bound"""
+    exe = _build(tmp_path, "fuzz_bvh")
+    r = subprocess.run([exe, "160"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert "soups ok" in r.stdout
+
+
 def test_face_naming_an_undefined_vertex_is_refused(tmp_path):
     """found by the fuzzer: the reference indexes attrib.vertices blindly (src/core/file.cppm:151-183)"""
     for body in ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -9\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//5\n",

@@ -505,6 +505,18 @@ def test_deep_stack_rays_take_the_tail_kernel(gpu_ctx, oracle):
             assert g.numNodeVisits == ref.stats.numNodeVisits and g.numTriTests == ref.stats.numTriTests
             assert ref.stats.numNodeVisits / ref.stats.numRays > 10000, "the skimming rays must really walk the whole row"
     _assert_same(imgs[0], imgs[1], "timed form vs counting form (LDS stack + overflow tail)")
+    # the list of abandoned rays holds 1/16 of the queue (at least 2^20 entries); past that k_shadow_tail redoes the whole queue.
+    # Forced here with a list of 4 entries: the same image
+    os.environ["RTR_TRACE_OVERFLOW_CAP"] = "4"
+    try:
+        fo = api.Frame(gpu_ctx, W, H)
+        api.render(scene, cam, info, api.make_params(W, H, spp=1, collect_stats=1, pipeline=2), fo)
+        assert fo.stats().shadowTailRays > 4
+        _assert_same(fo.download(), imgs[1], "abandoned-ray list overflowed: the redo kernel walks the whole queue")
+        api.render(scene, cam, info, api.make_params(W, H, spp=1, pipeline=2), fo)
+        _assert_same(fo.download(), imgs[1], "abandoned-ray list overflowed, timed form")
+    finally:
+        del os.environ["RTR_TRACE_OVERFLOW_CAP"]
     fm = api.Frame(gpu_ctx, W, H)
     api.render(scene, cam, info, api.make_params(W, H, spp=1, pipeline=1), fm)
     _assert_same(fm.download(), imgs[1], "megakernel on the deep-stack scene")
