@@ -8,9 +8,15 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
-#define RTR_ANYHIT_KERNEL_REVISION "r03.2"
+#define RTR_ANYHIT_KERNEL_REVISION "r03.3"
 
-constexpr uint32_t kQueueRegions = 8;                       /* one batch cursor per XCD: eight times the atomic rate of one counter */
+/* Batch cursors per queue (and batch lists per octant).  Workgroups are dealt round-robin to the XCDs, and a workgroup starts on
+ * cursor blockIdx mod 8: with 8, 4, 2 or 1 XCDs visible (SPX, DPX, QPX, CPX partitions of an MI355X) a cursor is still used by the
+ * waves of ONE XCD — cursor r by XCD r mod numXccs — which is what matters (a counter that the waves of several XCDs wait on
+ * serialises them: 3.75 instead of 1.9 ms).  Eight is therefore right for every partition mode of the part and stays a compile-time
+ * constant: `% kQueueRegions` is an AND in the refill path.  (rtr_ctx reads hipDeviceAttributeNumberOfXccs only to say so in
+ * rtr_ctx_device_name; a count that does not divide 8 would merely share cursors, never give a wrong result.) */
+constexpr uint32_t kQueueRegions = 8;
 constexpr uint32_t kQueueLists = kQueueRegions * kQueueRegions;        /* batch lists of the binned queue: (direction octant, consumer XCD) */
 constexpr uint32_t kQueueListLens = 16 + 16 * kQueueLists;            /* first word of the list lengths (read-only while the queue drains) */
 constexpr uint32_t kPrimaryCursors = kQueueListLens + kQueueLists;   /* kQueueRegions batch cursors of k_primary_persist, 64 B apart */
@@ -39,7 +45,9 @@ struct Workspace {
     uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
     RayQueue  rayQueue;              /* the queued shadow rays */
     uint8_t*  vis = nullptr;         /* per slot (query-major planes, rayQueue.slotStride apart): 1 = occluded */
-    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [16 + 16 r] batch cursor of queue region r (2-wide kernel, r < 8) or of batch list r = octant * 8 + xcd (64 B apart: a cursor is hammered by one XCD's waves), [kQueueListLens + r] length of list r, [kPrimaryCursors + 16 r] batch cursor of region r of the camera rays (k_primary_persist) */
+    uint32_t  visFill = 1;           /* what the array is pre-filled with before every launch (the commoner outcome); the any-hit kernel stores the other */
+    size_t    visBytes = 0;
+    uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [3] occluded rays of the any-hit launch, [16 + 16 r] batch cursor of queue region r (2-wide kernel, r < 8) or of batch list r = octant * 8 + xcd (64 B apart: a cursor is hammered by one XCD's waves), [kQueueListLens + r] length of list r, [kPrimaryCursors + 16 r] batch cursor of region r of the camera rays (k_primary_persist) */
     uint2*    batchLists = nullptr;  /* kQueueLists lists of listStride batches {first queue index, rays}: the queue binned by direction octant */
     uint32_t  listStride = 0;
     uint32_t* overflow = nullptr;    /* [0] count, then queue indices of rays k_shadow_trace left to k_shadow_tail: overflowCap entries; a count past the capacity makes k_shadow_tail redo the whole queue */
@@ -49,6 +57,10 @@ struct Workspace {
     size_t    capPixelSamples = 0;
     size_t    capRays = 0;
 };
+
+/* RTR_TRACE_BVH4=0 (read once per process): the staged pipeline walks the shadow rays with the 2-wide comparison kernel, which has no
+ * counting form. */
+bool two_wide_selected();
 
 /* stackEntries must be one of 16, 32, 64. */
 hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, int stackEntries,

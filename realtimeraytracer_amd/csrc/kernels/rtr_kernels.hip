@@ -43,6 +43,11 @@ struct InlinePolicy {
  * out of the L1s and L2s on its way through: the any-hit kernel 1.74 -> 1.71 ms alone and the frame 2.305 -> 2.245 ms with four in
  * flight.  WRITING it that way costs the queue-build kernel its write combining (0.238 -> 0.313 ms, 0.78 -> 0.99 GB of HBM writes), so
  * only the loads are streamed (profiles/r03/ab_deferred_leaf_and_nt_queue.log, ab_nt_split.log). */
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 typedef float rtr_f4 __attribute__((ext_vector_type(4)));
 /* one ray out of the queue: direction + far limit, visibility index, and the origin its pixel-sample's rays share */
 __device__ __forceinline__ void queue_load(const RayQueue& q, uint32_t ray, rtr_v3& o, rtr_v3& d, float& tmax, uint32_t& slot, uint32_t nt) {
@@ -448,7 +453,7 @@ constexpr uint32_t kTopNodes = 40u * (RTR_TRACE_BLOCK / 256);
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const RayQueue queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
-                                                              uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
+                                                              uint8_t* __restrict__ vis, uint32_t visFill, uint32_t kBatch, uint32_t kRefill,
                                                               uint32_t kInnerMin, uint32_t* overflow, uint32_t overflowCap) {
     __shared__ int32_t s_stack[(STACK + 1) * kBlock];        /* slot 0, below the stack, holds kDone for good */
     int32_t* lds = s_stack + threadIdx.x;
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const R
     int sp = 0;                              /* entries held; the top is lds[sp * kBlock] */
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
     float tmax = 0.f;
-    uint32_t slot = 0, rayIndex = 0, res = kResNone;
+    uint32_t slot = 0, rayIndex = 0, res = kResNone, occ = 0;
     const float tmin = 0.001f;
     /* nodes and triangles through buffer resources: the address of a visit is one 32-bit shift, not 64-bit lane arithmetic
      * (2.28 -> 2.17 ms, and 62 -> 47 VGPRs) */
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const R
         if (nIdle >= kRefill || nIdle == 64u) {
             if (cur == kDone && res != kResNone) {
                 if (res == 2u) { const uint32_t at = atomicAdd(overflow, 1u); if (at < overflowCap) overflow[1u + at] = rayIndex; }      /* finished by k_shadow_tail (a full list: it redoes the whole queue) */
-                else vis[slot] = (uint8_t)res;
+                else { if (res != visFill) vis[slot] = (uint8_t)res; occ += res; }      /* the array was pre-filled with the commoner outcome: only the other one is stored */
                 res = kResNone;
             }
             if (!exhausted) {
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const R
                         rayIndex = batchPos + prefix;
                         queue_load(queue, rayIndex, o, d, tmax, slot, 0u);
                         if (!(tmax > tmin)) {
-                            vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
+                            if (visFill != 0u) vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                         } else {
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
                             rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
@@ -579,6 +584,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const R
             else { cur = lds[sp * kBlock]; --sp; }                   /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }
     }
+    /* how many of this launch's rays were occluded: the host picks the next frame's pre-fill of the visibility array by it */
+    const uint32_t occWave = wave_sum_u32(occ);
+    if ((threadIdx.x & 63u) == 0 && occWave) atomicAdd(nextBatch - 13, occWave);      /* = queueCount[3] */
 }
 
 /* The inner-node loop of k_shadow_trace4, compiled per direction octant (OCT 0..7; 8 = any signs, see slab_oct). */
@@ -690,7 +698,7 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
 template <int STACK, bool LISTS, bool STATS>
 __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_trace4(DeviceScene sc, const RayQueue queue,
                                                               const uint32_t* __restrict__ count, uint32_t* nextBatch,
-                                                              uint8_t* __restrict__ vis, uint32_t kBatch, uint32_t kRefill,
+                                                              uint8_t* __restrict__ vis, uint32_t visFill, uint32_t kBatch, uint32_t kRefill,
                                                               uint32_t kInnerMin, uint32_t* overflow, uint32_t overflowCap, uint32_t octForms, uint32_t topCount,
                                                               const uint2* __restrict__ lists, uint32_t listStride, Counters* stats,
                                                               unsigned long long* __restrict__ clk) {
@@ -734,7 +742,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
     int32_t* sp = lds;                       /* LDS address of the top entry (lds = slot 0 = empty) */
     rtr_v3 o = rtr_mk(0, 0, 0), d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);   /* t(q) = q * ga + gb */
     float tmax = 0.f;
-    uint32_t slot = 0, rayIndex = 0, res = kResNone;
+    uint32_t slot = 0, rayIndex = 0, res = kResNone, occ = 0;
     const float tmin = 0.001f;
     /* nodes and triangles through buffer resources: the address of a visit is one 32-bit shift, not 64-bit lane arithmetic
      * (2.28 -> 2.17 ms, and 62 -> 47 VGPRs) */
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
             if (STATS) ws.refills++;
             if (cur == kDone && res != kResNone) {
                 if (res == 2u) { const uint32_t at = atomicAdd(overflow, 1u); if (at < overflowCap) overflow[1u + at] = rayIndex; }      /* finished by k_shadow_tail (a full list: it redoes the whole queue) */
-                else vis[slot] = (uint8_t)res;
+                else { if (res != visFill) vis[slot] = (uint8_t)res; occ += res; }      /* the array was pre-filled with the commoner outcome: only the other one is stored */
                 res = kResNone;
             }
             if (!exhausted) {
@@ -793,7 +801,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                         queue_load(queue, rayIndex, o, d, tmax, slot, octForms & 2u);
                         if (STATS) { st.rays++; st.shadow++; }
                         if (!(tmax > tmin)) {
-                            vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
+                            if (visFill != 0u) vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                         } else {
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
                             rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);      /* gb about the scene's wide centre: the records' planes are offsets from it */
@@ -855,6 +863,10 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
             if (hit) { res = 1u; cur = kDone; }
             else { cur = *sp; sp -= kTraceBlock; }                        /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }
+    }
+    {   /* how many of this launch's rays were occluded: the host picks the next frame's pre-fill of the visibility array by it */
+        const uint32_t occWave = wave_sum_u32(occ);
+        if ((threadIdx.x & 63u) == 0 && occWave) atomicAdd(nextBatch - 13, occWave);      /* = queueCount[3] */
     }
     if (stamp || STATS) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -1124,6 +1136,11 @@ static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t h
     return x < lo ? lo : (x > hi ? hi : (uint32_t)x);
 }
 
+bool two_wide_selected() {
+    static const bool v = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u) == 0u;
+    return v;
+}
+
 static uint32_t padded_pixels(const RenderArgs& ra) {
     const uint32_t band8 = (ra.localRows + 7u) / 8u;
     return band8 * ra.tilesPerRow * 64u;
@@ -1154,6 +1171,10 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     hipError_t e;
     if ((e = hipMemsetAsync(ws.queueCount, 0, kQueueCtrlWords * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] / [16 + 16 r] batch cursors */
     if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
+    /* the visibility array starts as "every ray had the commoner outcome" (the frame object's last launch says which: three shadow
+     * rays in four of the bench frame are occluded); the any-hit kernel stores only the other outcome — whole-line fill traffic
+     * instead of most of its scattered byte stores (WRITE_SIZE of the launch 136 -> 34 MB + 27 MB of fill) */
+    if ((e = hipMemsetAsync(ws.vis, (int)ws.visFill, ws.visBytes, s)) != hipSuccess) return e;
     if (ev) hipEventRecord(ev[0], s);
     /* the storage of ws.overflow is used twice per frame: first as k_primary's redo list (count in queueCount[2], consumed by
      * k_primary_tail), then as the any-hit kernel's overflow list (count in overflow[0]) */
@@ -1180,7 +1201,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
-    static const uint32_t kWide = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u);   /* 0: the 2-wide any-hit kernel on the plain queue (same results, for comparison) */
+    static const uint32_t kWide = two_wide_selected() ? 0u : 1u;   /* RTR_TRACE_BVH4=0: the 2-wide any-hit kernel on the plain queue (same results, for comparison; it has no counting form: rtr_render refuses collectStats with it) */
     const uint32_t genBlocks = (blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
     /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
      * (k_shadow_gen -> k_shadow_trace4 over eight regions of it).  Binning pays on long queues (+2 % frame rate at 12-25 M rays:
@@ -1191,7 +1212,7 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     const char* binEnv = getenv("RTR_TRACE_BINNED");
     const uint32_t binMode = (binEnv && (binEnv[0] == '0' || binEnv[0] == '1') && !binEnv[1]) ? (uint32_t)(binEnv[0] - '0') : 2u;
     const size_t maxRaysQ = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
-    const bool wide = (kWide || stats) && sc.nodes4;
+    const bool wide = kWide && sc.nodes4;
     const bool binned = wide && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
                         (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
@@ -1223,13 +1244,13 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (tblocks4 == 0) tblocks4 = 1;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
-    } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap);
+    } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap);
     if (ev) hipEventRecord(ev[5], s);
     if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.overflowCap, ws.queueCount, ws.vis, ws.spill, stats);
     else hipLaunchKernelGGL((k_shadow_tail<false>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.overflowCap, ws.queueCount, ws.vis, ws.spill, stats);

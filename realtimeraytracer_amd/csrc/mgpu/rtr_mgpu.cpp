@@ -561,6 +561,7 @@ int rtr_mgpu_wait(rtr_mgpu* m, int slot) {
     if (rc != RTR_OK) { const std::string keep = g_err; abort_all(m); g_err = keep + " (communicators aborted)"; return rc; }     /* a rank failed after phase 1: its peers' transfers can never be matched */
     /* ... then the device side, under the watchdog */
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(m->timeoutMs);
+    std::vector<Rank*> done;
     for (Rank* rp : waitFor) {
         Rank& r = *rp; Slot& s = r.slots[slot];
         if (hipSetDevice(r.device) != hipSuccess) { if (rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: hipSetDevice failed", r.rank); continue; }
@@ -585,10 +586,26 @@ int rtr_mgpu_wait(rtr_mgpu* m, int slot) {
             }
             if (e != hipSuccess) { if (rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: waiting for the exchange failed: %s", r.rank, hipGetErrorString(e)); continue; }
         }
-        r.stage = "rtr_frame_wait";
-        if (rtr_frame_wait(s.frame) != RTR_OK && rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: %s", r.rank, rtr_last_error());   /* the render is long done (or was not exchanged): this collects its per-kernel times */
         r.stage = "idle";
+        done.push_back(&r);
     }
+    /* the renders are long done (or were not exchanged): collecting their per-kernel times is a stream join and two small copies per
+     * rank — side by side on the ranks' own threads, not one after the other on the caller's (eight ranks, 0.4-ms frames) */
+    if (done.size() == 1) {          /* one local rank (a process per GPU): no thread hop */
+        Rank& r = *done[0];
+        if (hipSetDevice(r.device) != hipSuccess || rtr_frame_wait(r.slots[slot].frame) != RTR_OK) { if (rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rank %d: %s", r.rank, rtr_last_error()); }
+        return rc;
+    }
+    std::vector<std::future<int>> fs;
+    for (Rank* rp : done) {
+        Rank* r = rp; rtr_frame* fr = r->slots[slot].frame;
+        fs.push_back(r->worker->submit([r, fr](std::string& err) -> int {
+            W_HIP(hipSetDevice(r->device));
+            W_RTR(rtr_frame_wait(fr));
+            return RTR_OK;
+        }));
+    }
+    for (size_t i = 0; i < fs.size(); ++i) { const int c = fs[i].get(); if (c != RTR_OK && rc == RTR_OK) rc = fail(c, "rank %d: %s", done[i]->rank, done[i]->worker->error().c_str()); }
     return rc;
 }
 

@@ -73,7 +73,7 @@ struct rtr_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     hipDeviceProp_t prop;
-    int numXccs = 0;                     /* hipDeviceAttributeNumberOfXccs: the kernels cut their queues into kQueueRegions = 8 parts, one per XCD of an MI355X in SPX mode; with another count the mapping is merely less local, never wrong */
+    int numXccs = 0;                     /* hipDeviceAttributeNumberOfXccs (reported by rtr_ctx_device_name): the kernels' eight batch cursors stay private to one XCD each for 8, 4, 2 or 1 XCDs — kernels/rtr_kernels.h, kQueueRegions */
     /* scenes and frames keep a pointer to their context: a context destroyed while it still has children lives on,
      * unusable, until the last child is gone (garbage-collected bindings destroy objects in any order) */
     int children = 0;
@@ -142,6 +142,7 @@ struct rtr_frame {
     DevBuf<float4> hitTuvp, rayDT, rayOrigin;      /* hit records; per ray (direction, tmax); per pixel-sample the shadow rays' origin */
     DevBuf<uint32_t> raySlot;                      /* per ray: index of its visibility byte */
     uint32_t slotStride = 0;                       /* distance of the visibility planes: a power of two >= the pixel-sample slots */
+    uint32_t visFill = 1;                          /* pre-fill of the visibility array for the next launch: the commoner outcome of the last one (1 = occluded) */
     DevBuf<uint32_t> hitCustom, queueCount;
     DevBuf<uint8_t> vis;
     DevBuf<int32_t> spill;
@@ -235,7 +236,8 @@ int rtr_ctx_get_stream(rtr_ctx* c, void** out) {
 
 int rtr_ctx_device_name(rtr_ctx* c, char* buf, size_t bytes) {
     if (!c || !buf || bytes == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_device_name: bad argument");
-    snprintf(buf, bytes, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (c->numXccs > 0) snprintf(buf, bytes, "%s (%s, %d CUs in %d XCDs)", c->prop.name, c->prop.gcnArchName, c->prop.multiProcessorCount, c->numXccs);
+    else snprintf(buf, bytes, "%s (%s)", c->prop.name, c->prop.gcnArchName);
     return RTR_OK;
 }
 
@@ -938,6 +940,10 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     }
     if (blocks >= (1ull << 31)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame too large");
 
+    /* the counting form IS the timed kernel template; the 2-wide comparison kernel has none, and counting another kernel's work
+     * under its name would be a wrong number */
+    if (wave && p.collectStats && rtrdev::two_wide_selected())
+        return fail(RTR_ERR_UNSUPPORTED, "rtr_render: collectStats with RTR_TRACE_BVH4=0: the 2-wide comparison kernel has no counting form (unset the variable, or render with pipeline 1)");
     f->pendingWave = wave; f->pendingCounters = p.collectStats != 0;
     f->pendingImagesK = k; f->pendingHdr = wantHdr; f->pendingAccum = p.accumulate != 0;
     memset(&f->stats, 0, sizeof f->stats);
@@ -962,7 +968,8 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
         if (!f->clk.p) { HIP_TRY(f->clk.alloc(2 * rtrdev::kQueueRegions)); HIP_TRY(hipMemsetAsync(f->clk.p, 0, 2 * rtrdev::kQueueRegions * sizeof(unsigned long long), st)); }
         if (!f->spill.p) HIP_TRY(f->spill.alloc(rtrdev::kSpillInts));      /* 64 entries x the redo kernels' grid */
         Workspace ws;
-        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.vis = f->vis.p;
+        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.vis = f->vis.p; ws.visFill = f->visFill; ws.visBytes = (size_t)nSlots;
+        if (const char* e = getenv("RTR_TRACE_VIS_FILL")) if ((e[0] == '0' || e[0] == '1') && !e[1]) ws.visFill = (uint32_t)(e[0] - '0');      /* test hook: force the pre-fill */
         ws.rayQueue.dt = f->rayDT.p; ws.rayQueue.slot = f->raySlot.p; ws.rayQueue.origin = f->rayOrigin.p; ws.rayQueue.slotStride = f->slotStride; ws.rayQueue.slotMask = f->slotStride - 1u;
         ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nRays; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.overflowCap = f->overflowCap; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride; ws.clk = f->clk.p;
         e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
@@ -1001,6 +1008,11 @@ int rtr_frame_wait(rtr_frame* f) {
             for (uint32_t r = 0; r < rtrdev::kQueueRegions; ++r) if (h[2 * r + 1]) mhz[nv++] = (float)((double)h[2 * r] / (double)h[2 * r + 1] * 100.0);
             for (int i = 1; i < nv; ++i) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; --j) { const float t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }
             s.shadowTraceClockMHz = nv ? mhz[nv / 2] : 0.f;
+        }
+        if (f->queueCount.p) {      /* the next launch pre-fills the visibility array with this one's commoner outcome */
+            uint32_t q[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(q, f->queueCount.p, sizeof q, hipMemcpyDeviceToHost));
+            if (q[0]) f->visFill = (2ull * q[3] >= q[0]) ? 1u : 0u;
         }
     } else {
         float a = 0;

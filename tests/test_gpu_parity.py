@@ -582,6 +582,11 @@ p = api.make_params(160, 96, spp=2)
 api.render(scene, s.camera, s.scene_info(3), p, frame)
 ref = O.render(s.desc, s.camera, s.scene_info(3), p, bvh=scene.export_bvh(), threads=8)
 assert np.array_equal(frame.download(), ref.images[A.IMAGE_SHADOWED])
+try:        # no counting form for the comparison kernel: refused, not answered with another kernel's counters
+    api.render(scene, s.camera, s.scene_info(3), api.make_params(160, 96, spp=2, collect_stats=1), frame)
+    raise SystemExit("collectStats was accepted with the 2-wide kernel")
+except api.RtrError as e:
+    assert "counting form" in str(e)
 print("two-wide ok")
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -658,6 +663,28 @@ def test_d6_occluded_sample_with_overflowing_contribution(gpu_ctx, oracle, scene
     ref2 = oracle.render(d, s.camera, s.scene_info(0), p2, bvh=bvh, images=both, threads=8)
     _assert_same(f2.download(A.IMAGE_SHADOWED), ref2.images[A.IMAGE_SHADOWED], "D6 scene, shadowed image with every sample evaluated")
     _assert_same(f2.download(A.IMAGE_UNSHADOWED), ref2.images[A.IMAGE_UNSHADOWED], "D6 scene, unshadowed image")
+
+
+@pytest.mark.parametrize("fill", ["0", "1", "auto"])
+def test_visibility_prefill_polarity_does_not_change_a_pixel(gpu_ctx, oracle, scene_cache, queue_mode, fill):
+    """The visibility array is pre-filled with the commoner outcome of the frame object's last launch and the any-hit kernel stores
+    only the other one (WRITE_SIZE 136 -> 34 MB on the bench frame): either pre-fill, and the automatic choice over three frames
+    whose occlusion differs, must give the oracle's image."""
+    if fill != "auto":
+        os.environ["RTR_TRACE_VIS_FILL"] = fill
+    try:
+        s = scenes.bunny_class(320, 184)
+        scene = api.Scene(gpu_ctx, s.desc)
+        frame = api.Frame(gpu_ctx, 320, 184)
+        bvh = scene.export_bvh()
+        for f in (0, 1, 2):
+            for collect in (0, 1):
+                p = api.make_params(320, 184, spp=1, collect_stats=collect, pipeline=2)
+                api.render(scene, s.camera, s.scene_info(f), p, frame)
+                ref = oracle.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, threads=16)
+                _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"pre-fill {fill}, frame {f}, collect {collect}")
+    finally:
+        os.environ.pop("RTR_TRACE_VIS_FILL", None)
 
 
 def _run_staged_child(code, env, timeout):
