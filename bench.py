@@ -19,13 +19,16 @@ de-interleaved there; all of that is inside the timed region.
 Rank 0 prints ONE JSON line.  `value` = all rays traced per second (primary + shadow, exact count
 from the kernels' own counters in an untimed stats pass), whole job.  `roofline` is for the dominant
 kernel (k_shadow_trace4, the any-hit traversal of the shadow-ray queue).  The kernel is bound by
-vector-instruction ISSUE, not by HBM (its 17 MB tree is cache-resident: 6 % of its algorithmic bytes
+vector-instruction ISSUE, not by HBM (its 17 MB tree is cache-resident: a few per cent of its algorithmic bytes
 reach the fabric), so the block reports the ceiling that binds — SIMD issue cycles busy / SIMD cycles
 of the launch, with the launch duration (HIP events on the launch stream) and the shader clock (s_memtime
 over s_memrealtime stamps inside the launch) measured live, lane utilisation from the kernel's counting
 form run in this process, and the counter totals of the committed rocprofv3 passes of the same command
-(profiles/r02/pmc_roofline.json, tagged with the kernel revision) — and, beside it, the second unit that is
-nearly full (L1 tag look-ups per L1 per clock), the HBM and L2 fractions and the algorithmic byte rate.
+(profiles/r03/pmc_roofline.json — used only when workload, kernel revision, triangle count and queue length
+match this run) — and, beside it, the second unit that is nearly full (L1 tag look-ups per L1 per clock),
+the HBM and L2 fractions and the algorithmic byte rate.  `roofline_secondary` is the one kernel of the frame
+that IS HBM-bound (the queue build: bytes from the same counter passes over its live launch time) and
+`frame_hbm` the whole frame's HBM bytes over the frame time.
 `presented_frame` (N = 1) times the frame the reference presents: five images at 4 spp with the shipped LTC
 tables, four a-trous rounds, combine.  `cpu_baseline` is the CPU oracle (a scalar C++ port, oracle/)
 timed on the host cores on a bounded sample of the same workload — reported, not a target.
@@ -46,10 +49,14 @@ L2_PEAK_GBS = 34500.0    # same guide: L2 aggregate, 8 XCDs
 
 
 def default_frames_in_flight(n_gpus):
-    """Frames kept in flight per rank.  4 fills one MI355X with whole frames (flat from 2 to 8); a 1/4 or 1/8 shard is too small for
-    any of its kernels to fill the GPU, and eight of them on eight hardware queues do better than four on four
-    (profiles/r01/sweep_hw_queues_one_rank_of_8.log: 0.398 against 0.421 ms per frame for one rank of 8)."""
-    return 8 if n_gpus >= 4 else 4
+    """Frame objects in use per rank, and frames per launch of the pipeline (--batch).  A 1-spp frame — a 1/N shard of one even more
+    so — is too little work per launch for the latency-bound kernels: eight frames per launch, one launch at a time, render faster
+    than any number of single-frame launches overlapped (profiles/r03/ab_frame_batch2.log: N = 1 2.12 against 2.25 ms per frame;
+    one rank of 8 0.327 against 0.392)."""
+    return 8
+
+
+DEFAULT_BATCH = 8      # frames per launch (rtr_render_batch_async / rtr_mgpu_render_batch_async); --batch 1 = one launch per frame
 
 
 def launch_plan(args, env, argv):
@@ -60,7 +67,7 @@ def launch_plan(args, env, argv):
     fif = args.frames_in_flight or default_frames_in_flight(n)
     # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 8 frames in flight every frame's stream gets its own
     env_defaults = {"GPU_MAX_HW_QUEUES": "8"} if fif >= 8 else {}
-    base = {"n_gpus": n, "frames_in_flight": fif, "env_defaults": env_defaults}
+    base = {"n_gpus": n, "frames_in_flight": fif, "frames_per_launch": max(1, min(args.batch or DEFAULT_BATCH, fif)), "env_defaults": env_defaults}
     if n < 1:
         return dict(base, mode="error", why=f"--gpus {n}")
     ws = env.get("WORLD_SIZE")
@@ -157,12 +164,31 @@ def run_inproc(args, K, plan):
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
         kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
 
+    B = max(1, min(plan["frames_per_launch"], nbuf, A.MAX_BATCH)) if K == 1 else 1
+
     def step(i):
         b = i % nbuf
         collect(b)                                      # frame i - nbuf: done long ago unless the host runs ahead
         for j in range(K):
             mg.render_async(b, setup.camera, setup.scene_info(j if K > 1 else i), p_run[j], exchange=(j == K - 1))
         inflight[b] = True
+
+    def run_steps(first, count):
+        """`count` frames from frame `first` on: B per launch of the pipeline on every rank (rtr_mgpu_render_batch_async), each with its own exchange"""
+        if B == 1:
+            for i in range(first, first + count):
+                step(i)
+            return
+        i = first
+        while i < first + count:
+            c = min(B, first + count - i)
+            bufs = [(i + j) % nbuf for j in range(c)]
+            for b in bufs:
+                collect(b)
+            mg.render_batch_async(bufs, [setup.camera] * c, [setup.scene_info(i + j) for j in range(c)], p_run[0])
+            for b in bufs:
+                inflight[b] = True
+            i += c
 
     def drain():
         for b in range(nbuf):
@@ -175,14 +201,15 @@ def run_inproc(args, K, plan):
     for b in range(nbuf):                               # set-up, not warm-up: every slot allocates on its first render
         step(b)
     drain()
-    for i in range(args.warmup):
-        step(i)
+    if B > 1:                                           # ... and the leading slots' scratch grows to the batch on the first batched one
+        run_steps(0, nbuf)
+        drain()
+    run_steps(0, args.warmup)
     drain()
     kern.update({k: 0.0 for k in kern}); kern["n"] = 0
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run_steps(args.warmup, args.steps)
     drain()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -206,8 +233,9 @@ def run_inproc(args, K, plan):
                    "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries), "build_ms": round(float(sstats.buildMs), 1)}},
         "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
         "frames_in_flight": nbuf,
+        "frames_per_launch": B,
         "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
-        "kernels_scope": "rank 0's shard; HIP-event brackets with the other frames' kernels sharing the GPU",
+        "kernels_scope": "rank 0's shard, per frame (a launch covers frames_per_launch frames); HIP-event brackets",
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
         "rccl": {"nranks": int(info.nranks), "nlocal": int(info.nlocal), "version": int(info.rcclVersion), "launch": "one process, rtr_mgpu_create (ncclCommInitAll, a host thread per rank)",
                  "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
@@ -240,7 +268,10 @@ def main():
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N",
                     help="single-GPU rehearsal of what ONE rank does in an N-GPU run: renders shard 0 of N with the same two-stream "
                          "frame pipelining, without the gather (the printed value is this rank's rays/s, not a job total)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames pipelined on separate streams (0 = default: 4, at every N; 1 = one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frame objects in use, each with its own stream (0 = default: 8; 1 = one frame at a time)")
+    ap.add_argument("--batch", type=int, default=0, metavar="B",
+                    help="frames per launch of the pipeline (rtr_render_batch_async; 0 = default: 8, 1 = one launch per frame).  The frames in flight are "
+                         "rendered in groups of B: every kernel of the pipeline is launched once per group over B frames' work")
     ap.add_argument("--accumulate", type=int, default=1, metavar="K",
                     help="a step = K frames (frame = 0..K-1) summed in the float HDR buffer and tonemapped once (BASELINE config 5: "
                          "--width 3840 --height 2160 --accumulate 16)")
@@ -453,6 +484,37 @@ def main():
         if st.shadowTraceClockMHz > 0:
             clocks.append(st.shadowTraceClockMHz)
 
+    B = max(1, min(plan["frames_per_launch"], nbuf, A.MAX_BATCH)) if (K == 1 and (use_lib or not dist_on)) else 1
+
+    def step_batch(i0, count):
+        """frames i0 .. i0+count-1 in ONE launch of every kernel (rtr_render_batch_async), on the stream of the first one's buffer"""
+        bufs = [(i0 + j) % nbuf for j in range(count)]
+        last_buf[0] = bufs[-1]
+        if use_lib:                                     # one launch of the pipeline per rank for the batch, then every slot's exchange
+            for b in bufs:
+                lib_collect(b)
+            mg.render_batch_async(bufs, [setup.camera] * count, [setup.scene_info(i0 + j) for j in range(count)], p_run[0])
+            for b in bufs:
+                inflight[b] = True
+            return
+        with torch.cuda.stream(streams[bufs[0]]):
+            for b in bufs:
+                collect(b)
+            api.render_batch(scene, [setup.camera] * count, [setup.scene_info(i0 + j) for j in range(count)], p_run[0], [frames[b] for b in bufs])
+            for b in bufs:
+                inflight[b] = True
+
+    def run_steps(first, count):
+        if B == 1:
+            for i in range(first, first + count):
+                step(i)
+            return
+        i = first
+        while i < first + count:
+            c = min(B, first + count - i)
+            step_batch(i, c)
+            i += c
+
     def step(i):
         b = i % nbuf
         last_buf[0] = b
@@ -492,14 +554,15 @@ def main():
         if use_lib:
             step(b)                                     # the library's slots allocate on their first render too
     drain()
-    for i in range(args.warmup):
-        step(i)
+    if B > 1:                                           # the leading frames' scratch grows to the batch on its first batched render
+        run_steps(0, nbuf)
+        drain()
+    run_steps(0, args.warmup)
     drain()
     kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0})
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run_steps(args.warmup, args.steps)
     drain()
     torch.cuda.synchronize()
     sync_all()
@@ -637,7 +700,7 @@ def main():
                              "and algorithmic_* are measured by this process") if pmc else None,
                 "layout": {"bvh": int(sstats.bvhLayoutVersion), "wide": int(sstats.wideLayoutVersion)}}
             if pmc and pmc.get("kernels", {}).get("k_shadow_gen_oct") and kern_iso:
-                # the one kernel of the frame that IS bound by HBM: it writes the ray queue (32 B per ray) as fast as the memory takes it
+                # the one kernel of the frame that IS bound by HBM: it writes the ray queue (20 B per ray + 16 B per pixel-sample) as fast as the memory takes it
                 g = pmc["kernels"]["k_shadow_gen_oct"]
                 gen_ms = kern_iso["shadow_gen"]
                 gbytes = g["read_bytes"] + g["write_bytes"]
@@ -673,6 +736,7 @@ def main():
                                "build_ms": round(float(sstats.buildMs), 1)}},
             "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
             "frames_in_flight": nbuf,
+            "frames_per_launch": B,
             "kernels_ms": {k: round(v, 4) for k, v in kern_iso.items()} if kern_iso else {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
             "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"} if kern_iso else None,
             "one_frame_at_a_time": {"ms_per_step": round(iso_ms_per_frame, 4), "mrays_per_s": round(fs.numRays * K / iso_ms_per_frame / 1e3, 2),

@@ -273,6 +273,17 @@ int  rtr_render(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInf
  * different contexts render concurrently on their own streams against one scene. */
 int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo,
                       const rtr_render_params* params, rtr_frame* frame);
+/* Several frames in ONE launch of every kernel of the pipeline: cameras[b] / sceneInfos[b] -> frames[b], b < n <= RTR_MAX_BATCH, all
+ * with the same params (extent, spp, sharding, images; accumulate applies to each frame's own HDR image).  A frame at 1 spp — and
+ * a 1/N shard of one even more so — is too little work per launch for the latency-bound kernels (the camera-ray kernel takes
+ * 0.34 ms for one 1080p frame's rays and 0.41 ms for four times as many): batching trades latency of the individual frame for
+ * throughput, like frames in flight do, and composes with them.  Same pixels as n calls of rtr_render_async (tested).  The
+ * launch runs on frames[0]'s context stream and its times / counters (rtr_frame_get_stats) are frames[0]'s, for the whole launch;
+ * rtr_frame_wait on any of the frames joins it.  Staged pipeline only; the frames must live on one device and be distinct.
+ * The reference records one vkCmdTraceRaysKHR per frame (src/app/application.cppm:362-389); this is n of them in one. */
+#define RTR_MAX_BATCH 8
+int  rtr_render_batch_async(rtr_scene* scene, const RtrCameraData* cameras, const RtrSceneInfo* sceneInfos, const rtr_render_params* params,
+                            rtr_frame* const* frames, uint32_t n);
 int  rtr_frame_wait(rtr_frame* frame);
 
 /* The passes that follow the ray-gen dispatch in the reference's frame loop (src/app/application.cppm:391-445):

@@ -152,6 +152,7 @@ RTR_SYMBOLS = {
     "rtr_shard_rows": (u32, [u32, u32, u32]),
     "rtr_render": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
     "rtr_render_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
+    "rtr_render_batch_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), P(VP), u32]),
     "rtr_frame_wait": (C.c_int, [VP]),
     "rtr_deinterleave_bands": (C.c_int, [VP, VP, VP, u32, u32, u32, u32]),
     "rtr_denoise_combine": (C.c_int, [VP, C.c_int]),
@@ -222,6 +223,7 @@ MGPU_PLAN_MAX_OPS = 32
 MGPU_MAX_RANKS = 16
 
 
+MAX_BATCH = 8
 MGPU_ID_BYTES = 128
 MGPU_MAX_SLOTS = 8
 MGPU_NO_EXCHANGE = 1
@@ -234,6 +236,7 @@ MGPU_SYMBOLS = {
     "rtr_mgpu_destroy": (None, [VP]),
     "rtr_mgpu_scene_create": (C.c_int, [VP, P(rtr_scene_desc)]),
     "rtr_mgpu_render_async": (C.c_int, [VP, C.c_int, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), C.c_int]),
+    "rtr_mgpu_render_batch_async": (C.c_int, [VP, P(C.c_int), C.c_int, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), C.c_int]),
     "rtr_mgpu_wait": (C.c_int, [VP, C.c_int]),
     "rtr_mgpu_render": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params)]),
     "rtr_mgpu_frame_download": (C.c_int, [VP, C.c_int, VP, C.c_size_t]),

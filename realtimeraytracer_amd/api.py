@@ -172,6 +172,15 @@ def render(scene, camera, scene_info, params, frame, asynchronous=False):
     _check(fn(scene.h, C.byref(camera), C.byref(scene_info), C.byref(params), frame.h), "rtr_render")
 
 
+def render_batch(scene, cameras, scene_infos, params, frames):
+    """rtr_render_batch_async: len(frames) <= A.MAX_BATCH frames in one launch of every kernel; asynchronous, join with frames[k].wait()."""
+    n = len(frames)
+    cams = (A.RtrCameraData * n)(*cameras)
+    infos = (A.RtrSceneInfo * n)(*scene_infos)
+    hs = (A.VP * n)(*[f.h.value for f in frames])
+    _check(scene.lib.rtr_render_batch_async(scene.h, cams, infos, C.byref(params), hs, n), "rtr_render_batch_async")
+
+
 def deinterleave_bands(ctx, gathered_ptr, dst_ptr, width, height, band_rows, shard_count):
     _check(ctx.lib.rtr_deinterleave_bands(ctx.h, A.VP(gathered_ptr), A.VP(dst_ptr), width, height, band_rows, shard_count),
            "rtr_deinterleave_bands")

@@ -690,6 +690,25 @@ struct FrameOut {
     float4* hdr;
 };
 
+/* Several frames in ONE launch of every kernel of the staged pipeline (rtr_render_batch_async): a frame of the batch is a further
+ * run of sample planes — plane = frame * spp + sample, pixel-sample slot k = plane * planeStride + q — so the camera-ray kernel's
+ * grid, the queue and the any-hit kernel's work grow with the batch while the launches per frame shrink.  What differs between the
+ * frames (camera, seed, accumulation state, output images) is looked up per wave: planeStride is a multiple of 64, so a wave never
+ * straddles two frames.  Why: a 1-spp frame (let alone a 1/8 shard of one) is too little work per launch for the latency-bound
+ * kernels — the camera-ray kernel takes 0.34 ms for one frame's rays and 0.41 ms for four times as many. */
+constexpr uint32_t kMaxBatch = 8;
+struct FrameBatch {
+    RenderArgs ra[kMaxBatch];
+    FrameOut   fo[kMaxBatch];
+    uint32_t   n;
+};
+/* lane g of a launch over the whole batch -> frame b (wave-uniform) and pixel slot q inside the frame */
+__device__ __forceinline__ uint32_t batch_frame(uint32_t g, uint32_t planeStride, uint32_t& q) {
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g / planeStride));
+    q = g - b * planeStride;
+    return b;
+}
+
 /* raygen.rgen:341-364 + the HDR accumulation extension */
 __device__ __forceinline__ void write_pixel(const RenderArgs& ra, const FrameOut& fo, size_t p, Accum o) {
     const float n = (float)ra.spp;

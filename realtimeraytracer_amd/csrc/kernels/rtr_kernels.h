@@ -69,7 +69,7 @@ hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const 
 /* Staged pipeline: primary trace -> shadow-ray generation (ballot-compacted queue) -> any-hit trace
  * -> resolve.  `ev` (6 events, may be null) are recorded between stages for per-stage timing ([5]: after the any-hit kernel,
  * before k_shadow_tail). */
-hipError_t launch_wavefront(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, const Workspace& ws,
+hipError_t launch_wavefront(const DeviceScene& sc, const FrameBatch& batch, const Workspace& ws,
                             int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev, uint32_t numCus);
 
 /* fills DeviceScene::lightTris (4 x float4 per light triangle, light l from first[l]); after create and after light transforms change */

@@ -187,15 +187,17 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
  * stack (16 KiB per workgroup): ordered traversal seldom holds more, and the rare ray that needs more is listed in `redo` and
  * re-traced by k_primary_tail with a full-depth stack in global memory — the same rule in the timed and the counting form. */
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
+__global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
                                                     Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
     __shared__ int32_t s_stack[16 * kBlock];
     int32_t* stack = s_stack + threadIdx.x;
     /* the grid is spp planes of planeBlocks workgroups: one lane = one (sample, pixel slot), so at spp > 1 the samples of a pixel are
      * walked side by side by different waves instead of one after the other by one lane (the kernel is bound by the chain of dependent
      * fetches of its deepest rays: 0.88 -> 0.42 ms for the 4 spp of config 3, whose frame alone goes from 3.36 to 2.92 ms) */
-    const uint32_t i = blockIdx.x / planeBlocks;
-    const uint32_t q = (blockIdx.x - i * planeBlocks) * kBlock + threadIdx.x;
+    const uint32_t plane = blockIdx.x / planeBlocks;                 /* frame of the batch * spp + sample */
+    const RenderArgs& ra = fb.ra[plane / fb.ra[0].spp];
+    const uint32_t i = plane % fb.ra[0].spp;
+    const uint32_t q = (blockIdx.x - plane * planeBlocks) * kBlock + threadIdx.x;
     uint32_t px, lrow, py;
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
         }
     }
     /* sample-major planes keep each store of a wave contiguous */
-    const size_t k = (size_t)i * planeBlocks * kBlock + q;
+    const size_t k = (size_t)plane * planeBlocks * kBlock + q;
     if (h.custom == RTR_STACK_OVERFLOW) redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k;
     else {
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -232,21 +234,22 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, RenderArgs r
 /* Re-traces the pixel-samples the primary kernels abandoned: BVH2 walk with a full-depth stack in global memory (no LDS, so it
  * can always run).  STATS: the counting form (the ray itself was counted by the kernel that abandoned it). */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
+__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
                                                          const uint32_t* __restrict__ redoCount, const uint32_t* __restrict__ redoList,
                                                          int32_t* __restrict__ spill, uint32_t planeStride, Counters* stats) {
     const uint32_t n = *redoCount;
     if (n == 0) return;
     int32_t* stack = spill + blockIdx.x * kBlock + threadIdx.x;
     LocalStats st;
-    const rtr_v3 camPos = rtr_ld3(ra.cam.position);
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const uint32_t k = redoList[j];
-        const uint32_t i = k / planeStride, q = k % planeStride;           /* sample index, pixel slot */
+        const uint32_t plane = k / planeStride, q = k % planeStride;       /* frame * spp + sample, pixel slot */
+        const RenderArgs& ra = fb.ra[plane / fb.ra[0].spp];               /* (per lane: the list mixes the frames of the batch) */
+        const uint32_t i = plane % fb.ra[0].spp;
         uint32_t px, lrow, py;
         if (!pixel_of(ra, q, px, lrow, py)) continue;
         HitRec h;
-        trace<false, STATS, 64 * kBlock>(sc, stack, camPos, primary_dir(ra, px, py, i), 0.001f, 10000.0f, h, st);
+        trace<false, STATS, 64 * kBlock>(sc, stack, rtr_ld3(ra.cam.position), primary_dir(ra, px, py, i), 0.001f, 10000.0f, h, st);
         if (STATS) { st.rays--; st.primary--; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
@@ -264,13 +267,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 /* 1024-thread workgroups (16 waves): the queue is reserved once per workgroup, see below; planeStride = the sample-plane stride
  * of the hit records k_primary wrote (its grid x 256). */
 constexpr uint32_t kGenBlock = 1024;
-__global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, RenderArgs ra, const float4* hitTuvp,
+__global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, FrameBatch fb, const float4* hitTuvp,
                                                           const uint32_t* hitCustom, RayQueue queue, uint32_t* count, uint32_t planeStride) {
     __shared__ uint32_t s_off[kGenBlock / 64], s_tot[kGenBlock / 64], s_base;
-    const uint32_t q = blockIdx.x * kGenBlock + threadIdx.x;
+    uint32_t q;
+    const uint32_t frame = batch_frame(blockIdx.x * kGenBlock + threadIdx.x, planeStride, q);
+    const RenderArgs& ra = fb.ra[frame < fb.n ? frame : 0u];
+    const size_t plane0 = (size_t)frame * ra.spp;                 /* first sample plane of this lane's frame */
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t px = 0, lrow = 0, py = 0;
-    const bool live = pixel_of(ra, q, px, lrow, py);
+    const bool live = frame < fb.n && pixel_of(ra, q, px, lrow, py);
     LocalStats st;
     Accum acc = zero_accum();
     /* The surface fetch (hit -> object -> indices -> vertices, a chain of dependent loads) runs ONCE per sample; the
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, Render
     if (live) {
         CountPolicy cp{0};
         for (uint32_t i = 0; i < ra.spp; ++i) {
-            const size_t k = (size_t)i * planeStride + q;
+            const size_t k = (plane0 + i) * planeStride + q;
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, Render
     if (!live || n == 0) return;
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
-        const size_t k = (size_t)i * planeStride + q;
+        const size_t k = (plane0 + i) * planeStride + q;
         EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k};
         if (single) {
             if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
@@ -330,15 +336,18 @@ constexpr uint32_t kBinnedMinNodes = 1u << 16;       /* ... and this tree size: 
 constexpr uint32_t kGenOctBlock = 512;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
 /* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
  * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
-__global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc, RenderArgs ra, const float4* hitTuvp, const uint32_t* hitCustom,
+__global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom,
                                                               RayQueue queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
                                                               uint32_t listStride, uint32_t kBatch, uint32_t nt) {
     constexpr uint32_t kWaves = kGenOctBlock / 64;
     __shared__ uint32_t s_tot[kWaves][8], s_run[kWaves][8], s_first[8], s_len[8];
-    const uint32_t q = blockIdx.x * kGenOctBlock + threadIdx.x;
+    uint32_t q;
+    const uint32_t frame = batch_frame(blockIdx.x * kGenOctBlock + threadIdx.x, planeStride, q);
+    const RenderArgs& ra = fb.ra[frame < fb.n ? frame : 0u];
+    const size_t plane0 = (size_t)frame * ra.spp;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t px = 0, lrow = 0, py = 0;
-    const bool live = pixel_of(ra, q, px, lrow, py);
+    const bool live = frame < fb.n && pixel_of(ra, q, px, lrow, py);
     LocalStats st;
     Accum acc = zero_accum();
     const bool single = ra.spp == 1u;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc,
     CountOctPolicy cp{0ull, 0ull};
     if (live) {
         for (uint32_t i = 0; i < ra.spp; ++i) {
-            const size_t k = (size_t)i * planeStride + q;
+            const size_t k = (plane0 + i) * planeStride + q;
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc,
     __syncthreads();
     if (!live || mine == 0) return;
     for (uint32_t i = 0; i < ra.spp; ++i) {
-        const size_t k = (size_t)i * planeStride + q;
+        const size_t k = (plane0 + i) * planeStride + q;
         EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, nt};
         if (single) {
             if (surf0) light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
@@ -1075,7 +1084,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const Ra
 
 /* ---- wavefront stage 4: resolve (shade with looked-up visibility, tonemap, store) ------------- */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs ra, FrameOut fo, const float4* hitTuvp,
+__global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, FrameBatch fb, uint32_t planeStride, const float4* hitTuvp,
                                                     const uint32_t* hitCustom, const uint8_t* vis, uint32_t slotStride, Counters* stats, uint32_t rowWaves) {
     /* which pixel slot this lane resolves.  Upstream a wave is one 8x8 tile (slot q = tile * 64 + row-in-tile * 8 + column-in-tile).
      * rowWaves (set when the tile rows are whole groups of eight tiles): a pair of workgroups takes eight tiles side by side, and a
@@ -1088,13 +1097,17 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, RenderArgs r
         const uint32_t row = (threadIdx.x >> 6) + 4u * (blockIdx.x & 1u), col = threadIdx.x & 63u;
         q = (blockIdx.x >> 1) * (2u * kBlock) + (col >> 3) * 64u + row * 8u + (col & 7u);
     }
+    const uint32_t frame = batch_frame(q, planeStride, q);           /* q: lane over the whole batch -> pixel slot of its frame */
+    if (frame >= fb.n) return;
+    const RenderArgs& ra = fb.ra[frame];
+    const FrameOut& fo = fb.fo[frame];
     uint32_t px, lrow, py;
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
     Accum acc = zero_accum();
     const uint32_t want = (fo.img[0] != nullptr ? 1u : 0u) | (fo.img[2] != nullptr ? 2u : 0u);   /* analytic / unshadowed outputs */
     for (uint32_t i = 0; i < ra.spp; ++i) {
-        const size_t k = (size_t)i * gridDim.x * kBlock + q;
+        const size_t k = ((size_t)frame * ra.spp + i) * planeStride + q;
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
         const rtr_v3 dir = primary_dir(ra, px, py, i);
@@ -1165,9 +1178,11 @@ hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const 
 }
 
 template <int STACK>
-static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, const Workspace& ws,
+static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Workspace& ws,
                          Counters* stats, hipStream_t s, hipEvent_t* ev, uint32_t numCus) {
-    const uint32_t blocks = (padded_pixels(ra) + kBlock - 1) / kBlock;
+    const RenderArgs& ra = fb.ra[0];                   /* extent, spp, sharding: the same for every frame of the batch */
+    const uint32_t nb = fb.n;
+    const uint32_t blocks = (padded_pixels(ra) + kBlock - 1) / kBlock;      /* per frame and sample plane */
     hipError_t e;
     if ((e = hipMemsetAsync(ws.queueCount, 0, kQueueCtrlWords * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] / [16 + 16 r] batch cursors */
     if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
@@ -1187,22 +1202,22 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     static const uint32_t kPInnerMin = env_u32("RTR_PRIMARY_INNER_MIN", 20u, 0u, 63u);
     static const uint32_t kPWgsPerCu = env_u32("RTR_PRIMARY_WGS_PER_CU", 8u, 1u, 8u);
     const uint32_t planeStride = blocks * kBlock;
-    if (kPersist && (unsigned long long)planeStride * ra.spp < 0xffffffffull) {
+    if (kPersist && nb == 1u && (unsigned long long)planeStride * ra.spp < 0xffffffffull) {
         uint32_t pblocks = numCus * kPWgsPerCu;
         const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
         if (pblocks > pneeded) pblocks = pneeded;
         if (pblocks == 0) pblocks = 1;
-        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
-        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
-    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * ra.spp), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, blocks);
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * ra.spp), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, blocks);
-    if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
-    else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
+        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, blocks);
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, blocks);
+    if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
+    else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
     static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
     static const uint32_t kWide = two_wide_selected() ? 0u : 1u;   /* RTR_TRACE_BVH4=0: the 2-wide any-hit kernel on the plain queue (same results, for comparison; it has no counting form: rtr_render refuses collectStats with it) */
-    const uint32_t genBlocks = (blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
+    const uint32_t genBlocks = (nb * blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (nb * blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
     /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
      * (k_shadow_gen -> k_shadow_trace4 over eight regions of it).  Binning pays on long queues (+2 % frame rate at 12-25 M rays:
      * the octant forms of the slab test then run 97 % of the time instead of 36 %) and costs on short ones (its 64 short lists
@@ -1211,18 +1226,18 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
      * the same path as the timed one: same queue, same kernel template. */
     const char* binEnv = getenv("RTR_TRACE_BINNED");
     const uint32_t binMode = (binEnv && (binEnv[0] == '0' || binEnv[0] == '1') && !binEnv[1]) ? (uint32_t)(binEnv[0] - '0') : 2u;
-    const size_t maxRaysQ = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
+    const size_t maxRaysQ = (size_t)nb * blocks * kBlock * ra.spp * ra.maxRaysPerSample;
     const bool wide = kWide && sc.nodes4;
     const bool binned = wide && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
                         (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
     static const uint32_t kNtQueue = env_u32("RTR_QUEUE_NT", 1u, 0u, 3u);          /* bit 0: any-hit kernel reads the queue past the caches (default); bit 1: the queue-build kernel writes it so (slower, see queue_load) */
-    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
-    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, ra, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
+    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
+    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
     /* persistent waves: as many workgroups as stay resident (17 KiB of LDS stack + 2.5 KiB of tree top per workgroup -> 8 per CU,
      * the 32-wave hardware maximum), each pulling batches until the queue is empty */
-    const size_t maxRays = (size_t)blocks * kBlock * ra.spp * ra.maxRaysPerSample;
+    const size_t maxRays = (size_t)nb * blocks * kBlock * ra.spp * ra.maxRaysPerSample;
     /* 8 workgroups per CU fill every wave slot, which is what a long queue wants; the short queue of a 1/4 or 1/8 shard is
      * drained in a fraction of a millisecond, and then the other frames' small kernels (which can only start where a persistent
      * wave has retired) matter more: with 6 per CU one rank of 8 renders a frame in 0.394 instead of 0.418 ms and one rank of 4 in
@@ -1257,19 +1272,20 @@ static hipError_t wave_t(const DeviceScene& sc, const RenderArgs& ra, const Fram
     if (ev) hipEventRecord(ev[3], s);
     static const uint32_t kRowWaves = env_u32("RTR_RESOLVE_ROW_WAVES", 0u, 0u, 1u);
     const uint32_t rowWaves = (kRowWaves && ra.tilesPerRow % 8u == 0u && blocks % 2u == 0u) ? 1u : 0u;
-    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
-    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks), dim3(kBlock), 0, s, sc, ra, fo, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
     if (ev) hipEventRecord(ev[4], s);
     return hipGetLastError();
 }
 
-hipError_t launch_wavefront(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, const Workspace& ws,
+hipError_t launch_wavefront(const DeviceScene& sc, const FrameBatch& fb, const Workspace& ws,
                             int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev, uint32_t numCus) {
     if (numCus == 0) numCus = 256;
+    if (fb.n < 1 || fb.n > kMaxBatch) return hipErrorInvalidValue;
     switch (stackEntries) {
-        case 16: return wave_t<16>(sc, ra, fo, ws, stats, stream, ev, numCus);
-        case 32: return wave_t<32>(sc, ra, fo, ws, stats, stream, ev, numCus);
-        case 64: return wave_t<64>(sc, ra, fo, ws, stats, stream, ev, numCus);
+        case 16: return wave_t<16>(sc, fb, ws, stats, stream, ev, numCus);
+        case 32: return wave_t<32>(sc, fb, ws, stats, stream, ev, numCus);
+        case 64: return wave_t<64>(sc, fb, ws, stats, stream, ev, numCus);
         default: return hipErrorInvalidValue;
     }
 }

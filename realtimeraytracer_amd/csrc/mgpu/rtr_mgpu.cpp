@@ -76,7 +76,7 @@ struct Slot {
     hipEvent_t evRender = nullptr, evComm = nullptr;
     uint32_t width = 0, height = 0, rows = 0, bandRows = 0, images = 0;
     bool commPending = false;         /* evComm has been recorded at least once */
-    std::future<int> pending;         /* the enqueue job of the render in flight */
+    std::shared_future<int> pending;  /* the enqueue job of the render in flight (shared by the slots of one batch) */
     bool inFlight = false;
 };
 
@@ -212,43 +212,67 @@ int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t ba
     return RTR_OK;
 }
 
-/* Carries the plan out on this rank's streams.  The slot is prepared (prepare_slot) before this runs. */
-int enqueue(rtr_mgpu* m, Rank& r, int slot, RtrCameraData cam, RtrSceneInfo info, rtr_render_params p, int flags, std::string& err) {
+struct BatchJob {                     /* what one call renders: n frames into n distinct slots with ONE launch of the pipeline per rank */
+    int n = 0;
+    int slots[RTR_MAX_BATCH];
+    RtrCameraData cams[RTR_MAX_BATCH];
+    RtrSceneInfo infos[RTR_MAX_BATCH];
+    rtr_render_params p;
+    int flags = 0;
+};
+
+/* Carries the plan out on this rank's streams; the slots are prepared (prepare_slot) before this runs.  Every slot of the batch has
+ * the SAME plan (rtr_mgpu_plan).  They are executed interleaved: the operations before RENDER for every slot (each slot's previous
+ * exchange must be done with the buffers the launch overwrites), ONE render of all the batch's shards — on the first slot's
+ * render stream, which is "the render stream" of every slot's plan for this batch — then the rest of each slot's plan (its own
+ * events, its own exchange). */
+int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
     W_HIP(hipSetDevice(r.device));
     if (!r.scene) { err = "no scene: call rtr_mgpu_scene_create first"; return RTR_ERR_INVALID_ARGUMENT; }
-    Slot& s = r.slots[slot];
-    if (!slot_matches(m, s, p)) { err = "internal: slot not prepared for this extent"; return RTR_ERR_INVALID_ARGUMENT; }
+    rtr_render_params p = job.p;
+    for (int j = 0; j < job.n; ++j) if (!slot_matches(m, r.slots[job.slots[j]], p)) { err = "internal: slot not prepared for this extent"; return RTR_ERR_INVALID_ARGUMENT; }
     std::vector<rtr_mgpu_op> ops;
-    if (make_plan(r.rank, m->nranks, p.width, p.height, p.bandRows, flags, m->selfExchange ? 1 : 0, ops) != RTR_OK) { err = "internal: no plan for this rank / extent"; return RTR_ERR_INVALID_ARGUMENT; }
-    auto buffer = [&](int which) -> char* {
-        switch (which) {
-            case RTR_MGPU_BUF_LOCAL: return static_cast<char*>(s.local);
-            case RTR_MGPU_BUF_GATHER: return reinterpret_cast<char*>(s.gathered);
-            case RTR_MGPU_BUF_SELF_SRC: return reinterpret_cast<char*>(s.selfSrc);
-            case RTR_MGPU_BUF_FULL: return reinterpret_cast<char*>(s.full);
-            default: return nullptr;
-        }
-    };
+    if (make_plan(r.rank, m->nranks, p.width, p.height, p.bandRows, job.flags, m->selfExchange ? 1 : 0, ops) != RTR_OK) { err = "internal: no plan for this rank / extent"; return RTR_ERR_INVALID_ARGUMENT; }
+    size_t renderAt = ops.size();
+    for (size_t i = 0; i < ops.size(); ++i) if (ops[i].kind == RTR_MGPU_OP_RENDER) { renderAt = i; break; }
+    if (renderAt == ops.size()) { err = "internal: a plan without a render"; return RTR_ERR_INVALID_ARGUMENT; }
+    hipStream_t renderStream = r.renderStream[job.slots[0]];
     bool inGroup = false;
     int rc = RTR_OK;
-    for (const rtr_mgpu_op& o : ops) {
-        hipStream_t st = o.stream == RTR_MGPU_STREAM_RENDER ? r.renderStream[slot] : r.commStream;
+    auto run = [&](Slot& s, const rtr_mgpu_op& o) -> int {
+        auto buffer = [&](int which) -> char* {
+            switch (which) {
+                case RTR_MGPU_BUF_LOCAL: return static_cast<char*>(s.local);
+                case RTR_MGPU_BUF_GATHER: return reinterpret_cast<char*>(s.gathered);
+                case RTR_MGPU_BUF_SELF_SRC: return reinterpret_cast<char*>(s.selfSrc);
+                case RTR_MGPU_BUF_FULL: return reinterpret_cast<char*>(s.full);
+                default: return nullptr;
+            }
+        };
+        hipStream_t st = o.stream == RTR_MGPU_STREAM_RENDER ? renderStream : r.commStream;
         hipEvent_t ev = o.event == RTR_MGPU_EV_RENDER_DONE ? s.evRender : s.evComm;
         hipError_t he = hipSuccess; ncclResult_t ne = ncclSuccess;
+        int c = RTR_OK;
         switch (o.kind) {
             case RTR_MGPU_OP_WAIT:
                 r.stage = "hipStreamWaitEvent";
                 if (o.event == RTR_MGPU_EV_COMM_DONE && !s.commPending) break;       /* first use of the slot */
                 he = hipStreamWaitEvent(st, ev, 0);
                 break;
-            case RTR_MGPU_OP_RENDER: {
-                r.stage = "rtr_render_async";
-                if (buffer(o.buffer) + o.offset != static_cast<char*>(s.local)) { err = "internal: the frame is not bound to the buffer the plan renders into"; rc = RTR_ERR_INVALID_ARGUMENT; break; }
+            case RTR_MGPU_OP_RENDER: {              /* once per batch: s is the first slot */
+                r.stage = "rtr_render_batch_async";
+                rtr_frame* frames[RTR_MAX_BATCH];
+                for (int j = 0; j < job.n; ++j) {
+                    Slot& sj = r.slots[job.slots[j]];
+                    char* target = o.buffer == RTR_MGPU_BUF_LOCAL ? static_cast<char*>(sj.local) : (o.buffer == RTR_MGPU_BUF_GATHER ? reinterpret_cast<char*>(sj.gathered) : reinterpret_cast<char*>(sj.selfSrc));
+                    if (target + o.offset != static_cast<char*>(sj.local)) { err = "internal: the frame is not bound to the buffer the plan renders into"; return RTR_ERR_INVALID_ARGUMENT; }
+                    frames[j] = sj.frame;
+                }
                 p.shardIndex = (uint32_t)o.peer; p.shardCount = (uint32_t)m->nranks;
                 p.images = s.images; p.collectStats = 0;
                 if (!(s.images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { p.accumulate = 0; p.accumulatedFrames = 0; }
-                rc = rtr_render_async(r.scene, &cam, &info, &p, s.frame);
-                if (rc != RTR_OK) err = std::string("rtr_render_async: ") + rtr_last_error();
+                c = rtr_render_batch_async(r.scene, job.cams, job.infos, &p, frames, (uint32_t)job.n);
+                if (c != RTR_OK) err = std::string("rtr_render_batch_async: ") + rtr_last_error();
                 break;
             }
             case RTR_MGPU_OP_RECORD:
@@ -262,17 +286,24 @@ int enqueue(rtr_mgpu* m, Rank& r, int slot, RtrCameraData cam, RtrSceneInfo info
             case RTR_MGPU_OP_GROUP_END: r.stage = "ncclGroupEnd"; inGroup = false; ne = ncclGroupEnd(); break;
             case RTR_MGPU_OP_DEINTERLEAVE:
                 r.stage = "rtr_deinterleave_bands";
-                rc = rtr_deinterleave_bands(r.commCtx, s.gathered, s.full, s.width, s.height, s.bandRows, (uint32_t)m->nranks);
-                if (rc != RTR_OK) err = std::string("rtr_deinterleave_bands: ") + rtr_last_error();
+                c = rtr_deinterleave_bands(r.commCtx, s.gathered, s.full, s.width, s.height, s.bandRows, (uint32_t)m->nranks);
+                if (c != RTR_OK) err = std::string("rtr_deinterleave_bands: ") + rtr_last_error();
                 break;
-            default: err = "internal: unknown operation in the plan"; rc = RTR_ERR_INVALID_ARGUMENT; break;
+            default: err = "internal: unknown operation in the plan"; c = RTR_ERR_INVALID_ARGUMENT; break;
         }
-        if (he != hipSuccess) { err = std::string(r.stage.load()) + ": " + hipGetErrorString(he); rc = RTR_ERR_HIP; }
-        if (ne != ncclSuccess) { err = std::string(r.stage.load()) + ": " + ncclGetErrorString(ne); rc = RTR_ERR_HIP; }
-        if (rc != RTR_OK) {
-            if (inGroup) (void)ncclGroupEnd();     /* never leave this thread inside a group */
-            return rc;                              /* the caller aborts the communicators: peers may already have posted their half */
-        }
+        if (he != hipSuccess) { err = std::string(r.stage.load()) + ": " + hipGetErrorString(he); c = RTR_ERR_HIP; }
+        if (ne != ncclSuccess) { err = std::string(r.stage.load()) + ": " + ncclGetErrorString(ne); c = RTR_ERR_HIP; }
+        return c;
+    };
+    /* before the render, for every slot; the render, once; after it, slot by slot */
+    for (int j = 0; j < job.n && rc == RTR_OK; ++j)
+        for (size_t i = 0; i < renderAt && rc == RTR_OK; ++i) rc = run(r.slots[job.slots[j]], ops[i]);
+    if (rc == RTR_OK) rc = run(r.slots[job.slots[0]], ops[renderAt]);
+    for (int j = 0; j < job.n && rc == RTR_OK; ++j)
+        for (size_t i = renderAt + 1; i < ops.size() && rc == RTR_OK; ++i) rc = run(r.slots[job.slots[j]], ops[i]);
+    if (rc != RTR_OK) {
+        if (inGroup) (void)ncclGroupEnd();     /* never leave this thread inside a group */
+        return rc;                              /* the caller aborts the communicators: peers may already have posted their half */
     }
     r.stage = "idle";
     return RTR_OK;
@@ -343,7 +374,7 @@ std::string stages(const rtr_mgpu* m) {
 }
 
 /* Joins a host-side job with the watchdog.  false = it did not come back in time (the communicators are aborted). */
-bool join_job(rtr_mgpu* m, std::future<int>& f, int* rc) {
+bool join_job(rtr_mgpu* m, std::shared_future<int>& f, int* rc) {
     if (m->timeoutMs == 0) { *rc = f.get(); return true; }
     if (f.wait_for(std::chrono::milliseconds(m->timeoutMs)) != std::future_status::ready) {
         const std::string where = stages(m);
@@ -501,45 +532,60 @@ int rtr_mgpu_scene_create(rtr_mgpu* m, const rtr_scene_desc* desc) {
     return rc;
 }
 
-int rtr_mgpu_render_async(rtr_mgpu* m, int slot, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, int flags) {
-    if (!m || !cam || !info || !p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: null argument");
+int rtr_mgpu_render_batch_async(rtr_mgpu* m, const int* slots, int n, const RtrCameraData* cams, const RtrSceneInfo* infos, const rtr_render_params* p, int flags) {
+    if (!m || !slots || !cams || !infos || !p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: null argument");
     if (m->aborted) return fail(RTR_ERR_HIP, "rtr_mgpu_render_async: the communicators were aborted after an earlier failure; destroy the handle");
-    if (slot < 0 || slot >= m->framesInFlight) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: slot %d not in [0,%d)", slot, m->framesInFlight);
+    if (n < 1 || n > RTR_MAX_BATCH) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_batch_async: %d frames, 1 to %d per launch", n, RTR_MAX_BATCH);
+    for (int j = 0; j < n; ++j) {
+        if (slots[j] < 0 || slots[j] >= m->framesInFlight) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: slot %d not in [0,%d)", slots[j], m->framesInFlight);
+        for (int k = 0; k < j; ++k) if (slots[k] == slots[j]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_batch_async: slot %d given twice", slots[j]);
+    }
     if (p->width == 0 || p->height == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: empty frame");
     if (p->images & ~(RTR_IMAGES_FRAMEBUFFER | RTR_IMG_BIT(RTR_IMAGE_HDR))) return fail(RTR_ERR_UNSUPPORTED, "rtr_mgpu_render_async: only the RGBA8 framebuffer (RTR_IMAGE_SHADOWED) is gathered; RTR_IMAGE_HDR may be added for accumulation");
     if (p->accumulate && !(p->images & RTR_IMG_BIT(RTR_IMAGE_HDR))) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: accumulate needs RTR_IMAGE_HDR in params->images");
     for (auto& rp : m->ranks) if (!rp->scene) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_render_async: no scene: call rtr_mgpu_scene_create first");
     /* consecutive calls on a slot are ordered by its render stream; only an enqueue still running on a worker forbids the next call */
-    for (auto& rp : m->ranks) if (rp->slots[slot].inFlight) {
-        int c = RTR_OK;
-        const bool back = join_job(m, rp->slots[slot].pending, &c);
-        rp->slots[slot].inFlight = false;
-        if (!back) return c;
-        if (c != RTR_OK) { const std::string msg = rp->worker->error(); abort_all(m); return fail(c, "rank %d: %s (communicators aborted)", rp->rank, msg.c_str()); }
-    }
+    for (int j = 0; j < n; ++j)
+        for (auto& rp : m->ranks) if (rp->slots[slots[j]].inFlight) {
+            int c = RTR_OK;
+            const bool back = join_job(m, rp->slots[slots[j]].pending, &c);
+            rp->slots[slots[j]].inFlight = false;
+            if (!back) return c;
+            if (c != RTR_OK) { const std::string msg = rp->worker->error(); abort_all(m); return fail(c, "rank %d: %s (communicators aborted)", rp->rank, msg.c_str()); }
+        }
     /* Phase 1 — everything that can fail for lack of memory, on every local rank, joined BEFORE any rank posts a transfer: a rank
-     * that dropped out after its peers had posted theirs would leave them waiting for ever.  In steady state (the slot already has
+     * that dropped out after its peers had posted theirs would leave them waiting for ever.  In steady state (the slots already have
      * this extent) this is a comparison on the caller's thread. */
     bool prepared = true;
-    for (auto& rp : m->ranks) prepared = prepared && slot_matches(m, rp->slots[slot], *p);
+    for (int j = 0; j < n; ++j) for (auto& rp : m->ranks) prepared = prepared && slot_matches(m, rp->slots[slots[j]], *p);
     if (!prepared) {
         std::vector<std::future<int>> fs;
+        std::vector<int> sl(slots, slots + n);
         for (auto& rp : m->ranks) {
             Rank* r = rp.get(); const rtr_render_params pp = *p;
-            fs.push_back(r->worker->submit([m, r, slot, pp](std::string& err) -> int { return prepare_slot(m, *r, r->slots[slot], pp, err); }));
+            fs.push_back(r->worker->submit([m, r, sl, pp](std::string& err) -> int {
+                for (int s1 : sl) { const int c = prepare_slot(m, *r, r->slots[s1], pp, err); if (c != RTR_OK) return c; }
+                return RTR_OK;
+            }));
         }
         int rc = RTR_OK; size_t i = 0;
         for (auto& f : fs) { const int c = f.get(); if (c != RTR_OK && rc == RTR_OK) rc = fail(c, "rank %d: %s", m->ranks[i]->rank, m->ranks[i]->worker->error().c_str()); ++i; }
         if (rc != RTR_OK) return rc;            /* nothing was posted: the handle stays usable */
     }
     /* Phase 2 — the plan, rank by rank, each on its own thread */
+    BatchJob job;
+    job.n = n; job.p = *p; job.flags = flags;
+    for (int j = 0; j < n; ++j) { job.slots[j] = slots[j]; job.cams[j] = cams[j]; job.infos[j] = infos[j]; }
     for (auto& rp : m->ranks) {
         Rank* r = rp.get();
-        const RtrCameraData c = *cam; const RtrSceneInfo si = *info; const rtr_render_params pp = *p;
-        r->slots[slot].pending = r->worker->submit([m, r, slot, c, si, pp, flags](std::string& err) -> int { return enqueue(m, *r, slot, c, si, pp, flags, err); });
-        r->slots[slot].inFlight = true;
+        std::shared_future<int> f = r->worker->submit([m, r, job](std::string& err) -> int { return enqueue(m, *r, job, err); }).share();
+        for (int j = 0; j < n; ++j) { r->slots[slots[j]].pending = f; r->slots[slots[j]].inFlight = true; }
     }
     return RTR_OK;
+}
+
+int rtr_mgpu_render_async(rtr_mgpu* m, int slot, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, int flags) {
+    return rtr_mgpu_render_batch_async(m, &slot, 1, cam, info, p, flags);
 }
 
 int rtr_mgpu_wait(rtr_mgpu* m, int slot) {

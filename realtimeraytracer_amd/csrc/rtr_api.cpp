@@ -157,6 +157,8 @@ struct rtr_frame {
     rtr_frame_stats stats{};
     bool pendingStats = false, pendingWave = false, pendingCounters = false;
     uint32_t pendingImagesK = 0; bool pendingHdr = false, pendingAccum = false;
+    hipEvent_t evDone = nullptr;         /* a frame rendered as a later frame of a batch: recorded on the leading frame's stream behind the launch */
+    bool viaBatch = false;
     uint32_t* image_ptr(int which) const { return ext[which] ? ext[which] : img[which].p; }
 };
 
@@ -832,6 +834,7 @@ void rtr_frame_destroy(rtr_frame* f) {
     (void)hipStreamSynchronize(f->ctx->stream);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : f->evMega) if (e) (void)hipEventDestroy(e);
+    if (f->evDone) { (void)hipEventSynchronize(f->evDone); (void)hipEventDestroy(f->evDone); }
     rtr_ctx* c = f->ctx;
     delete f;
     ctx_release_child(c);
@@ -864,6 +867,7 @@ int rtr_frame_download(const rtr_frame* f, int which, void* dst, size_t bytes) {
     if (rc != RTR_OK) return rc;
     if (bytes != need) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_download: %zu bytes given, image %d is %zu", bytes, which, need);
     HIP_TRY(hipSetDevice(f->ctx->device));
+    if (f->viaBatch) HIP_TRY(hipEventSynchronize(f->evDone));          /* its pixels came from another frame's stream */
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, f->ctx->stream));
     HIP_TRY(hipStreamSynchronize(f->ctx->stream));
     return RTR_OK;
@@ -880,9 +884,13 @@ int rtr_frame_clear(rtr_frame* f) {
 }
 
 /* ---- dispatch ------------------------------------------------------------------------------ */
-static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* pin, rtr_frame* f) {
-    if (!s || !cam || !info || !pin || !f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: null argument");
-    /* work is enqueued on the FRAME's context stream; the (read-only) scene may belong to another context of the same
+/* Enqueues one launch of the pipeline over n frames (n = 1: rtr_render / rtr_render_async).  frames[0] leads: its context's stream
+ * carries the work, its scratch holds the batch, its statistics describe the launch. */
+static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrSceneInfo* infos, const rtr_render_params* pin, rtr_frame* const* frames, uint32_t n) {
+    if (!s || !cams || !infos || !pin || !frames || n < 1 || !frames[0]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: null argument");
+    if (n > rtrdev::kMaxBatch) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: %u frames, at most %u per launch", n, rtrdev::kMaxBatch);
+    rtr_frame* f = frames[0];
+    /* work is enqueued on the (leading) FRAME's context stream; the (read-only) scene may belong to another context of the same
      * device, so two frames on two streams can be in flight against one scene */
     if (s->ctx->device != f->ctx->device) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: scene and frame live on different devices");
     rtr_render_params p = *pin;
@@ -893,33 +901,46 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
         return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: bad width/height/spp/numShadowRays (%u,%u,%u,%u)", p.width, p.height, p.spp, p.numShadowRays);
     if (p.bandRows % 8u) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: bandRows %u must be a multiple of 8 (one wave = one 8x8 tile)", p.bandRows);
     if (p.shardIndex >= p.shardCount) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: shardIndex %u >= shardCount %u", p.shardIndex, p.shardCount);
-    if (info->numAreaLights > s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: SceneInfo.numAreaLights %u > scene lights %u", info->numAreaLights, s->numLights);
     const uint32_t rows = rtr_shard_rows(p.height, p.bandRows, p.shardCount);
-    if (f->width != p.width || f->rows != rows) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame is %ux%u, this shard needs %ux%u", f->width, f->rows, p.width, rows);
     if (p.images & RTR_IMAGES_DENOISE) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: denoise/combine images are produced by rtr_denoise_combine, not by the ray-gen dispatch");
     if ((p.images & RTR_IMG_BIT(RTR_IMAGE_ANALYTIC)) && !s->hasLtc) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: RTR_IMAGE_ANALYTIC needs the LTC tables (rtr_scene_desc.ltc1/ltc2)");
     const bool wantHdr = (p.images & RTR_IMG_BIT(RTR_IMAGE_HDR)) != 0 || p.accumulate;
-    if (wantHdr && !f->hdr.p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: HDR accumulation requested but the frame has no RTR_IMAGE_HDR");
-    FrameOut fo{};
-    uint32_t k = 0;
-    for (int i = 0; i < 8; ++i) {
-        fo.img[i] = nullptr;
-        if (p.images & RTR_IMG_BIT(i)) {
-            if (!f->image_ptr(i)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: image %d requested but not in the frame", i);
-            fo.img[i] = f->image_ptr(i); ++k;
-        }
-    }
-    fo.hdr = wantHdr ? f->hdr.p : nullptr;
+    if (n > 1 && p.pipeline == 1) return fail(RTR_ERR_UNSUPPORTED, "rtr_render_batch_async: the megakernel renders one frame per launch");
 
-    RenderArgs ra{};
-    ra.cam = *cam; ra.info = *info;
-    ra.width = p.width; ra.height = p.height; ra.spp = p.spp; ra.numShadowRays = p.numShadowRays;
-    ra.bandRows = p.bandRows; ra.shardIndex = p.shardIndex; ra.shardCount = p.shardCount;
-    ra.localRows = rows; ra.tilesPerRow = (p.width + 7u) / 8u;
-    ra.images = p.images; ra.accumulate = p.accumulate; ra.accumulatedFrames = p.accumulatedFrames;
+    rtrdev::FrameBatch fb{};
+    fb.n = n;
+    uint32_t k = 0;
     uint64_t maxRays = 1;
-    for (uint32_t l = 0; l < info->numAreaLights; ++l) maxRays += (uint64_t)s->hostLights[l].numTriangles * p.numShadowRays;
-    ra.maxRaysPerSample = (uint32_t)maxRays;
+    for (uint32_t b = 0; b < n; ++b) {
+        rtr_frame* fr = frames[b];
+        if (!fr) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: frame %u is null", b);
+        for (uint32_t c = 0; c < b; ++c) if (frames[c] == fr) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: frame %u given twice", b);
+        if (fr->ctx->device != f->ctx->device) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: frame %u lives on another device", b);
+        if (infos[b].numAreaLights > s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: SceneInfo.numAreaLights %u > scene lights %u", infos[b].numAreaLights, s->numLights);
+        if (infos[b].numAreaLights != infos[0].numAreaLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: the frames of a launch must use the same number of area lights");
+        if (fr->width != p.width || fr->rows != rows) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame is %ux%u, this shard needs %ux%u", fr->width, fr->rows, p.width, rows);
+        if (wantHdr && !fr->hdr.p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: HDR accumulation requested but the frame has no RTR_IMAGE_HDR");
+        FrameOut& fo = fb.fo[b];
+        k = 0;
+        for (int i = 0; i < 8; ++i) {
+            fo.img[i] = nullptr;
+            if (p.images & RTR_IMG_BIT(i)) {
+                if (!fr->image_ptr(i)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: image %d requested but not in the frame", i);
+                fo.img[i] = fr->image_ptr(i); ++k;
+            }
+        }
+        fo.hdr = wantHdr ? fr->hdr.p : nullptr;
+        RenderArgs& ra = fb.ra[b];
+        ra.cam = cams[b]; ra.info = infos[b];
+        ra.width = p.width; ra.height = p.height; ra.spp = p.spp; ra.numShadowRays = p.numShadowRays;
+        ra.bandRows = p.bandRows; ra.shardIndex = p.shardIndex; ra.shardCount = p.shardCount;
+        ra.localRows = rows; ra.tilesPerRow = (p.width + 7u) / 8u;
+        ra.images = p.images; ra.accumulate = p.accumulate; ra.accumulatedFrames = p.accumulatedFrames;
+        if (b == 0) for (uint32_t l = 0; l < infos[0].numAreaLights; ++l) maxRays += (uint64_t)s->hostLights[l].numTriangles * p.numShadowRays;
+        ra.maxRaysPerSample = (uint32_t)maxRays;
+    }
+    const RenderArgs& ra = fb.ra[0];
+    const FrameOut& fo = fb.fo[0];
 
     HIP_TRY(hipSetDevice(f->ctx->device));
     hipStream_t st = f->ctx->stream;
@@ -928,17 +949,17 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
 
     const uint64_t paddedPixels = (uint64_t)((rows + 7u) / 8u) * ra.tilesPerRow * 64u;
     const uint64_t blocks = (paddedPixels + 255u) / 256u;
-    const uint64_t nPS = blocks * 256u * p.spp;
+    const uint64_t nPS = blocks * 256u * p.spp * n;          /* pixel-sample slots of the launch */
     const uint64_t nRays = nPS * maxRays;                    /* queue capacity: every pixel-sample issuing every query */
     uint64_t slotStride = 256;                                /* the visibility planes are a power of two apart, so a slot names its pixel-sample with a mask */
     while (slotStride < nPS) slotStride <<= 1;
     const uint64_t nSlots = slotStride * maxRays;
     bool wave = p.pipeline != 1;
     if (wave && (nSlots >= (1ull << 31) || maxRays > 4096)) {
-        if (p.pipeline == 2) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: wavefront scratch would need %llu visibility slots", (unsigned long long)nSlots);
+        if (p.pipeline == 2 || n > 1) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: wavefront scratch would need %llu visibility slots", (unsigned long long)nSlots);
         wave = false;
     }
-    if (blocks >= (1ull << 31)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame too large");
+    if (blocks * n >= (1ull << 31)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame too large");
 
     /* the counting form IS the timed kernel template; the 2-wide comparison kernel has none, and counting another kernel's work
      * under its name would be a wrong number */
@@ -947,7 +968,8 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     f->pendingWave = wave; f->pendingCounters = p.collectStats != 0;
     f->pendingImagesK = k; f->pendingHdr = wantHdr; f->pendingAccum = p.accumulate != 0;
     memset(&f->stats, 0, sizeof f->stats);
-    f->stats.localRows = rows; f->stats.localPixels = rows * p.width;
+    f->stats.localRows = rows; f->stats.localPixels = rows * p.width * n;
+    f->viaBatch = false;
     hipError_t e;
     if (wave) {
         /* the list of rays left to the redo kernels: the camera rays' needs one entry per pixel-sample at most; the any-hit kernel's
@@ -963,6 +985,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
              * its octant, so a list holds at most 1/8 of one batch per 64 rays (the smallest batch) + one per k_shadow_gen_oct workgroup */
             f->listStride = (uint32_t)(nRays / 64 / rtrdev::kQueueRegions + nPS / 256 + 16);
             HIP_TRY(f->batchLists.alloc((size_t)f->listStride * rtrdev::kQueueLists)); }
+        else if (getenv("RTR_TRACE_OVERFLOW_CAP")) f->overflowCap = (uint32_t)std::min<uint64_t>(ovUse, f->overflow.n - 1);
         f->slotStride = (uint32_t)slotStride;
         if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(rtrdev::kQueueCtrlWords));
         if (!f->clk.p) { HIP_TRY(f->clk.alloc(2 * rtrdev::kQueueRegions)); HIP_TRY(hipMemsetAsync(f->clk.p, 0, 2 * rtrdev::kQueueRegions * sizeof(unsigned long long), st)); }
@@ -972,7 +995,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
         if (const char* e = getenv("RTR_TRACE_VIS_FILL")) if ((e[0] == '0' || e[0] == '1') && !e[1]) ws.visFill = (uint32_t)(e[0] - '0');      /* test hook: force the pre-fill */
         ws.rayQueue.dt = f->rayDT.p; ws.rayQueue.slot = f->raySlot.p; ws.rayQueue.origin = f->rayOrigin.p; ws.rayQueue.slotStride = f->slotStride; ws.rayQueue.slotMask = f->slotStride - 1u;
         ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nRays; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.overflowCap = f->overflowCap; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride; ws.clk = f->clk.p;
-        e = rtrdev::launch_wavefront(s->dev, ra, fo, ws, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
+        e = rtrdev::launch_wavefront(s->dev, fb, ws, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
     } else {
         (void)hipEventRecord(f->evMega[0], st);
         e = rtrdev::launch_megakernel(s->dev, ra, fo, (int)s->stats.stackEntries, dstats, st);
@@ -980,6 +1003,14 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cam, const RtrScene
     }
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     f->pendingStats = true;
+    /* the other frames of the batch were rendered on THIS frame's stream: each gets an event behind the launch to wait on */
+    for (uint32_t b = 1; b < n; ++b) {
+        rtr_frame* fr = frames[b];
+        if (!fr->evDone) HIP_TRY(hipEventCreateWithFlags(&fr->evDone, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(fr->evDone, st));
+        fr->viaBatch = true; fr->pendingStats = false;
+        memset(&fr->stats, 0, sizeof fr->stats);
+    }
     return RTR_OK;
 }
 
@@ -987,6 +1018,7 @@ int rtr_frame_wait(rtr_frame* f) {
     if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_wait: null frame");
     HIP_TRY(hipSetDevice(f->ctx->device));
     HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    if (f->viaBatch) { HIP_TRY(hipEventSynchronize(f->evDone)); return RTR_OK; }      /* rendered in another frame's launch: that launch's times and counters are the leading frame's */
     if (!f->pendingStats) return RTR_OK;
     f->pendingStats = false;
     rtr_frame_stats& s = f->stats;
@@ -1042,11 +1074,15 @@ int rtr_frame_wait(rtr_frame* f) {
 }
 
 int rtr_render_async(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, rtr_frame* f) {
-    return enqueue_render(s, cam, info, p, f);
+    return enqueue_render(s, cam, info, p, &f, 1);
+}
+
+int rtr_render_batch_async(rtr_scene* s, const RtrCameraData* cams, const RtrSceneInfo* infos, const rtr_render_params* p, rtr_frame* const* frames, uint32_t n) {
+    return enqueue_render(s, cams, infos, p, frames, n);
 }
 
 int rtr_render(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, rtr_frame* f) {
-    int rc = enqueue_render(s, cam, info, p, f);
+    int rc = enqueue_render(s, cam, info, p, &f, 1);
     if (rc != RTR_OK) return rc;
     return rtr_frame_wait(f);
 }

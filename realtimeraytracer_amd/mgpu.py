@@ -112,6 +112,16 @@ class MultiGpu:
         self._check(self.lib.rtr_mgpu_render_async(self.h, slot, C.byref(camera), C.byref(scene_info), C.byref(params), 0 if exchange else 1), "rtr_mgpu_render_async")
         self._extent[slot] = (params.height, params.width, params.bandRows or 8)
 
+    def render_batch_async(self, slots, cameras, scene_infos, params, exchange=True):
+        """rtr_mgpu_render_batch_async: len(slots) frames with one launch of the pipeline per rank, then every slot's exchange"""
+        import ctypes as C
+        from . import _abi as A
+        n = len(slots)
+        self._check(self.lib.rtr_mgpu_render_batch_async(self.h, (C.c_int * n)(*slots), n, (A.RtrCameraData * n)(*cameras), (A.RtrSceneInfo * n)(*scene_infos),
+                                                         C.byref(params), 0 if exchange else 1), "rtr_mgpu_render_batch_async")
+        for s1 in slots:
+            self._extent[s1] = (params.height, params.width, params.bandRows or 8)
+
     def wait(self, slot):
         self._check(self.lib.rtr_mgpu_wait(self.h, slot), "rtr_mgpu_wait")
 

@@ -21,16 +21,17 @@ def _plan(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTR_B
 
 def test_one_gpu_is_a_single_process():
     d = _plan([])
-    assert d["mode"] == "single" and d["n_gpus"] == 1 and d["frames_in_flight"] == 4 and d["env_defaults"] == {}
+    assert d["mode"] == "single" and d["n_gpus"] == 1 and d["frames_in_flight"] == 8 and d["frames_per_launch"] == 8
+    assert _plan(["--batch", "1", "--frames-in-flight", "4"])["frames_per_launch"] == 1 and _plan(["--frames-in-flight", "4"])["frames_per_launch"] == 4
 
 
 def test_started_plainly_n_gpus_run_in_one_process_through_the_library():
     for n in (2, 4, 8):
         d = _plan(["--gpus", str(n), "--steps", "5"])
         assert d["mode"] == "inproc" and d["library_entry"] == "rtr_mgpu_create" and d["devices"] == list(range(n)) and d["world"] == n
-    # the N >= 4 settings live in bench.py, not in the caller's environment
+    # the settings of an N-GPU run live in bench.py, not in the caller's environment
     assert _plan(["--gpus", "8"])["frames_in_flight"] == 8 and _plan(["--gpus", "8"])["env_defaults"] == {"GPU_MAX_HW_QUEUES": "8"}
-    assert _plan(["--gpus", "2"])["frames_in_flight"] == 4 and _plan(["--gpus", "8", "--frames-in-flight", "2"])["frames_in_flight"] == 2
+    assert _plan(["--gpus", "8"])["frames_per_launch"] == 8 and _plan(["--gpus", "8", "--frames-in-flight", "2"])["frames_in_flight"] == 2
 
 
 def test_under_torch_distributed_run_every_process_is_one_rank():

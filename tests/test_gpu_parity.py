@@ -687,6 +687,56 @@ def test_visibility_prefill_polarity_does_not_change_a_pixel(gpu_ctx, oracle, sc
         os.environ.pop("RTR_TRACE_VIS_FILL", None)
 
 
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_batched_frames_equal_single_renders(gpu_ctx, oracle, scene_cache, queue_mode, n):
+    """rtr_render_batch_async: n frames (own camera, own seed, own images) in ONE launch of every kernel give the pixels n launches
+    give — and the oracle's — sharded and unsharded; the counting form's counters are the sum of the single frames'; a frame that
+    was a follower of a batch renders alone again afterwards."""
+    from realtimeraytracer_amd import host
+    W, H = 200, 120
+    s = scenes.bunny_class(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    cams = []
+    for b in range(n):
+        pos = (s.cam_pos[0] + 0.3 * b, s.cam_pos[1] + 0.1 * b, s.cam_pos[2])
+        cams.append(host.Camera(55.0 + b, pos, (0.0, 0.6, 0.0), (0.0, 1.0, 0.0), W, H).getGPUData())
+    infos = [s.scene_info(7 + 3 * b) for b in range(n)]
+    for shard in ((0, 1), (1, 3)):
+        rows = api.shard_rows(H, 8, shard[1])
+        for collect in (0, 1):
+            p = api.make_params(W, H, spp=2, collect_stats=collect, pipeline=2, shard_index=shard[0], shard_count=shard[1])
+            singles, stats = [], []
+            f1 = api.Frame(gpu_ctx, W, rows)
+            for b in range(n):
+                api.render(scene, cams[b], infos[b], p, f1)
+                singles.append(f1.download()); stats.append(f1.stats())
+            frames = [api.Frame(gpu_ctx, W, rows) for _ in range(n)]
+            api.render_batch(scene, cams, infos, p, frames)
+            frames[-1].wait()                                   # any frame of the batch joins the launch
+            for b in range(n):
+                _assert_same(frames[b].download(), singles[b], f"batch of {n}, frame {b}, shard {shard}, collect {collect}")
+            frames[0].wait()
+            if collect:
+                g = frames[0].stats()
+                for fld in ("numRays", "numPrimaryRays", "numShadowRays", "numNodeVisits", "numTriTests", "numShadowNodeVisits", "numShadowTriTests", "numHits"):
+                    assert getattr(g, fld) == sum(getattr(t, fld) for t in stats), fld
+            if shard == (0, 1) and collect == 0:
+                ref = oracle.render(s.desc, cams[n - 1], infos[n - 1], p, bvh=bvh, threads=16)
+                _assert_same(frames[n - 1].download(), ref.images[A.IMAGE_SHADOWED], f"batch of {n}, last frame vs oracle")
+                api.render(scene, cams[0], infos[0], p, frames[n - 1])        # a follower leads its own launch afterwards
+                _assert_same(frames[n - 1].download(), singles[0], "former follower rendered alone")
+    # refused: too many frames, the same frame twice, the megakernel
+    many = [api.Frame(gpu_ctx, W, H) for _ in range(A.MAX_BATCH + 1)]
+    p = api.make_params(W, H, spp=1)
+    with pytest.raises(api.RtrError):
+        api.render_batch(scene, [cams[0]] * len(many), [infos[0]] * len(many), p, many)
+    with pytest.raises(api.RtrError):
+        api.render_batch(scene, [cams[0]] * 2, [infos[0]] * 2, p, [many[0], many[0]])
+    with pytest.raises(api.RtrError):
+        api.render_batch(scene, [cams[0]] * 2, [infos[0]] * 2, api.make_params(W, H, spp=1, pipeline=1), many[:2])
+
+
 def _run_staged_child(code, env, timeout):
     """A child process whose script announces every library call before making it (STAGE lines, flushed): when the child hangs, the
     timeout says where it stopped instead of nothing (round 2's 240-s hang left only RCCL's banner on stdout)."""
@@ -751,6 +801,11 @@ def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
         m.render_async(1, s.camera, s.scene_info(0), p2)         # the slot is re-created (phase 1 on every rank, joined) before anything is posted
         m.wait(1)
         small = m.download(1)
+        stage("rtr_mgpu_render_batch_async slots 0, 1")
+        m.render_batch_async([0, 1], [s.camera, s.camera], [s.scene_info(5), s.scene_info(6)], p)     # ONE launch of the pipeline per rank, each slot its own exchange
+        stage("rtr_mgpu_wait slots 1, 0 of the batch")
+        m.wait(1); m.wait(0)
+        gb = {5: m.download(0), 6: m.download(1)}
         stage("reference renders")
         ctx = api.Context(0)
         scene = api.Scene(ctx, s.desc)
@@ -762,6 +817,9 @@ def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
             assert int((got != whole).sum()) == 0, ("assembled vs unsharded", f, int((got != whole).sum()))
             ref = O.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, threads=8)
             assert int((got != ref.images[A.IMAGE_SHADOWED]).sum()) == 0, ("assembled vs oracle", f)
+        for f, got in gb.items():
+            api.render(scene, s.camera, s.scene_info(f), p, frame)
+            assert int((got != frame.download()).sum()) == 0, ("batched slots, assembled vs unsharded", f)
         frame2 = api.Frame(ctx, 320, 184)
         api.render(scene, s.camera, s.scene_info(0), p2, frame2)
         assert int((small != frame2.download()).sum()) == 0, "assembled vs unsharded, second extent"
