@@ -626,9 +626,15 @@ def main():
     out = None
     if rank == 0:
         n = max(kern["n"], 1)
-        bracket_ms = kern["shadow_trace"] / n                      # in-region HIP-event bracket
-        trace_ms = kern_iso["shadow_trace"] if kern_iso else bracket_ms
-        trace_bytes = fs.shadowTraceBytes                         # rank 0's launch
+        bracket_ms = kern["shadow_trace"] / n                      # in-region HIP-event bracket, per frame
+        # With B frames per launch and no more frame objects than one launch takes, ONE launch of every kernel is on the GPU at a time:
+        # the HIP-event brackets of the TIMED REGION are the kernels' own durations, and the roofline is that of the launches the
+        # headline number is made of (B frames' rays each).  Otherwise launches of different frames overlap and the kernel's own
+        # duration comes from the one-frame-at-a-time pass after the timed region.
+        own_launch = B > 1 and nbuf == B and not dist_on
+        launch_frames = B if own_launch else 1
+        trace_ms = bracket_ms * B if own_launch else (kern_iso["shadow_trace"] if kern_iso else bracket_ms)
+        trace_bytes = fs.shadowTraceBytes * launch_frames         # rank 0's launch
         roofline, roofline2, frame_hbm = None, None, None
         if pipeline_used == 2 and trace_ms > 0:
             rev = A.hip_lib().rtr_kernel_revision().decode()
@@ -637,19 +643,19 @@ def main():
             # command (profiles/pmc_r03.sh -> profiles/r03/pmc_roofline.json) and are only used when they describe THIS run — same
             # workload key, kernel revision, triangle count and queue length (= the shadow rays the counting form counted just now)
             tpath = os.path.join(ROOT, "profiles", "r03", "pmc_roofline.json")
-            key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
+            key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}" + (f"_batch{launch_frames}" if launch_frames > 1 else "")
             try:
                 pmc = json.load(open(tpath)).get(key)
                 if pmc is None:
                     pmc_note = f"no committed counter passes for {key}"
                 elif pmc.get("kernel_revision") != rev:
                     pmc, pmc_note = None, f"committed counters are of kernel revision {pmc.get('kernel_revision')}, this library is {rev}"
-                elif pmc.get("triangles") != int(sstats.numTriangles) or pmc.get("rays_per_launch") != sched["shadow_rays"]:
+                elif pmc.get("triangles") != int(sstats.numTriangles) or pmc.get("rays_per_launch") != sched["shadow_rays"] * launch_frames:
                     pmc, pmc_note = None, (f"committed counters are of a launch over {pmc.get('triangles')} triangles / {pmc.get('rays_per_launch')} queued rays, "
-                                           f"this run has {int(sstats.numTriangles)} / {sched['shadow_rays']}")
+                                           f"this run has {int(sstats.numTriangles)} / {sched['shadow_rays'] * launch_frames}")
             except Exception as e:      # noqa: BLE001
                 pmc_note = f"{tpath}: {e}"
-            ck = clocks_iso if (kern_iso and clocks_iso) else clocks
+            ck = clocks if own_launch else (clocks_iso if (kern_iso and clocks_iso) else clocks)
             clock_mhz = sorted(ck)[len(ck) // 2] if ck else None
             num_simds = 4 * torch.cuda.get_device_properties(device).multi_processor_count
             launch_cycles = trace_ms * 1e-3 * clock_mhz * 1e6 if clock_mhz else None
@@ -664,16 +670,20 @@ def main():
                 "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch)",
                 "frac": round(busy / launch_cycles, 4) if (busy and launch_cycles) else None,
                 "avg_launch_ms": round(trace_ms, 4),
-                "avg_launch_ms_source": (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
-                                         if kern_iso else "HIP events on the launch stream over the timed region"),
-                "in_flight_event_bracket_ms": round(bracket_ms, 4) if kern_iso else None,
+                "frames_per_launch": launch_frames, "avg_ms_per_frame": round(trace_ms / launch_frames, 4),
+                "avg_launch_ms_source": ("HIP events on the launch stream over the TIMED REGION: one launch of every kernel at a time, each over "
+                                         f"{launch_frames} frames' rays" if own_launch else
+                                         (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
+                                          if kern_iso else "HIP events on the launch stream over the timed region")),
+                "one_frame_launch_ms": round(kern_iso["shadow_trace"], 4) if kern_iso else None,
+                "in_flight_event_bracket_ms": round(bracket_ms, 4) if (kern_iso and not own_launch) else None,
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
                 # the same stamps from the timed region, where four frames share the GPU: the clock the chip sustains under that load
                 "clock_mhz_in_flight": round(sorted(clocks)[len(clocks) // 2], 1) if clocks else None,
                 "clock_source": "s_memtime / s_memrealtime stamps around the launch's persistent loop (lane 0 of the first workgroup of each XCD, median), same launches as avg_launch_ms",
                 "simds": num_simds,
                 "valu_wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]) if pmc else None,
-                "valu_wave_insts_per_ray": round(pmc["SQ_INSTS_VALU"] / sched["shadow_rays"], 2) if pmc else None,
+                "valu_wave_insts_per_ray": round(pmc["SQ_INSTS_VALU"] / (sched["shadow_rays"] * launch_frames), 2) if pmc else None,
                 # dead lanes: what fraction of the lanes did work in the trips of the kernel's two loops (counting form of the same kernel,
                 # run in this process), and what the hardware says for all vector instructions (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))
                 "lane_util": {"node_loop": round(sched["node_loop_lanes"] / max(64 * sched["node_loop_trips"], 1), 4),
@@ -699,21 +709,23 @@ def main():
                              "(checked against this run: workload, kernel revision, triangles, queue length); avg_launch_ms, clock_mhz, lane_util, per_ray, schedule "
                              "and algorithmic_* are measured by this process") if pmc else None,
                 "layout": {"bvh": int(sstats.bvhLayoutVersion), "wide": int(sstats.wideLayoutVersion)}}
-            if pmc and pmc.get("kernels", {}).get("k_shadow_gen_oct") and kern_iso:
+            if pmc and pmc.get("kernels", {}).get("k_shadow_gen_oct") and (kern_iso or own_launch):
                 # the one kernel of the frame that IS bound by HBM: it writes the ray queue (20 B per ray + 16 B per pixel-sample) as fast as the memory takes it
                 g = pmc["kernels"]["k_shadow_gen_oct"]
-                gen_ms = kern_iso["shadow_gen"]
+                gen_ms = (kern["shadow_gen"] / n) * B if own_launch else kern_iso["shadow_gen"]
                 gbytes = g["read_bytes"] + g["write_bytes"]
                 roofline2 = {"bound": "hbm", "kernel": "k_shadow_gen_oct: shadow-ray generation into the queue binned by direction octant",
                              "achieved": round(gbytes / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "frac_of_measured_copy_rate": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS, 4),
                              "traffic": gbytes, "read_bytes": g["read_bytes"], "write_bytes": g["write_bytes"],
-                             "algorithmic_bytes_per_launch": int(20 * sched["shadow_rays"] + (20 + 16) * fs.numPrimaryRays),      # 20-B ray records + 16-B origins out, 20-B hit records in
-                             "avg_launch_ms": round(gen_ms, 4), "avg_launch_ms_source": "HIP events on the launch stream, frames rendered one at a time (this run)",
+                             "algorithmic_bytes_per_launch": int(20 * sched["shadow_rays"] + (20 + 16) * fs.numPrimaryRays) * launch_frames,      # 20-B ray records + 16-B origins out, 20-B hit records in
+                             "frames_per_launch": launch_frames,
+                             "avg_launch_ms": round(gen_ms, 4), "avg_launch_ms_source": "HIP events on the launch stream, " + ("timed region (one launch at a time)" if own_launch else "frames rendered one at a time (this run)"),
                              "counters": "bytes from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; FETCH_SIZE's streamed part doubled, gfx950), duration from this run"}
                 fb = pmc.get("frame_hbm_bytes")
-                frame_hbm = {"bytes_per_frame": fb, "per_kernel": {kk: vv["read_bytes"] + vv["write_bytes"] for kk, vv in pmc["kernels"].items()},
+                fb = fb / launch_frames if fb else fb          # the counters are per launch
+                frame_hbm = {"bytes_per_frame": int(fb) if fb else None, "per_kernel_per_launch": {kk: vv["read_bytes"] + vv["write_bytes"] for kk, vv in pmc["kernels"].items()},
                              "gbps_at_ms_per_step": round(fb / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(fb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "scope": "sum of the frame's four kernels' HBM bytes (committed counter passes) over this run's frame time with frames in flight"} if fb else None
         elif trace_ms == 0 and kern["primary"] > 0:

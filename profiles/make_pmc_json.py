@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/make_pmc_json.py <gpurun_out/prof_TAG/pmc.json> <workload key> <kernel revision> <rays per launch> <pixel-samples> <triangles> > profiles/r03/pmc_roofline.json
+"""profiles/make_pmc_json.py <gpurun_out/prof_TAG/pmc.json> <workload key> <kernel revision> <rays per frame> <pixel-samples per frame> <triangles> [frames per launch] > profiles/r03/pmc_roofline.json
 Turns the per-kernel counter means of profiles/pmc_r03.sh into the per-launch figures bench.py reads: the any-hit kernel's issue /
 L1 / HBM counters (its roofline block), and the HBM bytes of every kernel of the frame (roofline_secondary for the queue-build
 kernel, frame_hbm), with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section) applied and spelled out:
@@ -8,6 +8,10 @@ import json
 import sys
 
 src, key, rev, rays, nps, ntri = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+frames = int(sys.argv[7]) if len(sys.argv) > 7 else 1          # frames per launch of the pipeline (bench.py --batch)
+rays, nps = rays * frames, nps * frames
+if frames > 1:
+    key += f"_batch{frames}"
 pmc = json.load(open(src))
 
 
@@ -19,6 +23,8 @@ def pick(*needles):
 
 
 name, k = pick("k_shadow_trace4<16, true, false>") if any("k_shadow_trace4<16, true, false>" in x for x in pmc) else pick("k_shadow_trace4<16, false, false>")
+# the counting form and the set-up renders launch the same kernels over ONE frame: the means must be over the batched launches only;
+# pmc_r03.sh therefore keeps per-kernel means of the launches whose duration is within 2x of the longest (see its python part)
 
 
 def hbm(entry, stream_read_bytes):
@@ -45,7 +51,7 @@ out = {
                 "rendered one at a time); read by bench.py for its roofline, roofline_secondary and frame_hbm blocks, which check workload, "
                 "kernel revision, triangle count and queue length against the run before using them",
     key: {
-        "kernel": name, "kernel_revision": rev, "rays_per_launch": rays, "pixel_samples": nps, "triangles": ntri,
+        "kernel": name, "kernel_revision": rev, "rays_per_launch": rays, "pixel_samples": nps, "triangles": ntri, "frames_per_launch": frames,
         "rocprof_avg_launch_ms": k["avg_ms"], "rocprof_calls": k["calls"],
         "SQ_WAVES": k["SQ_WAVES"], "SQ_WAVE_CYCLES_quad": k["SQ_WAVE_CYCLES"],
         "SQ_INSTS_VALU": k["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad": k["SQ_ACTIVE_INST_VALU"],
