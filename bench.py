@@ -165,9 +165,11 @@ def run_inproc(args, K, plan):
         kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
 
     B = max(1, min(plan["frames_per_launch"], nbuf, A.MAX_BATCH)) if K == 1 else 1
+    groups, launch_no, last_slot = max(nbuf // B, 1), [0], [0]
 
     def step(i):
         b = i % nbuf
+        last_slot[0] = b
         collect(b)                                      # frame i - nbuf: done long ago unless the host runs ahead
         for j in range(K):
             mg.render_async(b, setup.camera, setup.scene_info(j if K > 1 else i), p_run[j], exchange=(j == K - 1))
@@ -182,7 +184,10 @@ def run_inproc(args, K, plan):
         i = first
         while i < first + count:
             c = min(B, first + count - i)
-            bufs = [(i + j) % nbuf for j in range(c)]
+            g0 = (launch_no[0] % groups) * B            # fixed groups of slots: the slot that leads a launch owns its scratch
+            launch_no[0] += 1
+            bufs = [g0 + j for j in range(c)]
+            last_slot[0] = bufs[-1]
             for b in bufs:
                 collect(b)
             mg.render_batch_async(bufs, [setup.camera] * c, [setup.scene_info(i + j) for j in range(c)], p_run[0])
@@ -202,7 +207,8 @@ def run_inproc(args, K, plan):
         step(b)
     drain()
     if B > 1:                                           # ... and the leading slots' scratch grows to the batch on the first batched one
-        run_steps(0, nbuf)
+        for _ in range(groups):
+            run_steps(0, B)
         drain()
     run_steps(0, args.warmup)
     drain()
@@ -218,7 +224,7 @@ def run_inproc(args, K, plan):
     last_i = args.warmup + args.steps - 1
     for j in range(K):
         api.render(scene, setup.camera, setup.scene_info(j if K > 1 else last_i), params(0, j=j), whole)
-    bad = int((mg.download(last_i % nbuf) != whole.download()).sum())
+    bad = int((mg.download(last_slot[0]) != whole.download()).sum())
     info = mg.info
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     n = max(kern["n"], 1)
@@ -486,9 +492,16 @@ def main():
 
     B = max(1, min(plan["frames_per_launch"], nbuf, A.MAX_BATCH)) if (K == 1 and (use_lib or not dist_on)) else 1
 
+    groups = max(nbuf // B, 1)
+    launch_no = [0]
+
     def step_batch(i0, count):
-        """frames i0 .. i0+count-1 in ONE launch of every kernel (rtr_render_batch_async), on the stream of the first one's buffer"""
-        bufs = [(i0 + j) % nbuf for j in range(count)]
+        """frames i0 .. i0+count-1 in ONE launch of every kernel (rtr_render_batch_async), on the stream of the first one's buffer.
+        The frame objects are used in fixed groups of B, so the frame that leads a launch — and owns the launch's scratch — is always
+        one of the same few, whatever --warmup and --steps are (a fresh leader would allocate inside the timed region)."""
+        g0 = (launch_no[0] % groups) * B
+        launch_no[0] += 1
+        bufs = [g0 + j for j in range(count)]
         last_buf[0] = bufs[-1]
         if use_lib:                                     # one launch of the pipeline per rank for the batch, then every slot's exchange
             for b in bufs:
@@ -555,7 +568,8 @@ def main():
             step(b)                                     # the library's slots allocate on their first render too
     drain()
     if B > 1:                                           # the leading frames' scratch grows to the batch on its first batched render
-        run_steps(0, nbuf)
+        for _ in range(groups):
+            run_steps(0, B)
         drain()
     run_steps(0, args.warmup)
     drain()
@@ -804,7 +818,7 @@ def main():
         whole = api.Frame(ctx, W, H, images)
         render_step(whole, last_i, [params(0, 0, 1, j=j) for j in range(K)], False)
         torch.cuda.synchronize()
-        assembled = mg.download(last_i % nbuf) if use_lib else fulls[last_i % nbuf].cpu().numpy().view(np.uint32)
+        assembled = mg.download(last_buf[0]) if use_lib else fulls[last_buf[0]].cpu().numpy().view(np.uint32)
         bad = int((assembled != whole.download()).sum())
         out["verify"] = {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i,
                          "gather": "librtr_mgpu.so: grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave" if use_lib else "torch.distributed gather (rehearsal backend)"}
