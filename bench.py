@@ -613,7 +613,7 @@ def main():
         pscene = api.Scene(ctx, psetup.desc)
         pframe = api.Frame(ctx, W, H, 0xff)
         pp = api.make_params(W, H, spp=4, shadow_rays=args.shadow_rays, images=A.IMAGES_RAYGEN5, pipeline=args.pipeline)
-        acc = {"kernels": 0.0}
+        acc, pk = {"kernels": 0.0}, {}
         for j in range(2 + args.present_frames):
             if j == 2:
                 torch.cuda.synchronize()
@@ -625,11 +625,14 @@ def main():
             if j >= 2:
                 st = pframe.stats()
                 acc["kernels"] += st.totalMs
+                for k, v in (("primary", st.primaryMs), ("shadow_gen", st.shadowGenMs), ("shadow_trace", st.shadowTraceMs), ("resolve", st.resolveMs)):
+                    pk[k] = pk.get(k, 0.0) + v / args.present_frames
             pframe.denoise_combine(4)
         pms = (time.perf_counter() - t1) * 1e3 / args.present_frames
         ray_ms = sum(acc.values()) / args.present_frames
         presented = {"ms_per_frame": round(pms, 4), "frames": args.present_frames, "spp": 4, "images": 5, "denoise_iterations": 4, "combine": True,
                      "ltc_tables": "shipped (realtimeraytracer_amd/data/ltc_tables.bin)", "ray_gen_kernels_ms": round(ray_ms, 4),
+                     "kernels_ms": {k: round(v, 4) for k, v in pk.items()},
                      "denoise_combine_and_host_ms": round(pms - ray_ms, 4), "rays_per_frame": prays,
                      "scope": "one frame at a time, wall clock around rtr_render + rtr_denoise_combine; FINAL left in HBM"}
         pframe.close(); pscene.close()

@@ -1196,13 +1196,18 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     /* camera rays: the persistent kernel (k_primary_persist), or one ray per lane (k_primary; RTR_PRIMARY_PERSIST=0, for comparison).
      * Both walk the BVH2 and leave the rays that outgrow their 16-entry LDS stack to k_primary_tail; the counting form takes the
      * same path as the timed one. */
-    static const uint32_t kPersist = env_u32("RTR_PRIMARY_PERSIST", 0u, 0u, 1u);
+    static const uint32_t kPersist = env_u32("RTR_PRIMARY_PERSIST", 0u, 0u, 2u);          /* 0 never (default), 1 whenever it can, 2 by the size of the launch */
+    static const uint32_t kPersistMinRays = env_u32("RTR_PRIMARY_PERSIST_MIN_RAYS", 6u << 20, 0u, 0xffffffffu);
     static const uint32_t kPBatch = env_u32("RTR_PRIMARY_BATCH", 64u, 64u, 1u << 16);
     static const uint32_t kPRefill = env_u32("RTR_PRIMARY_REFILL", 24u, 1u, 64u);
     static const uint32_t kPInnerMin = env_u32("RTR_PRIMARY_INNER_MIN", 20u, 0u, 63u);
     static const uint32_t kPWgsPerCu = env_u32("RTR_PRIMARY_WGS_PER_CU", 8u, 1u, 8u);
     const uint32_t planeStride = blocks * kBlock;
-    if (kPersist && nb == 1u && (unsigned long long)planeStride * ra.spp < 0xffffffffull) {
+    /* Round 2 measured the persistent kernel faster alone from 8 M camera rays (0.58 against 0.89 ms at 1080p x 4 spp); since k_primary
+     * takes one lane per (sample, pixel) it is the other way round at every size (0.77 against 0.98 ms; whole frames 3-9 % slower with
+     * RTR_PRIMARY_PERSIST=2, profiles/r03/ab_primary_persist_auto.log), so nothing selects it by default. */
+    const unsigned long long camRays = (unsigned long long)planeStride * ra.spp;
+    if ((kPersist == 1u || (kPersist == 2u && camRays >= kPersistMinRays)) && nb == 1u && camRays < 0xffffffffull) {
         uint32_t pblocks = numCus * kPWgsPerCu;
         const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
         if (pblocks > pneeded) pblocks = pneeded;
