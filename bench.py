@@ -49,11 +49,13 @@ L2_PEAK_GBS = 34500.0    # same guide: L2 aggregate, 8 XCDs
 
 
 def default_frames_in_flight(n_gpus):
-    """Frame objects in use per rank, and frames per launch of the pipeline (--batch).  A 1-spp frame — a 1/N shard of one even more
+    """Frame objects in use per rank; --batch of them go into one launch of the pipeline.  A 1-spp frame — a 1/N shard of one even more
     so — is too little work per launch for the latency-bound kernels: eight frames per launch, one launch at a time, render faster
     than any number of single-frame launches overlapped (profiles/r03/ab_frame_batch2.log: N = 1 2.12 against 2.25 ms per frame;
-    one rank of 8 0.327 against 0.392)."""
-    return 8
+    one rank of 8 0.327 against 0.392).  Eight 1/4 or 1/8 shards are still only a frame or two of work, so from N = 4 on four such
+    launches are kept in flight (profiles/r03/sweep_batches_in_flight.log: one rank of 8 0.330 -> 0.305 ms per frame, one of 4
+    0.603 -> 0.578; at N = 1, 2 it makes no difference or costs 1 %)."""
+    return 32 if n_gpus >= 4 else 8
 
 
 DEFAULT_BATCH = 8      # frames per launch (rtr_render_batch_async / rtr_mgpu_render_batch_async); --batch 1 = one launch per frame
@@ -64,7 +66,7 @@ def launch_plan(args, env, argv):
     mode: 'single' (N = 1), 'rank' (this process is one rank of a torch.distributed.run job), 'inproc' (N > 1 started plainly: one
     process drives the N devices through librtr_mgpu.so), 'torchrun-child' (N > 1 started plainly with --launcher torchrun)."""
     n = args.gpus
-    fif = args.frames_in_flight or default_frames_in_flight(n)
+    fif = args.frames_in_flight or default_frames_in_flight(max(n, getattr(args, 'emulate_rank_of', 0) or 0))
     # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 8 frames in flight every frame's stream gets its own
     env_defaults = {"GPU_MAX_HW_QUEUES": "8"} if fif >= 8 else {}
     base = {"n_gpus": n, "frames_in_flight": fif, "frames_per_launch": max(1, min(args.batch or DEFAULT_BATCH, fif)), "env_defaults": env_defaults}

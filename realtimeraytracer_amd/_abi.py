@@ -225,7 +225,7 @@ MGPU_MAX_RANKS = 16
 
 MAX_BATCH = 8
 MGPU_ID_BYTES = 128
-MGPU_MAX_SLOTS = 8
+MGPU_MAX_SLOTS = 32
 MGPU_NO_EXCHANGE = 1
 
 # every entry point include/rtr_mgpu.h declares

@@ -84,8 +84,8 @@ struct Rank {
     int rank = 0, device = 0;
     /* one render context (= one HIP stream) PER FRAME SLOT: the kernels of a frame are a dependency chain with tails, and a 1/N shard
      * cannot fill the GPU, so frames in flight on separate streams are where most of the strong scaling comes from */
-    rtr_ctx* ctx[RTR_MGPU_MAX_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t renderStream[RTR_MGPU_MAX_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    rtr_ctx* ctx[RTR_MGPU_MAX_SLOTS] = {};
+    hipStream_t renderStream[RTR_MGPU_MAX_SLOTS] = {};
     rtr_ctx* commCtx = nullptr;       /* one more context whose stream is the communication stream (RCCL ops, k_deinterleave) */
     hipStream_t commStream = nullptr;
     rtr_scene* scene = nullptr;
