@@ -279,7 +279,9 @@ int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSc
  * 0.34 ms for one 1080p frame's rays and 0.41 ms for four times as many): batching trades latency of the individual frame for
  * throughput, like frames in flight do, and composes with them.  Same pixels as n calls of rtr_render_async (tested).  The
  * launch runs on frames[0]'s context stream and its times / counters (rtr_frame_get_stats) are frames[0]'s, for the whole launch;
- * rtr_frame_wait on any of the frames joins it.  Staged pipeline only; the frames must live on one device and be distinct.
+ * rtr_frame_wait on any of the frames joins it.  The other frames may live on other contexts (streams) of the device: the launch waits
+ * for what their streams hold when it is enqueued and their streams wait for the launch, so work enqueued for a frame before and
+ * after a batch is ordered around it without a host join (tested).  Staged pipeline only; the frames must live on one device and be distinct.
  * The reference records one vkCmdTraceRaysKHR per frame (src/app/application.cppm:362-389); this is n of them in one. */
 #define RTR_MAX_BATCH 8
 int  rtr_render_batch_async(rtr_scene* scene, const RtrCameraData* cameras, const RtrSceneInfo* sceneInfos, const rtr_render_params* params,

@@ -970,6 +970,15 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
     memset(&f->stats, 0, sizeof f->stats);
     f->stats.localRows = rows; f->stats.localPixels = rows * p.width * n;
     f->viaBatch = false;
+    /* the other frames of the batch are written on THIS frame's stream: whatever their own streams still hold for them (an earlier
+     * render, a download) comes first */
+    for (uint32_t b = 1; b < n; ++b) {
+        rtr_frame* fr = frames[b];
+        if (fr->ctx->stream == st) continue;
+        if (!fr->evDone) HIP_TRY(hipEventCreateWithFlags(&fr->evDone, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(fr->evDone, fr->ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(st, fr->evDone, 0));
+    }
     hipError_t e;
     if (wave) {
         /* the list of rays left to the redo kernels: the camera rays' needs one entry per pixel-sample at most; the any-hit kernel's
@@ -1003,11 +1012,13 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
     }
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     f->pendingStats = true;
-    /* the other frames of the batch were rendered on THIS frame's stream: each gets an event behind the launch to wait on */
+    /* ... and each gets an event behind the launch: rtr_frame_wait waits on it, and the frame's own stream does, so that whatever is
+     * enqueued for the frame next (a render of its own, a download) is ordered behind this launch */
     for (uint32_t b = 1; b < n; ++b) {
         rtr_frame* fr = frames[b];
         if (!fr->evDone) HIP_TRY(hipEventCreateWithFlags(&fr->evDone, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(fr->evDone, st));
+        if (fr->ctx->stream != st) HIP_TRY(hipStreamWaitEvent(fr->ctx->stream, fr->evDone, 0));
         fr->viaBatch = true; fr->pendingStats = false;
         memset(&fr->stats, 0, sizeof fr->stats);
     }

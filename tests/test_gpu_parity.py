@@ -737,6 +737,43 @@ def test_batched_frames_equal_single_renders(gpu_ctx, oracle, scene_cache, queue
         api.render_batch(scene, [cams[0]] * 2, [infos[0]] * 2, api.make_params(W, H, spp=1, pipeline=1), many[:2])
 
 
+@pytest.mark.gpu
+def test_batch_orders_itself_against_the_frames_own_streams(gpu_ctx, scene_cache):
+    """A launch of several frames runs on the LEADING frame's stream; the other frames live on their own contexts / streams.  Work
+    enqueued for such a frame before the batch (a render of its own) and after it (another render of its own) is ordered around the
+    launch without a host join in between: every download shows the last thing enqueued for that frame."""
+    import torch
+    from realtimeraytracer_amd import host
+    W, H = 480, 270
+    s = scenes.sponza_class(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    p = api.make_params(W, H, spp=1, pipeline=2)
+    cams = [host.Camera(60.0 + 2 * b, (s.cam_pos[0], s.cam_pos[1] + 20.0 * b, s.cam_pos[2]), (300.0, 380.0, -20.0), (0.0, 1.0, 0.0), W, H).getGPUData() for b in range(4)]
+    infos = [s.scene_info(11 + b) for b in range(4)]
+    ref = api.Frame(gpu_ctx, W, H)
+    singles = []
+    for b in range(4):
+        api.render(scene, cams[b], infos[b], p, ref)
+        singles.append(ref.download())
+    ctxs, streams, frames = [], [], []
+    for _ in range(3):
+        c = api.Context(0); st = torch.cuda.Stream(); c.set_stream(st.cuda_stream)
+        ctxs.append(c); streams.append(st); frames.append(api.Frame(c, W, H))
+    for rnd in range(3):
+        # frame 1 renders view 3 on its own stream, the batch (led by frame 0) then overwrites it with view 1 ...
+        api.render(scene, cams[3], infos[3], p, frames[1], asynchronous=True)
+        api.render_batch(scene, cams[:3], infos[:3], p, frames)
+        # ... and frame 2 is re-rendered alone (view 3) on its own stream straight after the batch wrote view 2 into it
+        api.render(scene, cams[3], infos[3], p, frames[2], asynchronous=True)
+        for b in range(3):
+            frames[b].wait()
+        _assert_same(frames[0].download(), singles[0], f"round {rnd}: leading frame")
+        _assert_same(frames[1].download(), singles[1], f"round {rnd}: the batch comes after the frame's own earlier render")
+        _assert_same(frames[2].download(), singles[3], f"round {rnd}: the frame's own later render comes after the batch")
+    for o in frames + ctxs + [ref, scene]:
+        o.close()
+
+
 def _run_staged_child(code, env, timeout):
     """A child process whose script announces every library call before making it (STAGE lines, flushed): when the child hangs, the
     timeout says where it stopped instead of nothing (round 2's 240-s hang left only RCCL's banner on stdout)."""
