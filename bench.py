@@ -50,15 +50,25 @@ L2_PEAK_GBS = 34500.0    # same guide: L2 aggregate, 8 XCDs
 
 def default_frames_in_flight(n_gpus):
     """Frame objects in use per rank; --batch of them go into one launch of the pipeline.  A 1-spp frame — a 1/N shard of one even more
-    so — is too little work per launch for the latency-bound kernels: eight frames per launch, one launch at a time, render faster
-    than any number of single-frame launches overlapped (profiles/r03/ab_frame_batch2.log: N = 1 2.12 against 2.25 ms per frame;
-    one rank of 8 0.327 against 0.392).  Eight 1/4 or 1/8 shards are still only a frame or two of work, so from N = 4 on four such
-    launches are kept in flight (profiles/r03/sweep_batches_in_flight.log: one rank of 8 0.330 -> 0.305 ms per frame, one of 4
-    0.603 -> 0.578; at N = 1, 2 it makes no difference or costs 1 %)."""
-    return 32 if n_gpus >= 4 else 8
+    so — is too little work per launch for the latency-bound kernels: sixteen frames per launch, one launch at a time, render faster
+    than any number of single-frame launches overlapped (profiles/r03/ab_frame_batch2.log, sweep_frames_per_launch.log: N = 1 2.25 ms
+    per frame with four single-frame launches in flight, 2.13 with eight frames per launch, 2.10 with sixteen).  Sixteen 1/4 or 1/8
+    shards are still only a few frames of work, so from N = 4 on two such launches are kept in flight (one rank of 8: 0.298 -> 0.280 ms
+    per frame, one of 4: 0.557 with two)."""
+    return 32 if n_gpus >= 4 else 16
 
 
-DEFAULT_BATCH = 8      # frames per launch (rtr_render_batch_async / rtr_mgpu_render_batch_async); --batch 1 = one launch per frame
+DEFAULT_BATCH = 16     # frames per launch (rtr_render_batch_async / rtr_mgpu_render_batch_async, at most RTR_MAX_BATCH); --batch 1 = one launch per frame
+
+
+def launch_sizes(count, batch):
+    """`count` frames in as few launches of at most `batch` frames as possible, of equal size (+-1): 20 frames at 16 per launch are
+    10 + 10, not 16 + 4 — a short launch is a slow one, and equal launches are what the per-launch figures of the line describe."""
+    if count <= 0:
+        return []
+    nl = -(-count // max(batch, 1))
+    base, extra = divmod(count, nl)
+    return [base + 1] * extra + [base] * (nl - extra)
 
 
 def launch_plan(args, env, argv):
@@ -184,8 +194,7 @@ def run_inproc(args, K, plan):
                 step(i)
             return
         i = first
-        while i < first + count:
-            c = min(B, first + count - i)
+        for c in launch_sizes(count, B):
             g0 = (launch_no[0] % groups) * B            # fixed groups of slots: the slot that leads a launch owns its scratch
             launch_no[0] += 1
             bufs = [g0 + j for j in range(c)]
@@ -208,9 +217,10 @@ def run_inproc(args, K, plan):
     for b in range(nbuf):                               # set-up, not warm-up: every slot allocates on its first render
         step(b)
     drain()
-    if B > 1:                                           # ... and the leading slots' scratch grows to the batch on the first batched one
+    if B > 1:                                           # ... and the leading slots' scratch grows to the launch on the first batched one
+        biggest = max(launch_sizes(args.steps, B) + launch_sizes(args.warmup, B) + [1])
         for _ in range(groups):
-            run_steps(0, B)
+            run_steps(0, biggest)
         drain()
     run_steps(0, args.warmup)
     drain()
@@ -241,7 +251,7 @@ def run_inproc(args, K, plan):
                    "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries), "build_ms": round(float(sstats.buildMs), 1)}},
         "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
         "frames_in_flight": nbuf,
-        "frames_per_launch": B,
+        "frames_per_launch": B, "timed_launches": launch_sizes(args.steps, B),
         "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
         "kernels_scope": "rank 0's shard, per frame (a launch covers frames_per_launch frames); HIP-event brackets",
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
@@ -261,8 +271,8 @@ def run_inproc(args, K, plan):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="sponza_class", choices=["sponza_class", "cornell", "bunny_class"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -525,8 +535,7 @@ def main():
                 step(i)
             return
         i = first
-        while i < first + count:
-            c = min(B, first + count - i)
+        for c in launch_sizes(count, B):
             step_batch(i, c)
             i += c
 
@@ -569,9 +578,10 @@ def main():
         if use_lib:
             step(b)                                     # the library's slots allocate on their first render too
     drain()
-    if B > 1:                                           # the leading frames' scratch grows to the batch on its first batched render
+    if B > 1:                                           # the leading frames' scratch grows to the launch on its first batched render
+        biggest = max(launch_sizes(args.steps, B) + launch_sizes(args.warmup, B) + [1])
         for _ in range(groups):
-            run_steps(0, B)
+            run_steps(0, biggest)
         drain()
     run_steps(0, args.warmup)
     drain()
@@ -650,9 +660,10 @@ def main():
         # the HIP-event brackets of the TIMED REGION are the kernels' own durations, and the roofline is that of the launches the
         # headline number is made of (B frames' rays each).  Otherwise launches of different frames overlap and the kernel's own
         # duration comes from the one-frame-at-a-time pass after the timed region.
-        own_launch = B > 1 and nbuf == B and not dist_on
-        launch_frames = B if own_launch else 1
-        trace_ms = bracket_ms * B if own_launch else (kern_iso["shadow_trace"] if kern_iso else bracket_ms)
+        timed_sizes = set(launch_sizes(args.steps, B))
+        own_launch = B > 1 and nbuf == B and not dist_on and len(timed_sizes) == 1          # equal launches, one at a time
+        launch_frames = timed_sizes.pop() if own_launch else 1
+        trace_ms = bracket_ms * launch_frames if own_launch else (kern_iso["shadow_trace"] if kern_iso else bracket_ms)
         trace_bytes = fs.shadowTraceBytes * launch_frames         # rank 0's launch
         roofline, roofline2, frame_hbm = None, None, None
         if pipeline_used == 2 and trace_ms > 0:
@@ -731,7 +742,7 @@ def main():
             if pmc and pmc.get("kernels", {}).get("k_shadow_gen_oct") and (kern_iso or own_launch):
                 # the one kernel of the frame that IS bound by HBM: it writes the ray queue (20 B per ray + 16 B per pixel-sample) as fast as the memory takes it
                 g = pmc["kernels"]["k_shadow_gen_oct"]
-                gen_ms = (kern["shadow_gen"] / n) * B if own_launch else kern_iso["shadow_gen"]
+                gen_ms = (kern["shadow_gen"] / n) * launch_frames if own_launch else kern_iso["shadow_gen"]
                 gbytes = g["read_bytes"] + g["write_bytes"]
                 roofline2 = {"bound": "hbm", "kernel": "k_shadow_gen_oct: shadow-ray generation into the queue binned by direction octant",
                              "achieved": round(gbytes / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -767,7 +778,7 @@ def main():
                                "build_ms": round(float(sstats.buildMs), 1)}},
             "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
             "frames_in_flight": nbuf,
-            "frames_per_launch": B,
+            "frames_per_launch": B, "timed_launches": launch_sizes(args.steps, B),
             "kernels_ms": {k: round(v, 4) for k, v in kern_iso.items()} if kern_iso else {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
             "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"} if kern_iso else None,
             "one_frame_at_a_time": {"ms_per_step": round(iso_ms_per_frame, 4), "mrays_per_s": round(fs.numRays * K / iso_ms_per_frame / 1e3, 2),

@@ -283,7 +283,7 @@ int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSc
  * for what their streams hold when it is enqueued and their streams wait for the launch, so work enqueued for a frame before and
  * after a batch is ordered around it without a host join (tested).  Staged pipeline only; the frames must live on one device and be distinct.
  * The reference records one vkCmdTraceRaysKHR per frame (src/app/application.cppm:362-389); this is n of them in one. */
-#define RTR_MAX_BATCH 8
+#define RTR_MAX_BATCH 16
 int  rtr_render_batch_async(rtr_scene* scene, const RtrCameraData* cameras, const RtrSceneInfo* sceneInfos, const rtr_render_params* params,
                             rtr_frame* const* frames, uint32_t n);
 int  rtr_frame_wait(rtr_frame* frame);

@@ -77,5 +77,12 @@ out = {
         },
     },
 }
-json.dump(out, sys.stdout, indent=1)
-print()
+into = __import__("os").environ.get("PMC_INTO")            # merge the key into an existing file instead of printing a new one
+if into:
+    have = json.load(open(into))
+    have[key] = out[key]
+    json.dump(have, open(into, "w"), indent=1)
+    print(f"{into}: {key} written")
+else:
+    json.dump(out, sys.stdout, indent=1)
+    print()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Counter passes behind bench.py's roofline block (round 3):  bash profiles/pmc_r03.sh <tag> [extra bench args]
-# The default bench command: 8 frames per launch, one launch at a time, so a kernel's counters are its own; separate --pmc passes with --kernel-trace only.
+# The driver's bench command (--steps 20 --warmup 5: two launches of 10 frames, one launch at a time, so a kernel's counters are its own;
+# STEPS=32 WARMUP=16 for launches of 16); separate --pmc passes with --kernel-trace only.
 # Writes gpurun_out/prof_<tag>/summary.txt and pmc.json (copy both into profiles/r03/).
 set -o pipefail
 TAG=${1:-r03}; shift || true
@@ -8,8 +9,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# the default command (8 frames per launch of every kernel, one launch at a time): kernels never overlap, a kernel's counters are its own
-BENCH="python3 $REPO/bench.py --steps 24 --warmup 8 --no-cpu-baseline --isolated-frames 0 --present-frames 0 $@"
+# equal launches of every kernel, one at a time: kernels never overlap, a kernel's counters are its own
+BENCH="python3 $REPO/bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --isolated-frames 0 --present-frames 0 $@"
 # every pass keeps its own stdout (the bench line) and stderr (rocprofv3's log): a pass that is refused or aborts leaves its reason behind
 pass() { name=$1; shift; timeout -k 10 170 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/bench_$name.log" 2> "$OUT/rocprof_$name.log" || { echo "$name failed"; tail -3 "$OUT/rocprof_$name.log"; }; }
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.log" 2> "$OUT/rocprof_stats.log" || echo "stats failed"
@@ -38,10 +39,10 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         if "rtrdev" not in k: continue
         short = k.split("(")[0].replace("void ", "")
         # a run launches every kernel over ONE frame too (each frame object's first render, the counting pass): the means are over
-        # the launches of the timed kind only — those within a factor of two of the largest value (every counter grows with the work)
+        # the launches of the timed kind only — those within 20 % of the largest value (every counter grows with the work)
         def big(v):
             m = max(v)
-            return [x for x in v if x >= 0.5 * m] if m > 0 else v
+            return [x for x in v if x >= 0.8 * m] if m > 0 else v
         e = {c: sum(big(v)) / len(big(v)) for c, v in agg[k].items()}
         if dur[k]: e["avg_ms"] = sum(big(dur[k])) / len(big(dur[k])); e["calls"] = len(big(dur[k]))
         res[short] = e

@@ -223,7 +223,7 @@ MGPU_PLAN_MAX_OPS = 32
 MGPU_MAX_RANKS = 16
 
 
-MAX_BATCH = 8
+MAX_BATCH = 16
 MGPU_ID_BYTES = 128
 MGPU_MAX_SLOTS = 32
 MGPU_NO_EXCHANGE = 1

@@ -159,6 +159,13 @@ struct rtr_frame {
     uint32_t pendingImagesK = 0; bool pendingHdr = false, pendingAccum = false;
     hipEvent_t evDone = nullptr;         /* a frame rendered as a later frame of a batch: recorded on the leading frame's stream behind the launch */
     bool viaBatch = false;
+    /* ordering between a batch launch (on the leading frame's stream) and the other frames' own streams, paid only when it is needed:
+     * batchStream = the stream of the launch that last wrote this frame as a later frame of a batch and has not been joined (evDone
+     * marks its end); ownPending = the frame's own stream may still hold work for it (a launch it led); evOwn orders a later batch
+     * behind that work */
+    hipStream_t batchStream = nullptr;
+    bool ownPending = false;
+    hipEvent_t evOwn = nullptr;
     uint32_t* image_ptr(int which) const { return ext[which] ? ext[which] : img[which].p; }
 };
 
@@ -835,6 +842,7 @@ void rtr_frame_destroy(rtr_frame* f) {
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : f->evMega) if (e) (void)hipEventDestroy(e);
     if (f->evDone) { (void)hipEventSynchronize(f->evDone); (void)hipEventDestroy(f->evDone); }
+    if (f->evOwn) (void)hipEventDestroy(f->evOwn);
     rtr_ctx* c = f->ctx;
     delete f;
     ctx_release_child(c);
@@ -886,6 +894,7 @@ int rtr_frame_clear(rtr_frame* f) {
 /* ---- dispatch ------------------------------------------------------------------------------ */
 /* Enqueues one launch of the pipeline over n frames (n = 1: rtr_render / rtr_render_async).  frames[0] leads: its context's stream
  * carries the work, its scratch holds the batch, its statistics describe the launch. */
+static_assert(RTR_MAX_BATCH == rtrdev::kMaxBatch, "include/rtr.h and kernels/rtr_device.h disagree on the frames per launch");
 static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrSceneInfo* infos, const rtr_render_params* pin, rtr_frame* const* frames, uint32_t n) {
     if (!s || !cams || !infos || !pin || !frames || n < 1 || !frames[0]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: null argument");
     if (n > rtrdev::kMaxBatch) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: %u frames, at most %u per launch", n, rtrdev::kMaxBatch);
@@ -970,14 +979,20 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
     memset(&f->stats, 0, sizeof f->stats);
     f->stats.localRows = rows; f->stats.localPixels = rows * p.width * n;
     f->viaBatch = false;
-    /* the other frames of the batch are written on THIS frame's stream: whatever their own streams still hold for them (an earlier
-     * render, a download) comes first */
+    /* The launch runs on THIS frame's stream.  What another stream still holds for one of its frames comes first: a launch the frame
+     * led on its own stream (ownPending), or a batch on a third stream that wrote it (batchStream).  In steady state — the same
+     * frames batched behind the same leader, or frames joined between uses — neither is set and nothing is enqueued here (cross-stream
+     * waits on every launch cost 3 % of the frame rate at N = 1 and 25 % on a 1/8 shard: profiles/r03/ab_batch_stream_order.log). */
+    if (f->batchStream && f->batchStream != st) HIP_TRY(hipStreamWaitEvent(st, f->evDone, 0));
+    f->batchStream = nullptr;
     for (uint32_t b = 1; b < n; ++b) {
         rtr_frame* fr = frames[b];
-        if (fr->ctx->stream == st) continue;
-        if (!fr->evDone) HIP_TRY(hipEventCreateWithFlags(&fr->evDone, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(fr->evDone, fr->ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(st, fr->evDone, 0));
+        if (fr->ownPending && fr->ctx->stream != st) {
+            if (!fr->evOwn) HIP_TRY(hipEventCreateWithFlags(&fr->evOwn, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(fr->evOwn, fr->ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(st, fr->evOwn, 0));
+        }
+        if (fr->batchStream && fr->batchStream != st) HIP_TRY(hipStreamWaitEvent(st, fr->evDone, 0));
     }
     hipError_t e;
     if (wave) {
@@ -1012,13 +1027,14 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
     }
     if (e != hipSuccess) return fail(RTR_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     f->pendingStats = true;
-    /* ... and each gets an event behind the launch: rtr_frame_wait waits on it, and the frame's own stream does, so that whatever is
-     * enqueued for the frame next (a render of its own, a download) is ordered behind this launch */
+    f->ownPending = true;
+    /* ... and each of the other frames gets an event behind the launch: rtr_frame_wait / rtr_frame_download wait on it, and so does
+     * the stream of whatever launch writes the frame next (above) */
     for (uint32_t b = 1; b < n; ++b) {
         rtr_frame* fr = frames[b];
         if (!fr->evDone) HIP_TRY(hipEventCreateWithFlags(&fr->evDone, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(fr->evDone, st));
-        if (fr->ctx->stream != st) HIP_TRY(hipStreamWaitEvent(fr->ctx->stream, fr->evDone, 0));
+        fr->batchStream = st;
         fr->viaBatch = true; fr->pendingStats = false;
         memset(&fr->stats, 0, sizeof fr->stats);
     }
@@ -1029,7 +1045,8 @@ int rtr_frame_wait(rtr_frame* f) {
     if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_wait: null frame");
     HIP_TRY(hipSetDevice(f->ctx->device));
     HIP_TRY(hipStreamSynchronize(f->ctx->stream));
-    if (f->viaBatch) { HIP_TRY(hipEventSynchronize(f->evDone)); return RTR_OK; }      /* rendered in another frame's launch: that launch's times and counters are the leading frame's */
+    f->ownPending = false;
+    if (f->viaBatch) { HIP_TRY(hipEventSynchronize(f->evDone)); f->batchStream = nullptr; return RTR_OK; }      /* rendered in another frame's launch: that launch's times and counters are the leading frame's */
     if (!f->pendingStats) return RTR_OK;
     f->pendingStats = false;
     rtr_frame_stats& s = f->stats;

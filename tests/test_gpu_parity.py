@@ -687,7 +687,7 @@ def test_visibility_prefill_polarity_does_not_change_a_pixel(gpu_ctx, oracle, sc
         os.environ.pop("RTR_TRACE_VIS_FILL", None)
 
 
-@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("n", [2, 3, 4, 16])
 def test_batched_frames_equal_single_renders(gpu_ctx, oracle, scene_cache, queue_mode, n):
     """rtr_render_batch_async: n frames (own camera, own seed, own images) in ONE launch of every kernel give the pixels n launches
     give — and the oracle's — sharded and unsharded; the counting form's counters are the sum of the single frames'; a frame that
