@@ -738,6 +738,43 @@ def test_batched_frames_equal_single_renders(gpu_ctx, oracle, scene_cache, queue
 
 
 @pytest.mark.gpu
+def test_batched_launch_ragged_extent_and_hdr_accumulation(gpu_ctx, oracle, scene_cache):
+    """A full launch (RTR_MAX_BATCH frames) of a frame whose extent is no multiple of the 8x8 tile or the workgroup, at 3 spp, every
+    frame accumulating into its OWN HDR image over two launches: bit-identical (HDR floats and tonemapped bytes) to the same frames
+    rendered one per launch, and to the oracle for the first and the last frame of the batch."""
+    W, H, N = 37, 19, A.MAX_BATCH
+    s = scenes.cornell_box(W, H)
+    imgs = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_HDR)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    batch = [api.Frame(gpu_ctx, W, H, imgs) for _ in range(N)]
+    single = api.Frame(gpu_ctx, W, H, imgs)
+    info = lambda b, f: s.scene_info(100 * f + 7 * b)
+    for f in range(2):                                             # two accumulation steps
+        p = api.make_params(W, H, spp=3, images=imgs, accumulate=1, accumulated_frames=f, pipeline=2)
+        api.render_batch(scene, [s.camera] * N, [info(b, f) for b in range(N)], p, batch)
+    batch[3].wait()
+    for b in (0, 5, N - 1):
+        single.clear()
+        hdr = np.zeros((H, W, 4), np.float32)
+        ref = None
+        for f in range(2):
+            p = api.make_params(W, H, spp=3, images=imgs, accumulate=1, accumulated_frames=f, pipeline=2)
+            api.render(scene, s.camera, info(b, f), p, single)
+            if b != 5:
+                ref = oracle.render(s.desc, s.camera, info(b, f), p, bvh=bvh, images=imgs, hdr=hdr, threads=8)
+        g = batch[b].download(A.IMAGE_HDR)
+        assert np.all(g[..., 3] == 2)
+        assert np.array_equal(g.view(np.uint32), single.download(A.IMAGE_HDR).view(np.uint32)), f"frame {b}: HDR of the batch vs one per launch"
+        _assert_same(batch[b].download(), single.download(), f"frame {b}: batch vs one per launch")
+        if ref is not None:
+            assert np.array_equal(g.view(np.uint32), hdr.view(np.uint32)), f"frame {b}: accumulated HDR vs oracle"
+            _assert_same(batch[b].download(), ref.images[A.IMAGE_SHADOWED], f"frame {b}: tonemapped accumulation vs oracle")
+    for o in batch + [single, scene]:
+        o.close()
+
+
+@pytest.mark.gpu
 def test_batch_orders_itself_against_the_frames_own_streams(gpu_ctx, scene_cache):
     """A launch of several frames runs on the LEADING frame's stream; the other frames live on their own contexts / streams.  Work
     enqueued for such a frame before the batch (a render of its own) and after it (another render of its own) is ordered around the
@@ -869,6 +906,62 @@ def test_mgpu_library_single_process_through_rccl(gpu_ctx, oracle, scene_cache):
     env = dict(os.environ, RTR_MGPU_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_MGPU_TIMEOUT_MS="60000")
     r = _run_staged_child(code, env, 240)
     assert r.returncode == 0 and "MGPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_mgpu_library_full_batches_overlapping_slot_groups():
+    """librtr_mgpu.so with 32 frame slots: two full launches (RTR_MAX_BATCH slots each) in flight, then a third whose slots are taken
+    from BOTH — another slot leads it on another stream, some of its frames were written last by the first launch's stream, others
+    led or followed the second — without a host join in between; every assembled frame equals the frame rendered unsharded.  (What
+    orders the launches is the events of rtr_render_batch_async and the slots' exchange events, not the caller.)"""
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, os.getcwd())
+        def stage(s): print("STAGE", s, flush=True)
+        stage("imports")
+        import numpy as np, torch
+        from realtimeraytracer_amd import _abi as A, api, mgpu, scenes
+        n = torch.cuda.device_count()
+        B = A.MAX_BATCH
+        W, H = 320, 184
+        s = scenes.cornell_box(W, H)
+        stage("rtr_mgpu_create")
+        m = mgpu.MultiGpu(devices=list(range(n)), frames_in_flight=2 * B)
+        stage("rtr_mgpu_scene_create")
+        m.scene_create(s.desc)
+        p = api.make_params(W, H, spp=1)
+        want = {}
+        def launch(slots, first):
+            m.render_batch_async(slots, [s.camera] * len(slots), [s.scene_info(first + j) for j in range(len(slots))], p)
+            for j, sl in enumerate(slots):
+                want[sl] = first + j
+        for rnd in range(2):
+            stage(f"round {rnd}: launch over slots 0..{B - 1}")
+            launch(list(range(B)), 1000 * rnd)
+            stage(f"round {rnd}: launch over slots {B}..{2 * B - 1}")
+            launch(list(range(B, 2 * B)), 1000 * rnd + 100)
+            stage(f"round {rnd}: launch over slots {B // 2}..{B // 2 + B - 1} (both groups)")
+            launch(list(range(B // 2, B // 2 + B)), 1000 * rnd + 200)
+        stage("rtr_mgpu_wait, every slot")
+        for sl in range(2 * B):
+            m.wait(sl)
+        got = {sl: m.download(sl) for sl in range(2 * B)}
+        stage("reference renders")
+        ctx = api.Context(0)
+        scene = api.Scene(ctx, s.desc)
+        frame = api.Frame(ctx, W, H)
+        for sl, f in sorted(want.items()):
+            api.render(scene, s.camera, s.scene_info(f), p, frame)
+            bad = int((got[sl] != frame.download()).sum())
+            assert bad == 0, ("slot", sl, "frame", f, "pixels differing", bad)
+        stage("rtr_mgpu_destroy")
+        m.close()
+        print("MGPU_BATCHES_OK", n, len(want))
+    """)
+    env = dict(os.environ, RTR_MGPU_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_MGPU_TIMEOUT_MS="60000")
+    r = _run_staged_child(code, env, 240)
+    assert r.returncode == 0 and "MGPU_BATCHES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_scene_create_like_uploads_the_tree_without_building_it(gpu_ctx, scene_cache):
