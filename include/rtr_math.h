@@ -296,11 +296,17 @@ RTR_HD void rtr_ray_grid(rtr_v3 o, rtr_v3 idir, const float* origin, const float
 }
 /* The same constants with the plane coordinate counted from the scene's wide centre c (RtrBvhGrid::wideCentreXY / Z, grid steps): what
  * the half-float planes of the 4-wide records (RtrWideNode) are offsets from.  ga is unchanged; gbc = (origin + c scale - o) * idir. */
+/* the wide centre in world units: the part of rtr_ray_grid_centre that does not depend on the ray (the any-hit kernel computes it once per workgroup) */
+RTR_HD rtr_v3 rtr_wide_centre_world(const float* origin, const float* scale, uint32_t centreXY, uint32_t centreZ) {
+    return rtr_mk(rtr_fma((float)(centreXY & 0xffffu), scale[0], origin[0]), rtr_fma((float)(centreXY >> 16), scale[1], origin[1]),
+                  rtr_fma((float)(centreZ & 0xffffu), scale[2], origin[2]));
+}
+RTR_HD void rtr_ray_grid_about(rtr_v3 o, rtr_v3 idir, rtr_v3 scale, rtr_v3 centreWorld, rtr_v3* ga, rtr_v3* gbc) {
+    ga->x = scale.x * idir.x; ga->y = scale.y * idir.y; ga->z = scale.z * idir.z;
+    gbc->x = (centreWorld.x - o.x) * idir.x; gbc->y = (centreWorld.y - o.y) * idir.y; gbc->z = (centreWorld.z - o.z) * idir.z;
+}
 RTR_HD void rtr_ray_grid_centre(rtr_v3 o, rtr_v3 idir, const float* origin, const float* scale, uint32_t centreXY, uint32_t centreZ, rtr_v3* ga, rtr_v3* gbc) {
-    ga->x = scale[0] * idir.x; ga->y = scale[1] * idir.y; ga->z = scale[2] * idir.z;
-    gbc->x = (rtr_fma((float)(centreXY & 0xffffu), scale[0], origin[0]) - o.x) * idir.x;
-    gbc->y = (rtr_fma((float)(centreXY >> 16), scale[1], origin[1]) - o.y) * idir.y;
-    gbc->z = (rtr_fma((float)(centreZ & 0xffffu), scale[2], origin[2]) - o.z) * idir.z;
+    rtr_ray_grid_about(o, idir, rtr_mk(scale[0], scale[1], scale[2]), rtr_wide_centre_world(origin, scale, centreXY, centreZ), ga, gbc);
 }
 /* Slab test of one child box given its six grid coordinates (already widened to 32 bits). */
 RTR_HD int rtr_slab_q(uint32_t qminx, uint32_t qminy, uint32_t qminz, uint32_t qmaxx, uint32_t qmaxy, uint32_t qmaxz,

@@ -430,6 +430,9 @@ __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc,
  *     finished), then all leaves are intersected together;
  * A lane's own sequence of node visits / triangle tests is exactly that of trace<true>() — and of the
  * oracle's trace_bvh() — so visibility bits AND work counters are unchanged. */
+#ifndef RTR_REFILL_LDS
+#define RTR_REFILL_LDS 1
+#endif
 constexpr int kTailBlocks = 64;            /* grid of the two "redo" kernels; their global stacks are strided by 64 * kBlock lanes */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
 constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
@@ -713,6 +716,23 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                                                               unsigned long long* __restrict__ clk) {
     __shared__ int32_t s_stack[(STACK + 1) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
+#if RTR_REFILL_LDS
+    /* What only the refill block needs — the queue's three arrays, the visibility array, the grid — waits in LDS, not in scalar registers:
+     * the kernel holds more wave-uniform values than a wave has SGPRs for, and the ones the compiler parked in VGPR lanes came back
+     * through ~20 v_readlane per refill pass (vector-issue slots, the unit this kernel is bound by); four ds_read_b128 are not. */
+    struct RefillConsts { uint64_t dt, slot, origin, vis; float cx, cy, cz, sx; float sy, sz; uint32_t slotMask, visFill; };     /* addresses as integers: a pointer read back from LDS is a generic one (flat_load) */
+    static_assert(sizeof(RefillConsts) == 64, "four 16-B LDS reads");
+    typedef const __attribute__((address_space(1))) rtr_f4* global_f4;
+    typedef const __attribute__((address_space(1))) uint32_t* global_u32;
+    typedef __attribute__((address_space(1))) uint8_t* global_u8;
+    __shared__ RefillConsts s_rc;
+    if (threadIdx.x == 0) {
+        const rtr_v3 cw = rtr_wide_centre_world(sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ);
+        s_rc.dt = (uint64_t)queue.dt; s_rc.slot = (uint64_t)queue.slot; s_rc.origin = (uint64_t)queue.origin; s_rc.vis = (uint64_t)vis;
+        s_rc.cx = cw.x; s_rc.cy = cw.y; s_rc.cz = cw.z; s_rc.sx = sc.grid->scale[0]; s_rc.sy = sc.grid->scale[1]; s_rc.sz = sc.grid->scale[2];
+        s_rc.slotMask = queue.slotMask; s_rc.visFill = visFill;
+    }
+#endif
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
     for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kTraceBlock) s_top[i] = sc.nodes4[i];
@@ -764,9 +784,18 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (nIdle >= kRefill || nIdle == 64u) {
             if (STATS) ws.refills++;
+#if RTR_REFILL_LDS
+            __asm__ volatile("" ::: "memory");                 /* the constants are read HERE, every pass: hoisted out of the loop they would cost 16 VGPRs for the whole kernel */
+            const RefillConsts rc = s_rc;
+            const global_u8 visOut = (global_u8)rc.vis;
+            const uint32_t fill = rc.visFill;
+#else
+            uint8_t* const visOut = vis;
+            const uint32_t fill = visFill;
+#endif
             if (cur == kDone && res != kResNone) {
                 if (res == 2u) { const uint32_t at = atomicAdd(overflow, 1u); if (at < overflowCap) overflow[1u + at] = rayIndex; }      /* finished by k_shadow_tail (a full list: it redoes the whole queue) */
-                else { if (res != visFill) vis[slot] = (uint8_t)res; occ += res; }      /* the array was pre-filled with the commoner outcome: only the other one is stored */
+                else { if (res != fill) visOut[slot] = (uint8_t)res; occ += res; }      /* the array was pre-filled with the commoner outcome: only the other one is stored */
                 res = kResNone;
             }
             if (!exhausted) {
@@ -807,13 +836,30 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (cur == kDone && prefix < avail) {
                         rayIndex = batchPos + prefix;
+#if RTR_REFILL_LDS
+                        {   /* queue_load() through the addresses kept in LDS */
+                            const global_f4 qdt = (global_f4)rc.dt, qorg = (global_f4)rc.origin;
+                            const global_u32 qslot = (global_u32)rc.slot;
+                            rtr_f4 a;
+                            if (octForms & 2u) { a = __builtin_nontemporal_load(qdt + rayIndex); slot = __builtin_nontemporal_load(qslot + rayIndex); }
+                            else { a = qdt[rayIndex]; slot = qslot[rayIndex]; }
+                            const rtr_f4 og = qorg[slot & rc.slotMask];
+                            o = rtr_mk(og.x, og.y, og.z); d = rtr_mk(a.x, a.y, a.z); tmax = a.w;
+                        }
+#else
                         queue_load(queue, rayIndex, o, d, tmax, slot, octForms & 2u);
+#endif
                         if (STATS) { st.rays++; st.shadow++; }
                         if (!(tmax > tmin)) {
-                            if (visFill != 0u) vis[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
+                            if (fill != 0u) visOut[slot] = 0;                 /* empty interval: nothing can be hit (oracle trace(): same rule) */
                         } else {
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
-                            rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);      /* gb about the scene's wide centre: the records' planes are offsets from it */
+                            /* gb about the scene's wide centre: the records' planes are offsets from it */
+#if RTR_REFILL_LDS
+                            rtr_ray_grid_about(o, idir, rtr_mk(rc.sx, rc.sy, rc.sz), rtr_mk(rc.cx, rc.cy, rc.cz), &ga, &gb);
+#else
+                            rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);
+#endif
                             cur = 0; sp = lds; res = 0u;
                         }
                     }
