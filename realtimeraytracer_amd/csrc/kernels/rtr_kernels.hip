@@ -460,7 +460,10 @@ constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
  * (1.86 -> 1.80 ms), but a big workgroup frees its LDS only when its last wave retires, which is when the other frames' kernels
  * can start: with four frames in flight 11.57 G rays/s became 11.1 (512 lanes) and 10.3 (1024) — profiles/r02/trace_block_size.log. */
 constexpr int kTraceBlock = RTR_TRACE_BLOCK;
-constexpr uint32_t kTopNodes = 40u * (RTR_TRACE_BLOCK / 256);
+#ifndef RTR_TRACE_TOP
+#define RTR_TRACE_TOP 40
+#endif
+constexpr uint32_t kTopNodes = (uint32_t)RTR_TRACE_TOP * (RTR_TRACE_BLOCK / 256);
 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const RayQueue queue,
