@@ -333,7 +333,10 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, FrameB
 constexpr size_t kBinnedMinRays = (size_t)10 << 20;  /* by default the binned queue is used from this queue capacity ... */
 constexpr uint32_t kBinnedMinNodes = 1u << 16;       /* ... and this tree size: binning pays where traversal dominates (Cornell at 1080p, 14.6 M
                                                       * cheap rays: 18.8 Grays/s plain, 14.7 binned; the 41 k-node sphere scene: -1 %) */
-constexpr uint32_t kGenOctBlock = 512;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
+#ifndef RTR_GEN_OCT_BLOCK
+#define RTR_GEN_OCT_BLOCK 512
+#endif
+constexpr uint32_t kGenOctBlock = RTR_GEN_OCT_BLOCK;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
 /* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
  * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
 __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom,
