@@ -438,7 +438,11 @@ __global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc,
 #endif
 constexpr int kTailBlocks = 64;            /* grid of the two "redo" kernels; their global stacks are strided by 64 * kBlock lanes */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
-constexpr uint32_t kBatchDefault = 256;    /* queue entries a wave reserves per atomic */
+/* queue entries a wave reserves per atomic: 256 for a queue of one frame's length, 512 for the queue of a launch of several frames
+ * (kBatchLongQueue: 0.6-1.5 % faster there — fewer cursor atomics, fewer short batches — while a single frame rendered alone ends in
+ * a longer tail with it, 2.65 instead of 2.53 ms; profiles/r03/sweep_batch_r03_4.log, bench_*_r03_5.log) */
+constexpr uint32_t kBatchDefault = 256, kBatchLong = 512;
+constexpr size_t kBatchLongQueue = (size_t)100 << 20;
 constexpr uint32_t kRefillDefault = 20;    /* idle lanes that trigger a refill (re-swept for the 4-wide kernel: profiles/r01/sweep_trace_wide.log) */
 
 /* Stack policy of the persistent kernels.  Ordered traversal rarely holds more than ~10 entries, so every lane gets 16 LDS
@@ -1272,7 +1276,8 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
-    static const uint32_t kBatch = env_u32("RTR_TRACE_BATCH", kBatchDefault, 64u, 1u << 20);
+    static const uint32_t kBatchEnv = env_u32("RTR_TRACE_BATCH", 0u, 0u, 1u << 20);        /* 0 (default): by the length of the queue */
+    const uint32_t kBatch = kBatchEnv >= 64u ? kBatchEnv : ((size_t)nb * blocks * kBlock * ra.spp * ra.maxRaysPerSample >= kBatchLongQueue ? kBatchLong : kBatchDefault);
     static const uint32_t kWide = two_wide_selected() ? 0u : 1u;   /* RTR_TRACE_BVH4=0: the 2-wide any-hit kernel on the plain queue (same results, for comparison; it has no counting form: rtr_render refuses collectStats with it) */
     const uint32_t genBlocks = (nb * blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (nb * blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
     /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
