@@ -628,6 +628,44 @@ print("persistent ok")
     assert r.returncode == 0 and "persistent ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("batch", ["64", "512", "4096"])
+def test_any_hit_batch_length_does_not_change_the_frame(scene_cache, batch):
+    """RTR_TRACE_BATCH (rays a wave reserves per cursor atomic; by default 256, or 512 on the queue of a launch of several frames):
+    which wave traces which rays changes, no ray's walk does — the frames of a four-frame launch equal the oracle's and the counting
+    form's work counters equal the oracle's sum, in both queue modes.  In a child process: the knob is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import numpy as np
+from realtimeraytracer_amd import _abi as A, api, scenes
+from oracle import oracle_py as O
+W, H, N = 320, 184, 4
+s = scenes.bunny_class(W, H)
+ctx = api.Context(0); scene = api.Scene(ctx, s.desc); bvh = scene.export_bvh()
+frames = [api.Frame(ctx, W, H) for _ in range(N)]
+for collect in (0, 1):
+    p = api.make_params(W, H, spp=2, collect_stats=collect, pipeline=2)
+    api.render_batch(scene, [s.camera] * N, [s.scene_info(3 + b) for b in range(N)], p, frames)
+    frames[0].wait()
+    tot = {}
+    for b in range(N):
+        ref = O.render(s.desc, s.camera, s.scene_info(3 + b), p, bvh=bvh, threads=8)
+        assert np.array_equal(frames[b].download(), ref.images[A.IMAGE_SHADOWED]), (collect, b)
+        for f in ("numRays", "numShadowRays", "numShadowNodeVisits", "numShadowTriTests", "numNodeVisits", "numTriTests"):
+            tot[f] = tot.get(f, 0) + getattr(ref.stats, f)
+    if collect:
+        g = frames[0].stats()
+        for f, v in tot.items():
+            assert getattr(g, f) == v, (f, getattr(g, f), v)
+print("batch ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTR_TRACE_BATCH=batch, PYTHONPATH=root, RTR_SCENE_CACHE=str(scene_cache))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "batch ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_d6_occluded_sample_with_overflowing_contribution(gpu_ctx, oracle, scene_cache):
     """Divergence D6.  The reference evaluates the BRDF of every light sample and multiplies by currShadow
     (raygen.rgen:244-270); the oracle does the same.  The product, when only the shadowed image is kept, does not evaluate the BRDF
