@@ -78,7 +78,9 @@ typedef struct rtr_mgpu_info {
     int nlocal;          /* ranks driven by this process */
     int firstRank;       /* rank of local rank 0 */
     int framesInFlight;
-    int selfExchange;    /* 1: a one-rank communicator still sends its shard to itself through RCCL (RTR_MGPU_SELF_EXCHANGE=1; test hook) */
+    int selfExchange;    /* 1: a one-rank communicator still sends its shard to itself through RCCL (RTR_MGPU_SELF_EXCHANGE=1; test hook).
+                          * (A second test hook, RTR_MGPU_TEST_SHARED_DEVICE=1, lets rtr_mgpu_create accept the same device for several ranks:
+                          * RCCL refuses that, tests/fake_rccl/ — preloaded by the GPU tests, never part of the product — does not.) */
     int aborted;         /* 1: a rank failed after the exchange was posted or the watchdog fired; the communicators were aborted */
     int rcclVersion;     /* ncclGetVersion of the library that is actually loaded */
     int timeoutMs;

@@ -423,10 +423,14 @@ int rtr_mgpu_create(const int* devices, int n, int framesInFlight, rtr_mgpu** ou
     if (n > RTR_MGPU_MAX_RANKS) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, at most %d ranks", n, RTR_MGPU_MAX_RANKS);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RTR_ERR_NO_DEVICE, "rtr_mgpu_create: no HIP device; this library has no CPU fallback");
-    if (n > count) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, %d present", n, count);
+    /* test hook: ranks may share a device (RCCL itself refuses that; tests/fake_rccl/ stands in for it on a one-GPU box so that the
+     * N > 1 code of this file runs there) */
+    const char* shared = getenv("RTR_MGPU_TEST_SHARED_DEVICE");
+    const bool sharedOk = shared && shared[0] == '1' && !shared[1];
+    if (n > count && !sharedOk) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, %d present", n, count);
     for (int i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= count) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: device %d not in [0,%d)", devices[i], count);
-        for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: device %d listed twice (one rank per GPU)", devices[i]);
+        for (int j = 0; j < i && !sharedOk; ++j) if (devices[j] == devices[i]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: device %d listed twice (one rank per GPU)", devices[i]);
     }
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     ncclResult_t r = ncclCommInitAll(comms.data(), n, devices);

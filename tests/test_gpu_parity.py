@@ -1002,6 +1002,89 @@ def test_mgpu_library_full_batches_overlapping_slot_groups():
     assert r.returncode == 0 and "MGPU_BATCHES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_mgpu_library_several_ranks_on_one_gpu_through_a_same_device_rccl_double(nranks):
+    """librtr_mgpu.so's N > 1 code — enqueue() carrying out every rank's plan on its own streams from its own host thread: shards
+    rendered into gather / local buffers, rank 0 receiving N - 1 shards at shardBytes * src while the others send, the de-interleave,
+    slot reuse, full launches of RTR_MAX_BATCH slots, launches over slots of two earlier groups — with 2, 3 and 8 ranks on a box
+    that has ONE GPU: the ranks share the device (the library's test hook RTR_MGPU_TEST_SHARED_DEVICE) and tests/fake_rccl/, preloaded
+    in front of librccl.so, turns a send / receive pair into an event-ordered device-to-device copy.  Every assembled frame equals the
+    same frame rendered unsharded.  What this cannot show is RCCL itself and the speed; what it does show is that the product's own
+    ordering, offsets and host threads are right with more than one rank in them."""
+    import textwrap
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is missing: run __graft_entry__.build()")
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, os.getcwd())
+        def stage(s): print("STAGE", s, flush=True)
+        stage("imports")
+        import numpy as np
+        from realtimeraytracer_amd import _abi as A, api, mgpu, scenes
+        n, B = {nranks}, A.MAX_BATCH
+        W, H = 320, 184
+        s = scenes.cornell_box(W, H)
+        stage("rtr_mgpu_create")
+        m = mgpu.MultiGpu(devices=[0] * n, frames_in_flight=2 * B)
+        assert m.info.nranks == n and m.info.nlocal == n and m.info.rcclVersion == 99999, (m.info.nranks, m.info.rcclVersion)
+        stage("rtr_mgpu_scene_create")
+        m.scene_create(s.desc)
+        p = api.make_params(W, H, spp=1)
+        want = {{}}
+        stage("single frames, two slots in flight, a slot reused")
+        m.render_async(0, s.camera, s.scene_info(1), p); m.render_async(1, s.camera, s.scene_info(2), p)
+        m.render_async(0, s.camera, s.scene_info(3), p)
+        want[0], want[1] = 3, 2
+        def launch(slots, first):
+            m.render_batch_async(slots, [s.camera] * len(slots), [s.scene_info(first + j) for j in range(len(slots))], p)
+            for j, sl in enumerate(slots):
+                want[sl] = first + j
+        stage("a launch over slots 2..5")
+        launch([2, 3, 4, 5], 10)
+        stage("rtr_mgpu_wait")
+        for sl in range(6):
+            m.wait(sl)
+        got = {{sl: m.download(sl) for sl in range(6)}}
+        shard = m.download_shard(0, n - 1)
+        assert shard.shape == (api.shard_rows(H, 8, n), W)
+        for rnd in range(2):
+            stage(f"round {{rnd}}: two full launches and a third over slots of both")
+            launch(list(range(B)), 1000 * rnd + 100)
+            launch(list(range(B, 2 * B)), 1000 * rnd + 200)
+            launch(list(range(B // 2, B // 2 + B)), 1000 * rnd + 300)
+        for sl in range(2 * B):
+            m.wait(sl)
+        stage("reference renders")
+        ctx = api.Context(0)
+        scene = api.Scene(ctx, s.desc)
+        frame = api.Frame(ctx, W, H)
+        def same(img, f, what):
+            api.render(scene, s.camera, s.scene_info(f), p, frame)
+            bad = int((img != frame.download()).sum())
+            assert bad == 0, (what, "frame", f, "pixels differing", bad)
+        for sl, f in ((0, 3), (1, 2), (2, 10), (3, 11), (4, 12), (5, 13)):
+            same(got[sl], f, ("first part, slot", sl))
+        for sl, f in sorted(want.items()):
+            same(m.download(sl), f, ("slot", sl))
+        stage("another extent")
+        p2 = api.make_params(200, 120, spp=2)
+        m.render_async(1, s.camera, s.scene_info(7), p2); m.wait(1)
+        small = m.download(1)
+        f2 = api.Frame(ctx, 200, 120)
+        api.render(scene, s.camera, s.scene_info(7), p2, f2)
+        assert int((small != f2.download()).sum()) == 0
+        stage("rtr_mgpu_destroy")
+        m.close()
+        print("MGPU_RANKS_OK", n, len(want))
+    """)
+    env = dict(os.environ, LD_PRELOAD=fake, RTR_MGPU_TEST_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_MGPU_TIMEOUT_MS="60000")
+    env.pop("RTR_MGPU_SELF_EXCHANGE", None)
+    r = _run_staged_child(code, env, 300)
+    assert r.returncode == 0 and "MGPU_RANKS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_scene_create_like_uploads_the_tree_without_building_it(gpu_ctx, scene_cache):
     """rtr_scene_create_like: the replica renders the same bytes, reports the same tree and did not spend a build (what
     rtr_mgpu_scene_create replicates the scene with); a description of another size is refused."""
