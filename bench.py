@@ -105,7 +105,10 @@ def launch_plan(args, env, argv):
         return dict(base, mode="torchrun-child", world=n, library_entry="rtr_mgpu_create_rank",
                     argv=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                           "--master-port", port, os.path.join(ROOT, "bench.py")] + child)
-    return dict(base, mode="inproc", world=n, library_entry="rtr_mgpu_create", devices=list(range(n)))
+    # rehearsal on a one-GPU box: the N ranks share device 0 (the library's test hook) and tests/fake_rccl stands in for RCCL (LD_PRELOAD);
+    # the line says so ("rehearsal") and its rate is that of ONE GPU time-sliced by N ranks — what the exchange machinery costs, not scaling
+    shared = env.get("RTR_MGPU_TEST_SHARED_DEVICE") == "1"
+    return dict(base, mode="inproc", world=n, library_entry="rtr_mgpu_create", devices=[0] * n if shared else list(range(n)), shared_device=shared)
 
 
 def build_setup(args, scenes, np):
@@ -211,7 +214,7 @@ def run_inproc(args, K, plan):
             collect(b)
 
     def sync_all():
-        for d in plan["devices"]:
+        for d in sorted(set(plan["devices"])):
             torch.cuda.synchronize(d)
 
     for b in range(nbuf):                               # set-up, not warm-up: every slot allocates on its first render
@@ -226,6 +229,9 @@ def run_inproc(args, K, plan):
     drain()
     kern.update({k: 0.0 for k in kern}); kern["n"] = 0
     sync_all()
+    import ctypes as C
+    info0 = A.rtr_mgpu_info()
+    A.mgpu_lib().rtr_mgpu_get_info(mg.h, C.byref(info0))         # the host-time counters before the timed region (set-up allocates)
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)
     drain()
@@ -237,7 +243,10 @@ def run_inproc(args, K, plan):
     for j in range(K):
         api.render(scene, setup.camera, setup.scene_info(j if K > 1 else last_i), params(0, j=j), whole)
     bad = int((mg.download(last_slot[0]) != whole.download()).sum())
-    info = mg.info
+    info = A.rtr_mgpu_info()
+    A.mgpu_lib().rtr_mgpu_get_info(mg.h, C.byref(info))          # after the run: with the host time of the ranks' threads
+    host_frames = max(int(info.enqueuedFrames) - int(info0.enqueuedFrames), 1)
+    host_ms, host_rccl_ms = (info.enqueueHostMs - info0.enqueueHostMs) / host_frames, (info.enqueueRcclMs - info0.enqueueRcclMs) / host_frames
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     n = max(kern["n"], 1)
     out = {
@@ -257,8 +266,13 @@ def run_inproc(args, K, plan):
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
         "rccl": {"nranks": int(info.nranks), "nlocal": int(info.nlocal), "version": int(info.rcclVersion), "launch": "one process, rtr_mgpu_create (ncclCommInitAll, a host thread per rank)",
                  "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
-                 "env": plan["env_defaults"]},
+                 "env": plan["env_defaults"],
+                 # host time of the slowest rank's thread per frame it enqueued (stream waits, the launch, RCCL calls, event records): the
+                 # ranks' threads run side by side, so this — not its sum over ranks — is what must stay below a shard's GPU time
+                 "host_enqueue_ms_per_frame": round(host_ms, 4), "of_which_inside_rccl_calls": round(host_rccl_ms, 4)},
         "verify": {"assembled_vs_unsharded_pixels_differing": bad, "frame": last_i},
+        "rehearsal": ("the %d ranks share ONE GPU (RTR_MGPU_TEST_SHARED_DEVICE=1; rcclVersion 99999 = tests/fake_rccl, a same-device double of RCCL): "
+                      "the rate is one GPU's, time-sliced — not a scaling point" % N) if plan.get("shared_device") else None,
         "roofline": None, "roofline_note": "the roofline block is reported for the one-GPU run of the same workload (N = 1 line)",
         "cpu_baseline": None,
     }

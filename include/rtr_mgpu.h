@@ -84,6 +84,12 @@ typedef struct rtr_mgpu_info {
     int aborted;         /* 1: a rank failed after the exchange was posted or the watchdog fired; the communicators were aborted */
     int rcclVersion;     /* ncclGetVersion of the library that is actually loaded */
     int timeoutMs;
+    /* host time the local ranks' threads spent carrying out plans (enqueue(): stream waits, the launch of the pipeline, RCCL calls, event
+     * records) since the handle was made, for the local rank that spent most, and the frames that rank enqueued: ms / frames must stay
+     * below the GPU time of a rank's shard (0.28 ms for one rank of eight on the bench frame) or the host is the limit */
+    double enqueueHostMs;
+    double enqueueRcclMs;              /* the part of enqueueHostMs spent inside RCCL calls (ncclGroupEnd posts the transfers; it may wait for peers) */
+    unsigned long long enqueuedFrames;
 } rtr_mgpu_info;
 int  rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out);
 

@@ -206,7 +206,8 @@ RTRH_SYMBOLS = {
 
 class rtr_mgpu_info(C.Structure):
     _fields_ = [("nranks", C.c_int), ("nlocal", C.c_int), ("firstRank", C.c_int), ("framesInFlight", C.c_int),
-                ("selfExchange", C.c_int), ("aborted", C.c_int), ("rcclVersion", C.c_int), ("timeoutMs", C.c_int)]
+                ("selfExchange", C.c_int), ("aborted", C.c_int), ("rcclVersion", C.c_int), ("timeoutMs", C.c_int),
+                ("enqueueHostMs", C.c_double), ("enqueueRcclMs", C.c_double), ("enqueuedFrames", C.c_ulonglong)]
 
 
 class rtr_mgpu_op(C.Structure):

@@ -95,6 +95,7 @@ struct Rank {
     /* what this rank's worker is doing right now (a string literal): the watchdog of rtr_mgpu_wait names it when it gives up, so a
      * hang says where it is */
     std::atomic<const char*> stage{"idle"};
+    std::atomic<unsigned long long> enqueueNs{0}, rcclNs{0}, enqueuedFrames{0};     /* host time of enqueue() on this rank's thread, and of the RCCL calls in it (rtr_mgpu_info) */
 };
 
 #define W_HIP(expr)  do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return RTR_ERR_HIP; } } while (0)
@@ -227,6 +228,10 @@ struct BatchJob {                     /* what one call renders: n frames into n 
  * render stream, which is "the render stream" of every slot's plan for this batch — then the rest of each slot's plan (its own
  * events, its own exchange). */
 int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
+    struct Clock {
+        Rank& r; int frames; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Clock() { r.enqueueNs += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); r.enqueuedFrames += (unsigned long long)frames; }
+    } clock{r, job.n};
     W_HIP(hipSetDevice(r.device));
     if (!r.scene) { err = "no scene: call rtr_mgpu_scene_create first"; return RTR_ERR_INVALID_ARGUMENT; }
     rtr_render_params p = job.p;
@@ -280,10 +285,15 @@ int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
                 he = hipEventRecord(ev, st);
                 if (he == hipSuccess && o.event == RTR_MGPU_EV_COMM_DONE) s.commPending = true;
                 break;
-            case RTR_MGPU_OP_GROUP_START: r.stage = "ncclGroupStart"; ne = ncclGroupStart(); inGroup = ne == ncclSuccess; break;
-            case RTR_MGPU_OP_RECV: r.stage = "ncclRecv"; ne = ncclRecv(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); break;
-            case RTR_MGPU_OP_SEND: r.stage = "ncclSend"; ne = ncclSend(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); break;
-            case RTR_MGPU_OP_GROUP_END: r.stage = "ncclGroupEnd"; inGroup = false; ne = ncclGroupEnd(); break;
+            case RTR_MGPU_OP_GROUP_START: case RTR_MGPU_OP_RECV: case RTR_MGPU_OP_SEND: case RTR_MGPU_OP_GROUP_END: {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (o.kind == RTR_MGPU_OP_GROUP_START) { r.stage = "ncclGroupStart"; ne = ncclGroupStart(); inGroup = ne == ncclSuccess; }
+                else if (o.kind == RTR_MGPU_OP_RECV) { r.stage = "ncclRecv"; ne = ncclRecv(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); }
+                else if (o.kind == RTR_MGPU_OP_SEND) { r.stage = "ncclSend"; ne = ncclSend(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); }
+                else { r.stage = "ncclGroupEnd"; inGroup = false; ne = ncclGroupEnd(); }
+                r.rcclNs += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                break;
+            }
             case RTR_MGPU_OP_DEINTERLEAVE:
                 r.stage = "rtr_deinterleave_bands";
                 c = rtr_deinterleave_bands(r.commCtx, s.gathered, s.full, s.width, s.height, s.bandRows, (uint32_t)m->nranks);
@@ -496,6 +506,10 @@ int rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out) {
     out->framesInFlight = m->framesInFlight; out->selfExchange = m->selfExchange ? 1 : 0;
     out->aborted = m->aborted ? 1 : 0; out->timeoutMs = (int)m->timeoutMs;
     int v = 0; if (ncclGetVersion(&v) == ncclSuccess) out->rcclVersion = v;
+    for (auto& rp : m->ranks) {
+        const double ms = (double)rp->enqueueNs.load() * 1e-6;
+        if (ms >= out->enqueueHostMs) { out->enqueueHostMs = ms; out->enqueueRcclMs = (double)rp->rcclNs.load() * 1e-6; out->enqueuedFrames = rp->enqueuedFrames.load(); }
+    }
     return RTR_OK;
 }
 

@@ -46,7 +46,7 @@ def test_mgpu_header_symbols_are_exported_and_bound():
     assert set(names) <= exported
     ldd = subprocess.check_output(["ldd", A.LIB_MGPU_PATH]).decode()
     assert "librccl" in ldd and "librtr_hip" in ldd and "oracle" not in ldd
-    assert C.sizeof(A.rtr_mgpu_info) == 32
+    assert C.sizeof(A.rtr_mgpu_info) == 56
 
 
 def test_mgpu_rejects_bad_arguments_and_missing_device():

@@ -84,3 +84,22 @@ def test_bench_more_gpus_than_present_fails_from_the_library(scene_cache):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2", "--warmup", "1"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert f"{want} devices requested, {have} present" in r.stderr + r.stdout, r.stderr[-2000:]
+
+
+def test_bench_gpus_4_started_plainly_with_the_ranks_sharing_one_gpu(scene_cache):
+    """`python bench.py --gpus 4` the way the driver starts it — no launcher, one process, rtr_mgpu_create — carried out for real on a
+    one-GPU box: the four ranks share device 0 (the library's test hook) and tests/fake_rccl stands in for RCCL.  The line is marked
+    as a rehearsal (its rate is one GPU's, time-sliced), carries what the communicator looked like and the ranks' host time, and the
+    assembled frame of the last step equals the unsharded one."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(fake), "run __graft_entry__.build()"
+    d = _bench(["--gpus", "4", "--steps", "24", "--warmup", "8", "--width", "640", "--height", "360"],
+               env={"RTR_SCENE_CACHE": str(scene_cache), "LD_PRELOAD": fake, "RTR_MGPU_TEST_SHARED_DEVICE": "1"})
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["value"] > 100 and d["rehearsal"] and "share ONE GPU" in d["rehearsal"]
+    r = d["rccl"]
+    assert r["nranks"] == 4 and r["nlocal"] == 4 and r["version"] == 99999 and "rtr_mgpu_create" in r["launch"]
+    assert 0 < r["host_enqueue_ms_per_frame"] < 5 and 0 <= r["of_which_inside_rccl_calls"] <= r["host_enqueue_ms_per_frame"]
+    assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0
+    assert d["frames_in_flight"] == 32 and d["frames_per_launch"] == 16 and d["timed_launches"] == [12, 12]
+    assert "band-sharded x4" in d["config"]["workload"]
+
