@@ -49,16 +49,19 @@ L2_PEAK_GBS = 34500.0    # same guide: L2 aggregate, 8 XCDs
 
 
 def default_frames_in_flight(n_gpus):
-    """Frame objects in use per rank; --batch of them go into one launch of the pipeline.  A 1-spp frame — a 1/N shard of one even more
-    so — is too little work per launch for the latency-bound kernels: sixteen frames per launch, one launch at a time, render faster
-    than any number of single-frame launches overlapped (profiles/r03/ab_frame_batch2.log, sweep_frames_per_launch.log: N = 1 2.25 ms
-    per frame with four single-frame launches in flight, 2.13 with eight frames per launch, 2.10 with sixteen).  Sixteen 1/4 or 1/8
-    shards are still only a few frames of work, so from N = 4 on two such launches are kept in flight (one rank of 8: 0.298 -> 0.280 ms
-    per frame, one of 4: 0.557 with two)."""
-    return 32 if n_gpus >= 4 else 16
+    """Frame objects in use per rank; default_batch() of them go into one launch of the pipeline.  A 1-spp frame — a 1/N shard of one
+    even more so — is too little work per launch for the latency-bound kernels: many frames per launch, one launch at a time, render
+    faster than any number of single-frame launches overlapped (profiles/r03/ab_frame_batch2.log, sweep_frames_per_launch.log,
+    sweep_frames_per_launch_32.log: N = 1 2.25 ms per frame with four single-frame launches in flight, 2.13 with eight frames per launch,
+    2.05 with sixteen, 2.02 with thirty-two).  Shards of 1/4 and 1/8 do as well with sixteen per launch and two launches in flight as
+    with thirty-two per launch (one rank of 8: 0.275 / 0.278 ms per frame), and two launches leave the exchange of one to overlap the
+    render of the other."""
+    return 32
 
 
-DEFAULT_BATCH = 16     # frames per launch (rtr_render_batch_async / rtr_mgpu_render_batch_async, at most RTR_MAX_BATCH); --batch 1 = one launch per frame
+def default_batch(n_gpus):
+    """frames per launch (rtr_render_batch_async / rtr_mgpu_render_batch_async, at most RTR_MAX_BATCH = 32); --batch 1 = one launch per frame"""
+    return 32 if n_gpus < 4 else 16
 
 
 def launch_sizes(count, batch):
@@ -79,7 +82,7 @@ def launch_plan(args, env, argv):
     fif = args.frames_in_flight or default_frames_in_flight(max(n, getattr(args, 'emulate_rank_of', 0) or 0))
     # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 8 frames in flight every frame's stream gets its own
     env_defaults = {"GPU_MAX_HW_QUEUES": "8"} if fif >= 8 else {}
-    base = {"n_gpus": n, "frames_in_flight": fif, "frames_per_launch": max(1, min(args.batch or DEFAULT_BATCH, fif)), "env_defaults": env_defaults}
+    base = {"n_gpus": n, "frames_in_flight": fif, "frames_per_launch": max(1, min(args.batch or default_batch(max(n, getattr(args, 'emulate_rank_of', 0) or 0)), fif)), "env_defaults": env_defaults}
     if n < 1:
         return dict(base, mode="error", why=f"--gpus {n}")
     ws = env.get("WORLD_SIZE")
@@ -179,7 +182,8 @@ def run_inproc(args, K, plan):
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
         kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
 
-    B = max(1, min(plan["frames_per_launch"], nbuf, A.MAX_BATCH)) if K == 1 else 1
+    # frames per launch: what was asked for, capped by what one launch of a rank's shard can address (rtr_render_batch_limit)
+    B = max(1, min(plan["frames_per_launch"], nbuf, api.render_batch_limit(scene, params(0, 0, N), setup.num_lights))) if K == 1 else 1
     groups, launch_no, last_slot = max(nbuf // B, 1), [0], [0]
 
     def step(i):
@@ -516,7 +520,8 @@ def main():
         if st.shadowTraceClockMHz > 0:
             clocks.append(st.shadowTraceClockMHz)
 
-    B = max(1, min(plan["frames_per_launch"], nbuf, A.MAX_BATCH)) if (K == 1 and (use_lib or not dist_on)) else 1
+    # frames per launch: what was asked for, capped by what one launch of this rank's shard can address (rtr_render_batch_limit)
+    B = max(1, min(plan["frames_per_launch"], nbuf, api.render_batch_limit(scene, p_run[0], setup.num_lights))) if (K == 1 and (use_lib or not dist_on)) else 1
 
     groups = max(nbuf // B, 1)
     launch_no = [0]

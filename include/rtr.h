@@ -283,9 +283,13 @@ int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSc
  * for what their streams hold when it is enqueued and their streams wait for the launch, so work enqueued for a frame before and
  * after a batch is ordered around it without a host join (tested).  Staged pipeline only; the frames must live on one device and be distinct.
  * The reference records one vkCmdTraceRaysKHR per frame (src/app/application.cppm:362-389); this is n of them in one. */
-#define RTR_MAX_BATCH 16
+#define RTR_MAX_BATCH 32
 int  rtr_render_batch_async(rtr_scene* scene, const RtrCameraData* cameras, const RtrSceneInfo* sceneInfos, const rtr_render_params* params,
                             rtr_frame* const* frames, uint32_t n);
+/* How many frames of these params one launch takes: min(RTR_MAX_BATCH, what the staged pipeline's scratch can address — its
+ * visibility slots are 31-bit indices: pixel-sample slots of the launch, rounded up to a power of two, x queries per pixel-sample).
+ * 1 when only a single frame fits (or the megakernel is asked for); a caller that batches asks this first.  Pure arithmetic. */
+int  rtr_render_batch_limit(const rtr_scene* scene, const rtr_render_params* params, uint32_t numAreaLights, uint32_t* maxFrames);
 int  rtr_frame_wait(rtr_frame* frame);
 
 /* The passes that follow the ray-gen dispatch in the reference's frame loop (src/app/application.cppm:391-445):

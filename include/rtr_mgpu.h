@@ -31,7 +31,7 @@ extern "C" {
 typedef struct rtr_mgpu rtr_mgpu;
 
 #define RTR_MGPU_ID_BYTES 128          /* sizeof(ncclUniqueId) */
-#define RTR_MGPU_MAX_SLOTS 32
+#define RTR_MGPU_MAX_SLOTS 64
 
 /* Fills `id` (RTR_MGPU_ID_BYTES bytes) with a fresh communicator id: call on one rank, distribute to all. */
 int  rtr_mgpu_unique_id(void* id);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Counter passes behind bench.py's roofline block (round 3):  bash profiles/pmc_r03.sh <tag> [extra bench args]
-# The driver's bench command (--steps 20 --warmup 5: two launches of 10 frames, one launch at a time, so a kernel's counters are its own;
-# STEPS=32 WARMUP=16 for launches of 16); separate --pmc passes with --kernel-trace only.
+# The driver's bench command (--steps 20 --warmup 5: one launch of 20 frames at a time, so a kernel's counters are its own;
+# STEPS=64 WARMUP=32 for launches of 32); separate --pmc passes with --kernel-trace only.
 # Writes gpurun_out/prof_<tag>/summary.txt and pmc.json (copy both into profiles/r03/).
 set -o pipefail
 TAG=${1:-r03}; shift || true

@@ -4,9 +4,9 @@ cd $GRAFT_REPO_ROOT
 TAG=${1:-r03_5}
 mkdir -p gpurun_out/r03
 timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > gpurun_out/r03/pytest_gpu_$TAG.log 2>&1; echo "pytest rc $?"; tail -4 gpurun_out/r03/pytest_gpu_$TAG.log
-bash profiles/pmc_r03.sh ${TAG}_b10 > gpurun_out/r03/pmc_${TAG}_b10.log 2>&1; echo "pmc b10 rc $?"
-STEPS=32 WARMUP=16 bash profiles/pmc_r03.sh ${TAG}_b16 > gpurun_out/r03/pmc_${TAG}_b16.log 2>&1; echo "pmc b16 rc $?"
-bash profiles/stats_r03.sh ${TAG}_b10s > gpurun_out/r03/stats_${TAG}_b10.log 2>&1; echo "stats rc $?"
+bash profiles/pmc_r03.sh ${TAG}_b20 > gpurun_out/r03/pmc_${TAG}_b20.log 2>&1; echo "pmc b20 rc $?"
+STEPS=64 WARMUP=32 bash profiles/pmc_r03.sh ${TAG}_b32 > gpurun_out/r03/pmc_${TAG}_b32.log 2>&1; echo "pmc b32 rc $?"
+bash profiles/stats_r03.sh ${TAG}_b20s > gpurun_out/r03/stats_${TAG}_b20.log 2>&1; echo "stats rc $?"
 cd $GRAFT_REPO_ROOT
 python3 bench.py --steps 20 --warmup 5 --verify > gpurun_out/r03/bench_driver_cmd_$TAG.log 2>&1; echo "bench driver rc $?"
 python3 bench.py > gpurun_out/r03/bench_default_$TAG.log 2>&1; echo "bench default rc $?"

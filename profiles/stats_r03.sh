@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the bench command (round 3): bash profiles/stats_r03.sh <tag>
-#   stats        : python bench.py --steps 20 --warmup 5 — the driver's command: two launches of 10 frames, one at a time (STEPS / WARMUP override)
+#   stats        : python bench.py --steps 20 --warmup 5 — the driver's command: one launch of 20 frames at a time (STEPS / WARMUP override)
 #   stats_serial : --batch 1 --frames-in-flight 1 — one frame per launch, one frame at a time
 # The untimed passes after the timed region (--isolated-frames, --present-frames) are switched off.  A run also launches every kernel
 # over ONE frame (each frame object's first render, the counting pass), so rocprofv3's own per-kernel average mixes two kinds of

@@ -153,6 +153,7 @@ RTR_SYMBOLS = {
     "rtr_render": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
     "rtr_render_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
     "rtr_render_batch_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), P(VP), u32]),
+    "rtr_render_batch_limit": (C.c_int, [VP, P(rtr_render_params), u32, P(u32)]),
     "rtr_frame_wait": (C.c_int, [VP]),
     "rtr_deinterleave_bands": (C.c_int, [VP, VP, VP, u32, u32, u32, u32]),
     "rtr_denoise_combine": (C.c_int, [VP, C.c_int]),
@@ -224,9 +225,9 @@ MGPU_PLAN_MAX_OPS = 32
 MGPU_MAX_RANKS = 16
 
 
-MAX_BATCH = 16
+MAX_BATCH = 32
 MGPU_ID_BYTES = 128
-MGPU_MAX_SLOTS = 32
+MGPU_MAX_SLOTS = 64
 MGPU_NO_EXCHANGE = 1
 
 # every entry point include/rtr_mgpu.h declares

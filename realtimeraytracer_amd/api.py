@@ -181,6 +181,13 @@ def render_batch(scene, cameras, scene_infos, params, frames):
     _check(scene.lib.rtr_render_batch_async(scene.h, cams, infos, C.byref(params), hs, n), "rtr_render_batch_async")
 
 
+def render_batch_limit(scene, params, num_area_lights):
+    """rtr_render_batch_limit: how many frames of these params one launch of the pipeline takes (<= A.MAX_BATCH)"""
+    n = C.c_uint32(0)
+    _check(scene.lib.rtr_render_batch_limit(scene.h, C.byref(params), num_area_lights, C.byref(n)), "rtr_render_batch_limit")
+    return int(n.value)
+
+
 def deinterleave_bands(ctx, gathered_ptr, dst_ptr, width, height, band_rows, shard_count):
     _check(ctx.lib.rtr_deinterleave_bands(ctx.h, A.VP(gathered_ptr), A.VP(dst_ptr), width, height, band_rows, shard_count),
            "rtr_deinterleave_bands")

@@ -696,13 +696,15 @@ struct FrameOut {
  * frames (camera, seed, accumulation state, output images) is looked up per wave: planeStride is a multiple of 64, so a wave never
  * straddles two frames.  Why: a 1-spp frame (let alone a 1/8 shard of one) is too little work per launch for the latency-bound
  * kernels — the camera-ray kernel takes 0.34 ms for one frame's rays and 0.41 ms for four times as many. */
-constexpr uint32_t kMaxBatch = 16;     /* = RTR_MAX_BATCH (include/rtr.h).  Sixteen frames' arguments are 3.5 KB of the 4 KB a launch may pass by value */
+constexpr uint32_t kMaxBatch = 32;     /* = RTR_MAX_BATCH (include/rtr.h).  Thirty-two frames' arguments are 7 KB passed by value: this stack takes 64 KB and more
+                                        * (profiles/microbench/kernarg_size.hip: launches with 2 ... 64 KB of arguments run and read them right), and the size costs
+                                        * nothing at launch (profiles/r03/ab_kernarg_batch16_build.log) */
 struct FrameBatch {
     RenderArgs ra[kMaxBatch];
     FrameOut   fo[kMaxBatch];
     uint32_t   n;
 };
-static_assert(sizeof(FrameBatch) + sizeof(DeviceScene) + 256 <= 4096, "a launch passes DeviceScene + FrameBatch + a few pointers by value: 4 KB of kernel arguments at most");
+static_assert(sizeof(FrameBatch) + sizeof(DeviceScene) + 256 <= 16384, "a launch passes DeviceScene + FrameBatch + a few pointers by value");
 /* lane g of a launch over the whole batch -> frame b (wave-uniform) and pixel slot q inside the frame */
 __device__ __forceinline__ uint32_t batch_frame(uint32_t g, uint32_t planeStride, uint32_t& q) {
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g / planeStride));

@@ -1041,6 +1041,29 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
     return RTR_OK;
 }
 
+int rtr_render_batch_limit(const rtr_scene* s, const rtr_render_params* pin, uint32_t numAreaLights, uint32_t* maxFrames) {
+    if (!s || !pin || !maxFrames) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_limit: null argument");
+    if (numAreaLights > s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_limit: %u area lights, the scene has %u", numAreaLights, s->numLights);
+    rtr_render_params p = *pin;
+    if (p.bandRows == 0) p.bandRows = 8;
+    if (p.shardCount == 0) p.shardCount = 1;
+    if (p.width == 0 || p.height == 0 || p.spp == 0 || p.bandRows % 8u) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_limit: bad width/height/spp/bandRows");
+    *maxFrames = 1;
+    if (p.pipeline == 1) return RTR_OK;
+    /* the arithmetic of enqueue_render() */
+    uint64_t maxRays = 1;
+    for (uint32_t l = 0; l < numAreaLights; ++l) maxRays += (uint64_t)s->hostLights[l].numTriangles * p.numShadowRays;
+    const uint32_t rows = rtr_shard_rows(p.height, p.bandRows, p.shardCount);
+    const uint64_t blocks = ((uint64_t)((rows + 7u) / 8u) * ((p.width + 7u) / 8u) * 64u + 255u) / 256u;
+    for (uint32_t n = rtrdev::kMaxBatch; n > 1; --n) {
+        const uint64_t nPS = blocks * 256u * p.spp * n;
+        uint64_t slotStride = 256;
+        while (slotStride < nPS) slotStride <<= 1;
+        if (slotStride * maxRays < (1ull << 31) && maxRays <= 4096 && blocks * n < (1ull << 31)) { *maxFrames = n; break; }
+    }
+    return RTR_OK;
+}
+
 int rtr_frame_wait(rtr_frame* f) {
     if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_wait: null frame");
     HIP_TRY(hipSetDevice(f->ctx->device));

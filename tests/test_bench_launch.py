@@ -21,7 +21,7 @@ def _plan(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTR_B
 
 def test_one_gpu_is_a_single_process():
     d = _plan([])
-    assert d["mode"] == "single" and d["n_gpus"] == 1 and d["frames_in_flight"] == 16 and d["frames_per_launch"] == 16
+    assert d["mode"] == "single" and d["n_gpus"] == 1 and d["frames_in_flight"] == 32 and d["frames_per_launch"] == 32
     assert _plan(["--batch", "1", "--frames-in-flight", "4"])["frames_per_launch"] == 1 and _plan(["--frames-in-flight", "4"])["frames_per_launch"] == 4
 
 
@@ -31,7 +31,7 @@ def test_started_plainly_n_gpus_run_in_one_process_through_the_library():
         assert d["mode"] == "inproc" and d["library_entry"] == "rtr_mgpu_create" and d["devices"] == list(range(n)) and d["world"] == n
     # the settings of an N-GPU run live in bench.py, not in the caller's environment
     assert _plan(["--gpus", "8"])["frames_in_flight"] == 32 and _plan(["--gpus", "8"])["env_defaults"] == {"GPU_MAX_HW_QUEUES": "8"}
-    assert _plan(["--gpus", "4"])["frames_in_flight"] == 32 and _plan(["--gpus", "2"])["frames_in_flight"] == 16
+    assert _plan(["--gpus", "4"])["frames_in_flight"] == 32 and _plan(["--gpus", "2"])["frames_in_flight"] == 32 and _plan(["--gpus", "2"])["frames_per_launch"] == 32
     assert _plan(["--emulate-rank-of", "8"])["frames_in_flight"] == 32 and _plan(["--emulate-rank-of", "8"])["mode"] == "single"
     assert _plan(["--gpus", "8"])["frames_per_launch"] == 16 and _plan(["--gpus", "8", "--frames-in-flight", "2"])["frames_in_flight"] == 2
 
@@ -66,7 +66,7 @@ def test_a_run_is_cut_into_equal_launches():
     """20 timed frames at 16 per launch are 10 + 10: a short launch is a slow one, and the per-launch figures of the line (roofline)
     describe equal launches"""
     import bench
-    assert bench.launch_sizes(20, 16) == [10, 10] and bench.launch_sizes(20, 8) == [7, 7, 6] and bench.launch_sizes(32, 16) == [16, 16]
+    assert bench.launch_sizes(20, 32) == [20] and bench.launch_sizes(20, 16) == [10, 10] and bench.launch_sizes(20, 8) == [7, 7, 6] and bench.launch_sizes(32, 16) == [16, 16]
     assert bench.launch_sizes(5, 16) == [5] and bench.launch_sizes(0, 16) == [] and bench.launch_sizes(17, 16) == [9, 8] and bench.launch_sizes(7, 1) == [1] * 7
     for count in range(1, 70):
         for b in (1, 2, 8, 16):
