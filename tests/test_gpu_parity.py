@@ -666,6 +666,39 @@ print("batch ok")
     assert r.returncode == 0 and "batch ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_batch_limit_is_the_launch_that_still_fits(gpu_ctx, scene_cache):
+    """rtr_render_batch_limit: RTR_MAX_BATCH where everything fits, the arithmetic of the 31-bit visibility slots where it does not
+    (1080p at 4 spp with 13 queries per pixel-sample: 16 frames), 1 for the megakernel — and a launch of one frame more than the limit
+    is refused before anything is allocated."""
+    s = scenes.sponza_class(1920, 1080)
+    scene = api.Scene(gpu_ctx, s.desc)
+    nl = s.num_lights
+    assert api.render_batch_limit(scene, api.make_params(1920, 1080, spp=1), nl) == A.MAX_BATCH
+    assert api.render_batch_limit(scene, api.make_params(1920, 1080, spp=1, pipeline=1), nl) == 1
+    queries = 1 + 3 * 2 * nl                                   # 3 shadow rays x 2 triangles per light quad + the directional light
+
+    def expect(w, h, spp, shards=1):
+        rows = api.shard_rows(h, 8, shards)
+        blocks = (((rows + 7) // 8) * ((w + 7) // 8) * 64 + 255) // 256
+        for n in range(A.MAX_BATCH, 1, -1):
+            stride = 256
+            while stride < blocks * 256 * spp * n:
+                stride *= 2
+            if stride * queries < 2 ** 31:
+                return n
+        return 1
+    for (w, h, spp, shards) in ((1920, 1080, 4, 1), (3840, 2160, 1, 1), (3840, 2160, 4, 1), (3840, 2160, 16, 1), (1920, 1080, 4, 8), (7680, 4320, 8, 2)):
+        p = api.make_params(w, h, spp=spp, shard_index=0, shard_count=shards)
+        assert api.render_batch_limit(scene, p, nl) == expect(w, h, spp, shards), (w, h, spp, shards)
+    assert expect(1920, 1080, 4) == 16
+    p = api.make_params(1920, 1080, spp=4, pipeline=2)
+    frames = [api.Frame(gpu_ctx, 1920, 1080) for _ in range(17)]
+    with pytest.raises(api.RtrError):
+        api.render_batch(scene, [s.camera] * 17, [s.scene_info(b) for b in range(17)], p, frames)
+    for f in frames:
+        f.close()
+
+
 def test_d6_occluded_sample_with_overflowing_contribution(gpu_ctx, oracle, scene_cache):
     """Divergence D6.  The reference evaluates the BRDF of every light sample and multiplies by currShadow
     (raygen.rgen:244-270); the oracle does the same.  The product, when only the shadowed image is kept, does not evaluate the BRDF
