@@ -304,9 +304,10 @@ def main():
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N",
                     help="single-GPU rehearsal of what ONE rank does in an N-GPU run: renders shard 0 of N with the same two-stream "
                          "frame pipelining, without the gather (the printed value is this rank's rays/s, not a job total)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="frame objects in use, each with its own stream (0 = default: 8; 1 = one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frame objects in use, each with its own stream (0 = default: 32; 1 = one frame at a time)")
     ap.add_argument("--batch", type=int, default=0, metavar="B",
-                    help="frames per launch of the pipeline (rtr_render_batch_async; 0 = default: 8, 1 = one launch per frame).  The frames in flight are "
+                    help="frames per launch of the pipeline (rtr_render_batch_async; 0 = default: 32 below four GPUs, 16 and two launches in flight from four on; "
+                         "1 = one launch per frame; capped by rtr_render_batch_limit).  The frames in flight are "
                          "rendered in groups of B: every kernel of the pipeline is launched once per group over B frames' work")
     ap.add_argument("--accumulate", type=int, default=1, metavar="K",
                     help="a step = K frames (frame = 0..K-1) summed in the float HDR buffer and tonemapped once (BASELINE config 5: "
