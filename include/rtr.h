@@ -171,7 +171,7 @@ typedef struct rtr_frame_stats {
     uint32_t localRows;        /* rows this shard rendered */
     uint32_t localPixels;
     uint32_t pipelineUsed;     /* 1 megakernel, 2 wavefront */
-    float    shadowTraceClockMHz; /* shader clock the any-hit launch ran at: s_memtime ticks / s_memrealtime (100 MHz) ticks, median of one wave per XCD */
+    float    shadowTraceClockMHz; /* shader clock the any-hit launch ran at: s_memtime ticks / s_memrealtime (100 MHz) ticks of one wave per XCD, MEAN over the XCDs (they clock independently; slowest / fastest below) */
     /* scheduling of the any-hit kernel, from its counting form (collectStats = 1): loop trips of its node and triangle phases,
      * summed over waves, and the lanes that had work in those trips (lane utilisation = lanes / (64 trips)) */
     uint64_t shadowInnerIterations, shadowInnerActiveLanes;
@@ -181,6 +181,7 @@ typedef struct rtr_frame_stats {
     uint32_t _padTail;
     uint64_t primaryTailRays;  /* camera rays that outgrew the 16-entry LDS stack of k_primary_persist and were redone by k_primary_tail over the BVH2 */
     uint64_t shadowTailRays;   /* rays that outgrew the 16-entry LDS stack and were finished by k_shadow_tail over the BVH2 (both parts of their work are in the counters) */
+    float    shadowTraceClockMinMHz, shadowTraceClockMaxMHz;   /* the slowest and the fastest XCD of that launch */
 } rtr_frame_stats;
 
 /* ---- context -------------------------------------------------------------------------- */

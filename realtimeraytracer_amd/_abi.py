@@ -100,7 +100,8 @@ class rtr_frame_stats(C.Structure):
                 ("totalMs", f32), ("primaryMs", f32), ("shadowGenMs", f32), ("shadowTraceMs", f32), ("resolveMs", f32),
                 ("localRows", u32), ("localPixels", u32), ("pipelineUsed", u32), ("shadowTraceClockMHz", f32),
                 ("shadowInnerIterations", u64), ("shadowInnerActiveLanes", u64), ("shadowTriIterations", u64), ("shadowTriActiveLanes", u64),
-                ("shadowRefills", u64), ("shadowTailMs", f32), ("_padTail", u32), ("primaryTailRays", u64), ("shadowTailRays", u64)]
+                ("shadowRefills", u64), ("shadowTailMs", f32), ("_padTail", u32), ("primaryTailRays", u64), ("shadowTailRays", u64),
+                ("shadowTraceClockMinMHz", f32), ("shadowTraceClockMaxMHz", f32)]
 
 
 assert C.sizeof(RtrVertex) == 48 and C.sizeof(RtrCameraData) == 64 and C.sizeof(RtrSceneInfo) == 32

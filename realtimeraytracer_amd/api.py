@@ -172,12 +172,15 @@ def render(scene, camera, scene_info, params, frame, asynchronous=False):
     _check(fn(scene.h, C.byref(camera), C.byref(scene_info), C.byref(params), frame.h), "rtr_render")
 
 
-def render_batch(scene, cameras, scene_infos, params, frames):
-    """rtr_render_batch_async: len(frames) <= A.MAX_BATCH frames in one launch of every kernel; asynchronous, join with frames[k].wait()."""
+def marshal_batch(cameras, scene_infos, frames):
+    """the argument arrays of rtr_render_batch_async, built once (a caller that knows its next launches prepares them ahead)"""
     n = len(frames)
-    cams = (A.RtrCameraData * n)(*cameras)
-    infos = (A.RtrSceneInfo * n)(*scene_infos)
-    hs = (A.VP * n)(*[f.h.value for f in frames])
+    return ((A.RtrCameraData * n)(*cameras), (A.RtrSceneInfo * n)(*scene_infos), (A.VP * n)(*[f.h.value for f in frames]), n)
+
+
+def render_batch(scene, cameras, scene_infos, params, frames, marshalled=None):
+    """rtr_render_batch_async: len(frames) <= A.MAX_BATCH frames in one launch of every kernel; asynchronous, join with frames[k].wait()."""
+    cams, infos, hs, n = marshalled if marshalled is not None else marshal_batch(cameras, scene_infos, frames)
     _check(scene.lib.rtr_render_batch_async(scene.h, cams, infos, C.byref(params), hs, n), "rtr_render_batch_async")
 
 

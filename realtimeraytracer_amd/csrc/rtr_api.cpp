@@ -1084,13 +1084,16 @@ int rtr_frame_wait(rtr_frame* f) {
         (void)hipEventElapsedTime(&d, f->ev[3], f->ev[4]);
         s.primaryMs = a; s.shadowGenMs = b; s.shadowTraceMs = c; s.resolveMs = d; s.totalMs = a + b + c + tail + d;
         s.pipelineUsed = 2;
-        if (f->clk.p) {      /* shader clock held during the any-hit launch: s_memtime ticks over 100-MHz ticks, median of one wave per XCD */
+        if (f->clk.p) {      /* shader clock held during the any-hit launch: s_memtime ticks over 100-MHz ticks of one wave per XCD; the MEAN over the XCDs — they clock
+                              * independently (2.25 ... 2.40 GHz within one launch on a warm part) and the launch's vector-issue capacity is the sum of theirs */
             unsigned long long h[2 * rtrdev::kQueueRegions];
             HIP_TRY(hipMemcpy(h, f->clk.p, sizeof h, hipMemcpyDeviceToHost));
             float mhz[rtrdev::kQueueRegions]; int nv = 0;
             for (uint32_t r = 0; r < rtrdev::kQueueRegions; ++r) if (h[2 * r + 1]) mhz[nv++] = (float)((double)h[2 * r] / (double)h[2 * r + 1] * 100.0);
             for (int i = 1; i < nv; ++i) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; --j) { const float t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }
-            s.shadowTraceClockMHz = nv ? mhz[nv / 2] : 0.f;
+            double sum = 0; for (int i = 0; i < nv; ++i) sum += mhz[i];
+            s.shadowTraceClockMHz = nv ? (float)(sum / nv) : 0.f;
+            s.shadowTraceClockMinMHz = nv ? mhz[0] : 0.f; s.shadowTraceClockMaxMHz = nv ? mhz[nv - 1] : 0.f;
         }
         if (f->queueCount.p) {      /* the next launch pre-fills the visibility array with this one's commoner outcome */
             uint32_t q[4] = {0, 0, 0, 0};
