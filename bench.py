@@ -55,8 +55,9 @@ def default_frames_in_flight(n_gpus):
     sweep_frames_per_launch_32.log: N = 1 2.25 ms per frame with four single-frame launches in flight, 2.13 with eight frames per launch,
     2.05 with sixteen, 2.02 with thirty-two).  Shards of 1/4 and 1/8 do as well with sixteen per launch and two launches in flight as
     with thirty-two per launch (one rank of 8: 0.275 / 0.278 ms per frame), and two launches leave the exchange of one to overlap the
-    render of the other."""
-    return 32
+    render of the other.  At N = 2, 3 (thirty-two half or third frames per launch) the same reason asks for two launches in flight:
+    sixty-four frame objects (profiles/r03/sweep_two_launches_n2.log: no cost on the rendering side)."""
+    return 64 if n_gpus in (2, 3) else 32
 
 
 def default_batch(n_gpus):

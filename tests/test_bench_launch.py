@@ -31,7 +31,7 @@ def test_started_plainly_n_gpus_run_in_one_process_through_the_library():
         assert d["mode"] == "inproc" and d["library_entry"] == "rtr_mgpu_create" and d["devices"] == list(range(n)) and d["world"] == n
     # the settings of an N-GPU run live in bench.py, not in the caller's environment
     assert _plan(["--gpus", "8"])["frames_in_flight"] == 32 and _plan(["--gpus", "8"])["env_defaults"] == {"GPU_MAX_HW_QUEUES": "8"}
-    assert _plan(["--gpus", "4"])["frames_in_flight"] == 32 and _plan(["--gpus", "2"])["frames_in_flight"] == 32 and _plan(["--gpus", "2"])["frames_per_launch"] == 32
+    assert _plan(["--gpus", "4"])["frames_in_flight"] == 32 and _plan(["--gpus", "2"])["frames_in_flight"] == 64 and _plan(["--gpus", "2"])["frames_per_launch"] == 32
     assert _plan(["--emulate-rank-of", "8"])["frames_in_flight"] == 32 and _plan(["--emulate-rank-of", "8"])["mode"] == "single"
     assert _plan(["--gpus", "8"])["frames_per_launch"] == 16 and _plan(["--gpus", "8", "--frames-in-flight", "2"])["frames_in_flight"] == 2
 
