@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 2
+#define RTR_ABI_VERSION 3
 
 typedef enum rtr_status {
     RTR_OK = 0,
@@ -195,6 +195,13 @@ int  rtr_ctx_set_stream(rtr_ctx* ctx, void* hipStream);
 /* The HIP stream (hipStream_t) this context's work is enqueued on, for callers that order their own work against it with events. */
 int  rtr_ctx_get_stream(rtr_ctx* ctx, void** hipStream);
 int  rtr_ctx_device_name(rtr_ctx* ctx, char* buf, size_t bytes);
+/* Run-time tunables of the staged pipeline (scheduling knobs of its kernels: queue binning, batch lengths, persistent workgroups per
+ * CU ...; the names are the fields of rtrdev::Tunables, kernels/rtr_kernels.h).  A context reads them from the environment ONCE, when
+ * it is created (RTR_<NAME IN CAPITALS>); a render uses those of the context of its (leading) frame.  No setting changes a pixel
+ * (tested); the defaults are the measured optima.  RTR_ERR_INVALID_ARGUMENT for an unknown name or a value outside its range.
+ * The reference has no counterpart: its traversal is the driver's (src/vulkan/ray_tracing_pipeline.cppm:212-214). */
+int  rtr_ctx_set_tunable(rtr_ctx* ctx, const char* name, uint32_t value);
+int  rtr_ctx_get_tunable(const rtr_ctx* ctx, const char* name, uint32_t* value);
 
 /* ---- scene ---------------------------------------------------------------------------- */
 /* replaces createSceneFromObjectsAndLights' GPU half (src/app/setup/create_scene.cppm:48-160):
@@ -287,6 +294,19 @@ int  rtr_render_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSc
 #define RTR_MAX_BATCH 32
 int  rtr_render_batch_async(rtr_scene* scene, const RtrCameraData* cameras, const RtrSceneInfo* sceneInfos, const rtr_render_params* params,
                             rtr_frame* const* frames, uint32_t n);
+/* The LATENCY form: ONE frame as `parts` (<= RTR_MAX_SPLIT) band-shards — bands of params->bandRows rows, band b to part b mod parts,
+ * the sharding of the multi-GPU path — each on a stream of its own inside the library, all writing their rows of `frame`'s images in
+ * place (no gather: `frame` is the whole frame, rows == height).  The kernels of a frame are a dependency chain and each ends in a
+ * tail; split, part k+1's camera rays and queue build run under part k's traversal.  Same pixels as rtr_render (tested), stream-ordered
+ * on the frame's context stream like rtr_render_async (fork and join are events); rtr_frame_wait joins, and rtr_frame_get_stats then
+ * gives totalMs = the frame's duration, fork to join, and the counters and per-kernel times SUMMED over the parts (they overlap).
+ * params->shardCount must be 0 or 1.  parts == 1 is rtr_render_async.  What the reference's loop needs — one frame per iteration, then
+ * waitIdle (src/app/application.cppm:352-389,437) — where rtr_render_batch_async trades that latency for throughput. */
+#define RTR_MAX_SPLIT 16
+int  rtr_render_split_async(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo, const rtr_render_params* params,
+                            rtr_frame* frame, uint32_t parts);
+int  rtr_render_split(rtr_scene* scene, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo, const rtr_render_params* params,
+                      rtr_frame* frame, uint32_t parts);
 /* How many frames of these params one launch takes: min(RTR_MAX_BATCH, what the staged pipeline's scratch can address — its
  * visibility slots are 31-bit indices: pixel-sample slots of the launch, rounded up to a power of two, x queries per pixel-sample).
  * 1 when only a single frame fits (or the megakernel is asked for); a caller that batches asks this first.  Pure arithmetic. */

@@ -133,6 +133,8 @@ RTR_SYMBOLS = {
     "rtr_ctx_set_stream": (C.c_int, [VP, VP]),
     "rtr_ctx_get_stream": (C.c_int, [VP, P(VP)]),
     "rtr_ctx_device_name": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
+    "rtr_ctx_set_tunable": (C.c_int, [VP, C.c_char_p, u32]),
+    "rtr_ctx_get_tunable": (C.c_int, [VP, C.c_char_p, P(u32)]),
     "rtr_scene_create": (C.c_int, [VP, P(rtr_scene_desc), P(VP)]),
     "rtr_scene_create_like": (C.c_int, [VP, P(rtr_scene_desc), VP, P(VP)]),
     "rtr_scene_destroy": (None, [VP]),
@@ -155,6 +157,8 @@ RTR_SYMBOLS = {
     "rtr_render_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP]),
     "rtr_render_batch_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), P(VP), u32]),
     "rtr_render_batch_limit": (C.c_int, [VP, P(rtr_render_params), u32, P(u32)]),
+    "rtr_render_split_async": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP, u32]),
+    "rtr_render_split": (C.c_int, [VP, P(RtrCameraData), P(RtrSceneInfo), P(rtr_render_params), VP, u32]),
     "rtr_frame_wait": (C.c_int, [VP]),
     "rtr_deinterleave_bands": (C.c_int, [VP, VP, VP, u32, u32, u32, u32]),
     "rtr_denoise_combine": (C.c_int, [VP, C.c_int]),
@@ -227,6 +231,7 @@ MGPU_MAX_RANKS = 16
 
 
 MAX_BATCH = 32
+MAX_SPLIT = 16
 MGPU_ID_BYTES = 128
 MGPU_MAX_SLOTS = 64
 MGPU_NO_EXCHANGE = 1
@@ -270,18 +275,45 @@ def _bind(path, table, what):
 
 
 _hip = None
+_hip_hooks = None
 _host = None
 _mgpu = None
 LIB_MGPU_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtr_mgpu.so")
+# The same sources built with -DRTR_TEST_HOOKS (csrc/Makefile): the environment switches the tests need — a short overflow list, a
+# forced pre-fill of the visibility array, ranks sharing one device, a one-rank communicator that still exchanges — exist ONLY in these
+# two; the product libraries above do not contain them.
+LIB_HIP_HOOKS_PATH = os.path.join(_HERE, "librtr_hip_test.so")
+LIB_MGPU_HOOKS_PATH = os.path.join(_HERE, "librtr_mgpu_test.so")
+
+
+def test_hooks_requested():
+    """This process wants the multi-GPU library's test build: RTR_TEST_HOOKS=1, or one of the two switches only that build has is set
+    (child processes of the GPU tests, bench.py's one-GPU rehearsal of N ranks)"""
+    e = os.environ
+    return e.get("RTR_TEST_HOOKS") == "1" or e.get("RTR_MGPU_SELF_EXCHANGE") == "1" or e.get("RTR_MGPU_TEST_SHARED_DEVICE") == "1"
 
 
 def mgpu_lib():
-    """librtr_mgpu.so (include/rtr_mgpu.h): the tile-sharded frame over several GPUs, RCCL inside.  Loaded after librtr_hip.so."""
+    """librtr_mgpu.so (include/rtr_mgpu.h): the tile-sharded frame over several GPUs, RCCL inside.  Loaded after librtr_hip.so.
+    With RTR_TEST_HOOKS=1: librtr_mgpu_test.so, the same sources with the test hooks compiled in."""
     global _mgpu
     if _mgpu is None:
         hip_lib()
-        _mgpu = _bind(LIB_MGPU_PATH, MGPU_SYMBOLS, "librtr_mgpu.so")
+        if test_hooks_requested():
+            _mgpu = _bind(LIB_MGPU_HOOKS_PATH, MGPU_SYMBOLS, "librtr_mgpu_test.so")
+        else:
+            _mgpu = _bind(LIB_MGPU_PATH, MGPU_SYMBOLS, "librtr_mgpu.so")
     return _mgpu
+
+
+def hip_lib_with_hooks():
+    """librtr_hip_test.so: librtr_hip.so's sources with -DRTR_TEST_HOOKS, for the few tests that force a rare path (api.Context(...,
+    test_hooks=True)); may live in one process beside the product library."""
+    global _hip_hooks
+    if _hip_hooks is None:
+        hip_lib()
+        _hip_hooks = _bind(LIB_HIP_HOOKS_PATH, RTR_SYMBOLS, "librtr_hip_test.so")
+    return _hip_hooks
 
 
 def hip_lib():

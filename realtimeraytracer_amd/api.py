@@ -22,10 +22,19 @@ def _check(status, what):
 
 
 class Context:
-    def __init__(self, device=0):
-        self.lib = A.hip_lib()
+    def __init__(self, device=0, test_hooks=False):
+        """test_hooks: everything made from this context goes through librtr_hip_test.so (the product's sources + the test switches)"""
+        self.lib = A.hip_lib_with_hooks() if test_hooks else A.hip_lib()
         self.h = A.VP()
         _check(self.lib.rtr_ctx_create(device, C.byref(self.h)), "rtr_ctx_create")
+
+    def set_tunable(self, name, value):
+        _check(self.lib.rtr_ctx_set_tunable(self.h, name.encode(), int(value)), "rtr_ctx_set_tunable")
+
+    def get_tunable(self, name):
+        v = C.c_uint32(0)
+        _check(self.lib.rtr_ctx_get_tunable(self.h, name.encode(), C.byref(v)), "rtr_ctx_get_tunable")
+        return int(v.value)
 
     def set_stream(self, stream_ptr):
         _check(self.lib.rtr_ctx_set_stream(self.h, A.VP(stream_ptr) if stream_ptr else None), "rtr_ctx_set_stream")
@@ -170,6 +179,12 @@ def shard_rows(height, band_rows=8, shard_count=1):
 def render(scene, camera, scene_info, params, frame, asynchronous=False):
     fn = scene.lib.rtr_render_async if asynchronous else scene.lib.rtr_render
     _check(fn(scene.h, C.byref(camera), C.byref(scene_info), C.byref(params), frame.h), "rtr_render")
+
+
+def render_split(scene, camera, scene_info, params, frame, parts, asynchronous=False):
+    """rtr_render_split[_async]: ONE frame as `parts` band-shards on streams of their own, written in place (the latency form)"""
+    fn = scene.lib.rtr_render_split_async if asynchronous else scene.lib.rtr_render_split
+    _check(fn(scene.h, C.byref(camera), C.byref(scene_info), C.byref(params), frame.h, int(parts)), "rtr_render_split")
 
 
 def marshal_batch(cameras, scene_infos, frames):

@@ -401,6 +401,8 @@ struct RenderArgs {
     uint32_t maxRaysPerSample;/* slots per (pixel,sample) in the wavefront visibility array */
     uint32_t images;          /* RTR_IMG_BIT mask */
     uint32_t accumulate, accumulatedFrames;
+    uint32_t directRows;      /* 1: the output images are the FULL frame and this shard writes its rows where they belong (row gy), not into a compact
+                               * (localRows x width) image: the parts of rtr_render_split_async, which share one set of images and need no gather */
 };
 
 /* Canonical pixel order: 8x8 tiles, row-major inside a tile, tiles left->right inside a band of 8
@@ -413,6 +415,11 @@ __device__ __forceinline__ bool pixel_of(const RenderArgs& ra, uint32_t q, uint3
     const uint32_t lb = lrow / ra.bandRows, r = lrow % ra.bandRows;
     gy = (lb * ra.shardCount + ra.shardIndex) * ra.bandRows + r;
     return x < ra.width && lrow < ra.localRows && gy < ra.height;
+}
+
+/* index of pixel (px, local row lrow = global row gy) in the images a launch writes */
+__device__ __forceinline__ size_t out_index(const RenderArgs& ra, uint32_t px, uint32_t lrow, uint32_t gy) {
+    return (size_t)(ra.directRows ? gy : lrow) * ra.width + px;
 }
 
 /* raygen.rgen:83-92 */

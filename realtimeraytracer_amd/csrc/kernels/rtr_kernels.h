@@ -17,8 +17,14 @@ namespace rtrdev {
  * constant: `% kQueueRegions` is an AND in the refill path.  (rtr_ctx reads hipDeviceAttributeNumberOfXccs only to say so in
  * rtr_ctx_device_name; a count that does not divide 8 would merely share cursors, never give a wrong result.) */
 constexpr uint32_t kQueueRegions = 8;
+/* Words of Workspace::queueCount (the control block of a launch, zeroed before it): */
+constexpr uint32_t kQueueLenWord = 0;        /* queued rays */
+constexpr uint32_t kPrimaryRedoWord = 2;     /* camera rays k_primary left to k_primary_tail */
+constexpr uint32_t kOccludedWord = 3;        /* occluded rays of the any-hit launch (the next launch's pre-fill of the visibility array is chosen by it) */
+constexpr uint32_t kBatchCursorWord = 16;    /* first batch cursor; cursor r at kBatchCursorWord + 16 r (64 B apart) */
+static_assert(kOccludedWord < kBatchCursorWord && kPrimaryRedoWord < kOccludedWord, "the small counters sit below the first batch cursor");
 constexpr uint32_t kQueueLists = kQueueRegions * kQueueRegions;        /* batch lists of the binned queue: (direction octant, consumer XCD) */
-constexpr uint32_t kQueueListLens = 16 + 16 * kQueueLists;            /* first word of the list lengths (read-only while the queue drains) */
+constexpr uint32_t kQueueListLens = kBatchCursorWord + 16 * kQueueLists;            /* first word of the list lengths (read-only while the queue drains) */
 constexpr uint32_t kPrimaryCursors = kQueueListLens + kQueueLists;   /* kQueueRegions batch cursors of k_primary_persist, 64 B apart */
 constexpr uint32_t kQueueCtrlWords = kPrimaryCursors + 16 * kQueueRegions;
 static_assert(kQueueLists == 64, "k_shadow_gen_oct reserves the batch lists with one lane per list");
@@ -46,7 +52,8 @@ struct Workspace {
     RayQueue  rayQueue;              /* the queued shadow rays */
     uint8_t*  vis = nullptr;         /* per slot (query-major planes, rayQueue.slotStride apart): 1 = occluded */
     uint32_t  visFill = 1;           /* what the array is pre-filled with before every launch (the commoner outcome); the any-hit kernel stores the other */
-    size_t    visBytes = 0;
+    size_t    visPlaneBytes = 0;     /* what a launch pre-fills and reads of each plane: its pixel-sample slots (a multiple of 256) */
+    uint32_t  visPlanes = 0;         /* queries per pixel-sample = planes in use */
     uint32_t* queueCount = nullptr;  /* kQueueCtrlWords words: [0] queued rays, [1] batch cursor of the counting kernel, [2] k_primary's redo count, [3] occluded rays of the any-hit launch, [16 + 16 r] batch cursor of queue region r (2-wide kernel, r < 8) or of batch list r = octant * 8 + xcd (64 B apart: a cursor is hammered by one XCD's waves), [kQueueListLens + r] length of list r, [kPrimaryCursors + 16 r] batch cursor of region r of the camera rays (k_primary_persist) */
     uint2*    batchLists = nullptr;  /* kQueueLists lists of listStride batches {first queue index, rays}: the queue binned by direction octant */
     uint32_t  listStride = 0;
@@ -58,9 +65,28 @@ struct Workspace {
     size_t    capRays = 0;
 };
 
-/* RTR_TRACE_BVH4=0 (read once per process): the staged pipeline walks the shadow rays with the 2-wide comparison kernel, which has no
- * counting form. */
-bool two_wide_selected();
+/* Run-time tunables of the staged pipeline.  They belong to an rtr_ctx: read from the environment ONCE, when the context is created
+ * (RTR_<NAME IN CAPITALS>, e.g. RTR_TRACE_BINNED=1), settable afterwards with rtr_ctx_set_tunable; a render uses those of its (leading)
+ * frame's context.  The defaults are the swept optima (profiles/sweep_*.sh); every setting renders the same pixels (tested). */
+struct Tunables {
+    uint32_t primary_persist = 0;                 /* camera rays by k_primary_persist: 0 never, 1 whenever it can, 2 by the size of the launch */
+    uint32_t primary_persist_min_rays = 6u << 20;
+    uint32_t primary_batch = 64, primary_refill = 24, primary_inner_min = 20, primary_wgs_per_cu = 8;
+    uint32_t trace_bvh4 = 1;                      /* 0: the 2-wide any-hit kernel on the plain queue (comparison form; it has no counting form) */
+    uint32_t trace_batch = 0;                     /* rays a wave reserves per cursor atomic; 0: by the length of the queue (256 / 512) */
+    uint32_t trace_binned = 2;                    /* queue binned by direction octant: 0 never, 1 always, 2 by queue and tree size */
+    uint32_t queue_nt = 1;                        /* bit 0: the any-hit kernel reads the queue past the caches; bit 1: the queue-build kernel writes it so */
+    uint32_t trace_wgs_per_cu = 0;                /* persistent workgroups per CU; 0: 8 on long queues, 6 on short ones */
+    uint32_t trace_refill = 20, trace_inner_min = 28;
+    uint32_t trace_octant_forms = 1;
+    uint32_t trace_top_nodes = 0xffffffffu;       /* 4-wide records kept in LDS (at most the kernel's kTopNodes) */
+    uint32_t resolve_row_waves = 0;
+    uint32_t gen_oct_stage = 1;                   /* k_shadow_gen_oct: 1 = a wave's records of one emission step leave as whole runs per octant (LDS-staged) */
+};
+Tunables tunables_from_env();
+/* name: a field of Tunables (lower case).  false: no such tunable, or a value outside its range. */
+bool tunable_set(Tunables& t, const char* name, uint32_t value);
+bool tunable_get(const Tunables& t, const char* name, uint32_t* value);
 
 /* stackEntries must be one of 16, 32, 64. */
 hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const FrameOut& fo, int stackEntries,
@@ -69,7 +95,7 @@ hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const 
 /* Staged pipeline: primary trace -> shadow-ray generation (ballot-compacted queue) -> any-hit trace
  * -> resolve.  `ev` (6 events, may be null) are recorded between stages for per-stage timing ([5]: after the any-hit kernel,
  * before k_shadow_tail). */
-hipError_t launch_wavefront(const DeviceScene& sc, const FrameBatch& batch, const Workspace& ws,
+hipError_t launch_wavefront(const DeviceScene& sc, const FrameBatch& batch, const Workspace& ws, const Tunables& tun,
                             int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev, uint32_t numCus);
 
 /* fills DeviceScene::lightTris (4 x float4 per light triangle, light l from first[l]); after create and after light transforms change */

@@ -23,7 +23,9 @@
  */
 #include "rtr_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace rtrdev {
 
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
         trace<false, STATS, kBlock>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
         shade_sample<InlinePolicy<STATS, STACK>, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
-    write_pixel(ra, fo, (size_t)lrow * ra.width + px, acc);
+    write_pixel(ra, fo, out_index(ra, px, lrow, py), acc);
     if (STATS) st.flush(stats);
 }
 
@@ -443,7 +445,6 @@ constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first
  * a longer tail with it, 2.65 instead of 2.53 ms; profiles/r03/sweep_batch_r03_4.log, bench_*_r03_5.log) */
 constexpr uint32_t kBatchDefault = 256, kBatchLong = 512;
 constexpr size_t kBatchLongQueue = (size_t)100 << 20;
-constexpr uint32_t kRefillDefault = 20;    /* idle lanes that trigger a refill (re-swept for the 4-wide kernel: profiles/r01/sweep_trace_wide.log) */
 
 /* Stack policy of the persistent kernels.  Ordered traversal rarely holds more than ~10 entries, so every lane gets 16 LDS
  * entries (16 KiB per workgroup -> 8 workgroups = 32 waves per CU, the hardware maximum).  The rare ray that needs a 17th entry is
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_trace(DeviceScene sc, const R
     }
     /* how many of this launch's rays were occluded: the host picks the next frame's pre-fill of the visibility array by it */
     const uint32_t occWave = wave_sum_u32(occ);
-    if ((threadIdx.x & 63u) == 0 && occWave) atomicAdd(nextBatch - 13, occWave);      /* = queueCount[3] */
+    if ((threadIdx.x & 63u) == 0 && occWave) atomicAdd(nextBatch - kBatchCursorWord + kOccludedWord, occWave);      /* nextBatch = the control block + kBatchCursorWord (the launcher's expression) */
 }
 
 /* The inner-node loop of k_shadow_trace4, compiled per direction octant (OCT 0..7; 8 = any signs, see slab_oct). */
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
      * into — octants get workgroups in proportion to their batches — and there on the list of its own XCD, then takes the other
      * XCDs' lists of that octant, then the next octant: the rays in a wave share their direction signs except around such a move.
      * (With one list per octant, shared by all XCDs, the same kernel took 3.8 ms instead of 1.9.) */
-    const uint32_t* __restrict__ lens = nextBatch - 16 + kQueueListLens;
+    const uint32_t* __restrict__ lens = nextBatch - kBatchCursorWord + kQueueListLens;
     const uint32_t n = LISTS ? 0u : *count;
     const uint32_t regionLen = ((n + kQueueRegions - 1) / kQueueRegions + kBatch - 1) / kBatch * kBatch;
     const uint32_t myXcd = blockIdx.x % kQueueRegions;
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
     }
     {   /* how many of this launch's rays were occluded: the host picks the next frame's pre-fill of the visibility array by it */
         const uint32_t occWave = wave_sum_u32(occ);
-        if ((threadIdx.x & 63u) == 0 && occWave) atomicAdd(nextBatch - 13, occWave);      /* = queueCount[3] */
+        if ((threadIdx.x & 63u) == 0 && occWave) atomicAdd(nextBatch - kBatchCursorWord + kOccludedWord, occWave);      /* nextBatch = the control block + kBatchCursorWord (the launcher's expression) */
     }
     if (stamp || STATS) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -1170,7 +1171,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, FrameBatch f
         LookupPolicy pol{vis, (uint32_t)k, slotStride};
         shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
-    write_pixel(ra, fo, (size_t)lrow * ra.width + px, acc);
+    write_pixel(ra, fo, out_index(ra, px, lrow, py), acc);
     if (STATS) st.flush(stats);
 }
 
@@ -1197,17 +1198,50 @@ __global__ __launch_bounds__(64) void k_light_tris(const RtrAreaLightInfo* __res
     for (uint32_t ti = 0; ti < L->numTriangles; ++ti) light_tri_record(L, vertices, indices, ti, out + (size_t)(first[l] + ti) * kLightTriRecord);
 }
 
-/* ---- launchers ------------------------------------------------------------------------------- */
-static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    unsigned long x = strtoul(v, nullptr, 10);
-    return x < lo ? lo : (x > hi ? hi : (uint32_t)x);
+/* Pre-fill of the visibility array: the first planeVec 16-B words of each plane (blockIdx.y), pitchVec words apart. */
+__global__ __launch_bounds__(kBlock) void k_fill_planes(uint4* __restrict__ vis, uint32_t word, uint32_t planeVec, uint32_t pitchVec) {
+    const uint4 v = make_uint4(word, word, word, word);
+    uint4* plane = vis + (size_t)blockIdx.y * pitchVec;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < planeVec; i += gridDim.x * kBlock) plane[i] = v;
 }
 
-bool two_wide_selected() {
-    static const bool v = env_u32("RTR_TRACE_BVH4", 1u, 0u, 1u) == 0u;
-    return v;
+/* ---- launchers ------------------------------------------------------------------------------- */
+namespace {
+struct TunableField { const char* name; uint32_t Tunables::* field; uint32_t lo, hi; };
+const TunableField kTunables[] = {
+    {"primary_persist", &Tunables::primary_persist, 0u, 2u}, {"primary_persist_min_rays", &Tunables::primary_persist_min_rays, 0u, 0xffffffffu},
+    {"primary_batch", &Tunables::primary_batch, 64u, 1u << 16}, {"primary_refill", &Tunables::primary_refill, 1u, 64u},
+    {"primary_inner_min", &Tunables::primary_inner_min, 0u, 63u}, {"primary_wgs_per_cu", &Tunables::primary_wgs_per_cu, 1u, 8u},
+    {"trace_bvh4", &Tunables::trace_bvh4, 0u, 1u}, {"trace_batch", &Tunables::trace_batch, 0u, 1u << 20}, {"trace_binned", &Tunables::trace_binned, 0u, 2u},
+    {"queue_nt", &Tunables::queue_nt, 0u, 3u}, {"trace_wgs_per_cu", &Tunables::trace_wgs_per_cu, 0u, 8u}, {"trace_refill", &Tunables::trace_refill, 1u, 64u},
+    {"trace_inner_min", &Tunables::trace_inner_min, 0u, 63u}, {"trace_octant_forms", &Tunables::trace_octant_forms, 0u, 1u},
+    {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u},
+    {"gen_oct_stage", &Tunables::gen_oct_stage, 0u, 1u},
+};
+}  // namespace
+
+bool tunable_set(Tunables& t, const char* name, uint32_t value) {
+    for (const TunableField& f : kTunables)
+        if (name && !strcmp(name, f.name)) { if (value < f.lo || value > f.hi) return false; t.*(f.field) = value; return true; }
+    return false;
+}
+bool tunable_get(const Tunables& t, const char* name, uint32_t* value) {
+    for (const TunableField& f : kTunables) if (name && !strcmp(name, f.name)) { if (value) *value = t.*(f.field); return true; }
+    return false;
+}
+/* RTR_TRACE_BINNED=1 and friends: the field's name in capitals behind RTR_; out-of-range values are clamped, as they always were */
+Tunables tunables_from_env() {
+    Tunables t;
+    for (const TunableField& f : kTunables) {
+        char env[64] = "RTR_"; size_t n = 4;
+        for (const char* c = f.name; *c && n + 1 < sizeof env; ++c) env[n++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        env[n] = 0;
+        const char* v = getenv(env);
+        if (!v || !*v) continue;
+        const unsigned long x = strtoul(v, nullptr, 10);
+        t.*(f.field) = x < f.lo ? f.lo : (x > f.hi ? f.hi : (uint32_t)x);
+    }
+    return t;
 }
 
 static uint32_t padded_pixels(const RenderArgs& ra) {
@@ -1234,7 +1268,7 @@ hipError_t launch_megakernel(const DeviceScene& sc, const RenderArgs& ra, const 
 }
 
 template <int STACK>
-static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Workspace& ws,
+static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Workspace& ws, const Tunables& tun,
                          Counters* stats, hipStream_t s, hipEvent_t* ev, uint32_t numCus) {
     const RenderArgs& ra = fb.ra[0];                   /* extent, spp, sharding: the same for every frame of the batch */
     const uint32_t nb = fb.n;
@@ -1245,19 +1279,22 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     /* the visibility array starts as "every ray had the commoner outcome" (the frame object's last launch says which: three shadow
      * rays in four of the bench frame are occluded); the any-hit kernel stores only the other outcome — whole-line fill traffic
      * instead of most of its scattered byte stores (WRITE_SIZE of the launch 136 -> 34 MB + 27 MB of fill) */
-    if ((e = hipMemsetAsync(ws.vis, (int)ws.visFill, ws.visBytes, s)) != hipSuccess) return e;
+    {   /* only the bytes the launch uses: its pixel-sample slots at the start of each plane, not the power-of-two pitch between the planes
+         * (a 20-frame 1080p launch: 539 MB instead of 872) */
+        const uint32_t planeVec = (uint32_t)(ws.visPlaneBytes / 16u), pitchVec = ws.rayQueue.slotStride / 16u;
+        uint32_t fblocks = std::min<uint32_t>((planeVec + kBlock - 1) / kBlock, std::max<uint32_t>(4096u / std::max<uint32_t>(ws.visPlanes, 1u), 64u));
+        if (fblocks == 0) fblocks = 1;
+        hipLaunchKernelGGL(k_fill_planes, dim3(fblocks, ws.visPlanes ? ws.visPlanes : 1u), dim3(kBlock), 0, s, reinterpret_cast<uint4*>(ws.vis), ws.visFill * 0x01010101u, planeVec, pitchVec);
+    }
     if (ev) hipEventRecord(ev[0], s);
     /* the storage of ws.overflow is used twice per frame: first as k_primary's redo list (count in queueCount[2], consumed by
      * k_primary_tail), then as the any-hit kernel's overflow list (count in overflow[0]) */
     /* camera rays: the persistent kernel (k_primary_persist), or one ray per lane (k_primary; RTR_PRIMARY_PERSIST=0, for comparison).
      * Both walk the BVH2 and leave the rays that outgrow their 16-entry LDS stack to k_primary_tail; the counting form takes the
      * same path as the timed one. */
-    static const uint32_t kPersist = env_u32("RTR_PRIMARY_PERSIST", 0u, 0u, 2u);          /* 0 never (default), 1 whenever it can, 2 by the size of the launch */
-    static const uint32_t kPersistMinRays = env_u32("RTR_PRIMARY_PERSIST_MIN_RAYS", 6u << 20, 0u, 0xffffffffu);
-    static const uint32_t kPBatch = env_u32("RTR_PRIMARY_BATCH", 64u, 64u, 1u << 16);
-    static const uint32_t kPRefill = env_u32("RTR_PRIMARY_REFILL", 24u, 1u, 64u);
-    static const uint32_t kPInnerMin = env_u32("RTR_PRIMARY_INNER_MIN", 20u, 0u, 63u);
-    static const uint32_t kPWgsPerCu = env_u32("RTR_PRIMARY_WGS_PER_CU", 8u, 1u, 8u);
+    const uint32_t kPersist = tun.primary_persist;          /* 0 never (default), 1 whenever it can, 2 by the size of the launch */
+    const uint32_t kPersistMinRays = tun.primary_persist_min_rays;
+    const uint32_t kPBatch = tun.primary_batch, kPRefill = tun.primary_refill, kPInnerMin = tun.primary_inner_min, kPWgsPerCu = tun.primary_wgs_per_cu;
     const uint32_t planeStride = blocks * kBlock;
     /* Round 2 measured the persistent kernel faster alone from 8 M camera rays (0.58 against 0.89 ms at 1080p x 4 spp); since k_primary
      * takes one lane per (sample, pixel) it is the other way round at every size (0.77 against 0.98 ms; whole frames 3-9 % slower with
@@ -1268,17 +1305,17 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
         if (pblocks > pneeded) pblocks = pneeded;
         if (pblocks == 0) pblocks = 1;
-        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
-        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
-    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, blocks);
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + 2, ws.overflow + 1, blocks);
-    if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
-    else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + 2, ws.overflow + 1, ws.spill, planeStride, stats);
+        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+    if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+    else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
-    static const uint32_t kBatchEnv = env_u32("RTR_TRACE_BATCH", 0u, 0u, 1u << 20);        /* 0 (default): by the length of the queue */
+    const uint32_t kBatchEnv = tun.trace_batch;        /* 0 (default): by the length of the queue */
     const uint32_t kBatch = kBatchEnv >= 64u ? kBatchEnv : ((size_t)nb * blocks * kBlock * ra.spp * ra.maxRaysPerSample >= kBatchLongQueue ? kBatchLong : kBatchDefault);
-    static const uint32_t kWide = two_wide_selected() ? 0u : 1u;   /* RTR_TRACE_BVH4=0: the 2-wide any-hit kernel on the plain queue (same results, for comparison; it has no counting form: rtr_render refuses collectStats with it) */
+    const uint32_t kWide = tun.trace_bvh4;   /* trace_bvh4 = 0: the 2-wide any-hit kernel on the plain queue (same results, for comparison; it has no counting form: rtr_render refuses collectStats with it) */
     const uint32_t genBlocks = (nb * blocks * kBlock + kGenBlock - 1) / kGenBlock, genOctBlocks = (nb * blocks * kBlock + kGenOctBlock - 1) / kGenOctBlock;
     /* Queue binned by direction octant + per-(octant, XCD) batch lists (k_shadow_gen_oct -> k_shadow_trace4), or the plain queue
      * (k_shadow_gen -> k_shadow_trace4 over eight regions of it).  Binning pays on long queues (+2 % frame rate at 12-25 M rays:
@@ -1286,14 +1323,13 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
      * drain unevenly: -2 % at 3-6 M rays), hence the thresholds (kBinnedMinRays, kBinnedMinNodes); RTR_TRACE_BINNED=0/1 forces it off/on (the tests run both).
      * The 16-bit per-lane counters of the binned count hold any realistic ray count per pixel.  The counting form (stats) takes
      * the same path as the timed one: same queue, same kernel template. */
-    const char* binEnv = getenv("RTR_TRACE_BINNED");
-    const uint32_t binMode = (binEnv && (binEnv[0] == '0' || binEnv[0] == '1') && !binEnv[1]) ? (uint32_t)(binEnv[0] - '0') : 2u;
+    const uint32_t binMode = tun.trace_binned;
     const size_t maxRaysQ = (size_t)nb * blocks * kBlock * ra.spp * ra.maxRaysPerSample;
     const bool wide = kWide && sc.nodes4;
     const bool binned = wide && ws.batchLists && (size_t)ra.spp * ra.maxRaysPerSample <= 65535u &&
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
                         (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
-    static const uint32_t kNtQueue = env_u32("RTR_QUEUE_NT", 1u, 0u, 3u);          /* bit 0: any-hit kernel reads the queue past the caches (default); bit 1: the queue-build kernel writes it so (slower, see queue_load) */
+    const uint32_t kNtQueue = tun.queue_nt;          /* bit 0: any-hit kernel reads the queue past the caches (default); bit 1: the queue-build kernel writes it so (slower, see queue_load) */
     if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
     else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
@@ -1305,34 +1341,33 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
      * wave has retired) matter more: with 6 per CU one rank of 8 renders a frame in 0.394 instead of 0.418 ms and one rank of 4 in
      * 0.693 instead of 0.708 (4 frames in flight, profiles/r01/sweep_wgs_per_cu.log); at N = 1, 2 it makes no difference.
      * numCus comes from hipDeviceProp_t::multiProcessorCount (256 on an MI355X in SPX mode). */
-    static const uint32_t kWgsPerCu = env_u32("RTR_TRACE_WGS_PER_CU", 0u, 0u, 8u);
+    const uint32_t kWgsPerCu = tun.trace_wgs_per_cu;
     uint32_t tblocks = numCus * (kWgsPerCu ? kWgsPerCu : (maxRays >= kBinnedMinRays ? 8u : 6u));
     const uint32_t needed = (uint32_t)((maxRays + kBlock - 1) / kBlock);
     if (tblocks > needed) tblocks = needed;
     if (tblocks == 0) tblocks = 1;
-    static const uint32_t kRefill = env_u32("RTR_TRACE_REFILL", kRefillDefault, 1u, 64u);
-    static const uint32_t kInnerMin = env_u32("RTR_TRACE_INNER_MIN", 28u, 0u, 63u);
+    const uint32_t kRefill = tun.trace_refill, kInnerMin = tun.trace_inner_min;
     (void)sizeof(STACK);   /* the BVH-depth bound only sizes the spill area; the LDS part is always 16 entries */
-    static const uint32_t kOct = env_u32("RTR_TRACE_OCTANT_FORMS", 1u, 0u, 1u) | ((kNtQueue & 1u) << 1);        /* bit 0: octant forms of the node loop; bit 1: the queue is read past the caches */
-    static const uint32_t kTop = env_u32("RTR_TRACE_TOP_NODES", kTopNodes, 0u, kTopNodes);
+    const uint32_t kOct = tun.trace_octant_forms | ((kNtQueue & 1u) << 1);        /* bit 0: octant forms of the node loop; bit 1: the queue is read past the caches */
+    const uint32_t kTop = tun.trace_top_nodes < kTopNodes ? tun.trace_top_nodes : kTopNodes;
     const uint32_t top = kTop < sc.numNodes4 ? kTop : sc.numNodes4;
     /* the 4-wide kernel's workgroups are kTraceBlock lanes: the same number of waves in fewer workgroups */
     uint32_t tblocks4 = tblocks * (uint32_t)kBlock / (uint32_t)kTraceBlock;
     if (tblocks4 == 0) tblocks4 = 1;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
-    } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + 16, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap);
+    } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap);
     if (ev) hipEventRecord(ev[5], s);
     if (stats) hipLaunchKernelGGL((k_shadow_tail<true>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.overflowCap, ws.queueCount, ws.vis, ws.spill, stats);
     else hipLaunchKernelGGL((k_shadow_tail<false>), dim3(kTailBlocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.overflow, ws.overflowCap, ws.queueCount, ws.vis, ws.spill, stats);
     if (ev) hipEventRecord(ev[3], s);
-    static const uint32_t kRowWaves = env_u32("RTR_RESOLVE_ROW_WAVES", 0u, 0u, 1u);
+    const uint32_t kRowWaves = tun.resolve_row_waves;
     const uint32_t rowWaves = (kRowWaves && ra.tilesPerRow % 8u == 0u && blocks % 2u == 0u) ? 1u : 0u;
     if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
@@ -1340,14 +1375,14 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     return hipGetLastError();
 }
 
-hipError_t launch_wavefront(const DeviceScene& sc, const FrameBatch& fb, const Workspace& ws,
+hipError_t launch_wavefront(const DeviceScene& sc, const FrameBatch& fb, const Workspace& ws, const Tunables& tun,
                             int stackEntries, Counters* stats, hipStream_t stream, hipEvent_t* ev, uint32_t numCus) {
     if (numCus == 0) numCus = 256;
     if (fb.n < 1 || fb.n > kMaxBatch) return hipErrorInvalidValue;
     switch (stackEntries) {
-        case 16: return wave_t<16>(sc, fb, ws, stats, stream, ev, numCus);
-        case 32: return wave_t<32>(sc, fb, ws, stats, stream, ev, numCus);
-        case 64: return wave_t<64>(sc, fb, ws, stats, stream, ev, numCus);
+        case 16: return wave_t<16>(sc, fb, ws, tun, stats, stream, ev, numCus);
+        case 32: return wave_t<32>(sc, fb, ws, tun, stats, stream, ev, numCus);
+        case 64: return wave_t<64>(sc, fb, ws, tun, stats, stream, ev, numCus);
         default: return hipErrorInvalidValue;
     }
 }

@@ -364,8 +364,10 @@ int check_slots(int framesInFlight) {
 }
 
 void read_env(rtr_mgpu* m) {
+#ifdef RTR_TEST_HOOKS      /* librtr_mgpu_test.so only: a one-rank communicator still sends its shard to itself through RCCL */
     const char* se = getenv("RTR_MGPU_SELF_EXCHANGE");
     m->selfExchange = se && se[0] == '1';
+#endif
     if (const char* t = getenv("RTR_MGPU_TIMEOUT_MS")) m->timeoutMs = (uint32_t)strtoul(t, nullptr, 10);
 }
 
@@ -433,10 +435,13 @@ int rtr_mgpu_create(const int* devices, int n, int framesInFlight, rtr_mgpu** ou
     if (n > RTR_MGPU_MAX_RANKS) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, at most %d ranks", n, RTR_MGPU_MAX_RANKS);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RTR_ERR_NO_DEVICE, "rtr_mgpu_create: no HIP device; this library has no CPU fallback");
-    /* test hook: ranks may share a device (RCCL itself refuses that; tests/fake_rccl/ stands in for it on a one-GPU box so that the
-     * N > 1 code of this file runs there) */
+#ifdef RTR_TEST_HOOKS      /* librtr_mgpu_test.so only: ranks may share a device (RCCL itself refuses that; tests/fake_rccl/ stands in for it on a
+                            * one-GPU box so that the N > 1 code of this file runs there) */
     const char* shared = getenv("RTR_MGPU_TEST_SHARED_DEVICE");
     const bool sharedOk = shared && shared[0] == '1' && !shared[1];
+#else
+    const bool sharedOk = false;
+#endif
     if (n > count && !sharedOk) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: %d devices requested, %d present", n, count);
     for (int i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= count) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_create: device %d not in [0,%d)", devices[i], count);

@@ -78,6 +78,7 @@ struct rtr_ctx {
      * unusable, until the last child is gone (garbage-collected bindings destroy objects in any order) */
     int children = 0;
     bool destroyed = false;
+    rtrdev::Tunables tun;                /* run-time tunables of the staged pipeline: environment at creation, rtr_ctx_set_tunable afterwards */
 };
 
 static void ctx_free(rtr_ctx* c) {
@@ -166,7 +167,17 @@ struct rtr_frame {
     hipStream_t batchStream = nullptr;
     bool ownPending = false;
     hipEvent_t evOwn = nullptr;
+    /* rtr_render_split_async: the frame as band-shards ("parts") on streams of their own.  A part is an internal frame object — its
+     * own scratch, events, counters and context (= stream) — that owns no image: it is bound to THIS frame's images and writes its
+     * rows where they belong (RenderArgs::directRows) */
+    std::vector<rtr_ctx*> partCtx;
+    std::vector<rtr_frame*> parts;
+    std::vector<hipEvent_t> evPart;      /* part k's launches are done (recorded on its stream, waited for by this frame's) */
+    hipEvent_t evSplit[2] = {nullptr, nullptr};     /* on this frame's stream: the fork, and behind the join — the split render's duration */
+    uint32_t pendingSplit = 0;           /* parts of the split render in flight (0: the last render was not split) */
+    float4* extHdr = nullptr;            /* a part: the HDR image of the frame it belongs to */
     uint32_t* image_ptr(int which) const { return ext[which] ? ext[which] : img[which].p; }
+    float4* hdr_ptr() const { return extHdr ? extHdr : hdr.p; }
 };
 
 extern "C" {
@@ -218,7 +229,20 @@ int rtr_ctx_create(int ordinal, rtr_ctx** out) {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->ownStream = true;
+    c->tun = rtrdev::tunables_from_env();
     *out = c;
+    return RTR_OK;
+}
+
+int rtr_ctx_set_tunable(rtr_ctx* c, const char* name, uint32_t value) {
+    if (!c || !name) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_set_tunable: null argument");
+    if (!rtrdev::tunable_set(c->tun, name, value)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_set_tunable: no tunable '%s', or %u is outside its range", name, value);
+    return RTR_OK;
+}
+
+int rtr_ctx_get_tunable(const rtr_ctx* c, const char* name, uint32_t* value) {
+    if (!c || !name || !value) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_get_tunable: null argument");
+    if (!rtrdev::tunable_get(c->tun, name, value)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_get_tunable: no tunable '%s'", name);
     return RTR_OK;
 }
 
@@ -810,7 +834,14 @@ int rtr_check_scene_limits(uint64_t numTriangles, uint64_t numNodes) {
 }
 
 /* ---- frame -------------------------------------------------------------------------------- */
+static int frame_new(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t images, bool ownImages, rtr_frame** out);
+
 int rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t images, rtr_frame** out) {
+    return frame_new(ctx, width, rows, images, true, out);
+}
+
+/* ownImages == false: a part of a split render (no images of its own, see rtr_frame::parts) */
+static int frame_new(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t images, bool ownImages, rtr_frame** out) {
     if (!ctx || !out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: null ctx/out");
     if (ctx->destroyed) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_create: the context has been destroyed");
     *out = nullptr;
@@ -823,9 +854,9 @@ int rtr_frame_create(rtr_ctx* ctx, uint32_t width, uint32_t rows, uint32_t image
     f->ctx = ctx; ++ctx->children; f->width = width; f->rows = rows; f->images = images;
     const size_t px = (size_t)width * rows;
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 8 && e == hipSuccess; ++i)
+    for (int i = 0; i < 8 && e == hipSuccess && ownImages; ++i)
         if (images & RTR_IMG_BIT(i)) { e = f->img[i].alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->img[i].p, 0, px * 4, ctx->stream); }
-    if (e == hipSuccess && (images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { e = f->hdr.alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->hdr.p, 0, px * 16, ctx->stream); }
+    if (e == hipSuccess && ownImages && (images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { e = f->hdr.alloc(px); if (e == hipSuccess) e = hipMemsetAsync(f->hdr.p, 0, px * 16, ctx->stream); }
     if (e == hipSuccess) e = f->counters.alloc(1);
     for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&f->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&f->evMega[i]);
@@ -843,6 +874,10 @@ void rtr_frame_destroy(rtr_frame* f) {
     for (auto& e : f->evMega) if (e) (void)hipEventDestroy(e);
     if (f->evDone) { (void)hipEventSynchronize(f->evDone); (void)hipEventDestroy(f->evDone); }
     if (f->evOwn) (void)hipEventDestroy(f->evOwn);
+    for (rtr_frame* part : f->parts) rtr_frame_destroy(part);
+    for (rtr_ctx* pc : f->partCtx) rtr_ctx_destroy(pc);
+    for (auto& e : f->evPart) if (e) (void)hipEventDestroy(e);
+    for (auto& e : f->evSplit) if (e) (void)hipEventDestroy(e);
     rtr_ctx* c = f->ctx;
     delete f;
     ctx_release_child(c);
@@ -881,9 +916,21 @@ int rtr_frame_download(const rtr_frame* f, int which, void* dst, size_t bytes) {
     return RTR_OK;
 }
 
+/* Work about to be enqueued for `f` on its own stream comes behind a batch launch on another stream that wrote it last (the launch
+ * runs on its leading frame's stream), and a later batch must come behind this work (ownPending): the ordering contract of
+ * rtr_render_batch_async for everything that is not itself a render */
+static int order_on_own_stream(rtr_frame* f) {
+    hipStream_t st = f->ctx->stream;
+    if (f->batchStream && f->batchStream != st) HIP_TRY(hipStreamWaitEvent(st, f->evDone, 0));
+    f->batchStream = nullptr;
+    f->ownPending = true;
+    return RTR_OK;
+}
+
 int rtr_frame_clear(rtr_frame* f) {
     if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_clear: null frame");
     HIP_TRY(hipSetDevice(f->ctx->device));
+    { const int rc = order_on_own_stream(f); if (rc != RTR_OK) return rc; }
     const size_t px = (size_t)f->width * f->rows;
     for (int i = 0; i < 8; ++i) if (f->image_ptr(i)) HIP_TRY(hipMemsetAsync(f->image_ptr(i), 0, px * 4, f->ctx->stream));
     if (f->hdr.p) HIP_TRY(hipMemsetAsync(f->hdr.p, 0, px * 16, f->ctx->stream));
@@ -895,7 +942,7 @@ int rtr_frame_clear(rtr_frame* f) {
 /* Enqueues one launch of the pipeline over n frames (n = 1: rtr_render / rtr_render_async).  frames[0] leads: its context's stream
  * carries the work, its scratch holds the batch, its statistics describe the launch. */
 static_assert(RTR_MAX_BATCH == rtrdev::kMaxBatch, "include/rtr.h and kernels/rtr_device.h disagree on the frames per launch");
-static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrSceneInfo* infos, const rtr_render_params* pin, rtr_frame* const* frames, uint32_t n) {
+static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrSceneInfo* infos, const rtr_render_params* pin, rtr_frame* const* frames, uint32_t n, bool direct = false) {
     if (!s || !cams || !infos || !pin || !frames || n < 1 || !frames[0]) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: null argument");
     if (n > rtrdev::kMaxBatch) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: %u frames, at most %u per launch", n, rtrdev::kMaxBatch);
     rtr_frame* f = frames[0];
@@ -911,6 +958,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
     if (p.bandRows % 8u) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: bandRows %u must be a multiple of 8 (one wave = one 8x8 tile)", p.bandRows);
     if (p.shardIndex >= p.shardCount) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: shardIndex %u >= shardCount %u", p.shardIndex, p.shardCount);
     const uint32_t rows = rtr_shard_rows(p.height, p.bandRows, p.shardCount);
+    const uint32_t frameRows = direct ? p.height : rows;     /* direct: the images are the whole frame, this shard writes its own rows of them */
     if (p.images & RTR_IMAGES_DENOISE) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: denoise/combine images are produced by rtr_denoise_combine, not by the ray-gen dispatch");
     if ((p.images & RTR_IMG_BIT(RTR_IMAGE_ANALYTIC)) && !s->hasLtc) return fail(RTR_ERR_UNSUPPORTED, "rtr_render: RTR_IMAGE_ANALYTIC needs the LTC tables (rtr_scene_desc.ltc1/ltc2)");
     const bool wantHdr = (p.images & RTR_IMG_BIT(RTR_IMAGE_HDR)) != 0 || p.accumulate;
@@ -927,8 +975,8 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
         if (fr->ctx->device != f->ctx->device) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: frame %u lives on another device", b);
         if (infos[b].numAreaLights > s->numLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: SceneInfo.numAreaLights %u > scene lights %u", infos[b].numAreaLights, s->numLights);
         if (infos[b].numAreaLights != infos[0].numAreaLights) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_batch_async: the frames of a launch must use the same number of area lights");
-        if (fr->width != p.width || fr->rows != rows) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame is %ux%u, this shard needs %ux%u", fr->width, fr->rows, p.width, rows);
-        if (wantHdr && !fr->hdr.p) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: HDR accumulation requested but the frame has no RTR_IMAGE_HDR");
+        if (fr->width != p.width || fr->rows != frameRows) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: frame is %ux%u, this shard needs %ux%u", fr->width, fr->rows, p.width, frameRows);
+        if (wantHdr && !fr->hdr_ptr()) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render: HDR accumulation requested but the frame has no RTR_IMAGE_HDR");
         FrameOut& fo = fb.fo[b];
         k = 0;
         for (int i = 0; i < 8; ++i) {
@@ -938,13 +986,13 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
                 fo.img[i] = fr->image_ptr(i); ++k;
             }
         }
-        fo.hdr = wantHdr ? fr->hdr.p : nullptr;
+        fo.hdr = wantHdr ? fr->hdr_ptr() : nullptr;
         RenderArgs& ra = fb.ra[b];
         ra.cam = cams[b]; ra.info = infos[b];
         ra.width = p.width; ra.height = p.height; ra.spp = p.spp; ra.numShadowRays = p.numShadowRays;
         ra.bandRows = p.bandRows; ra.shardIndex = p.shardIndex; ra.shardCount = p.shardCount;
         ra.localRows = rows; ra.tilesPerRow = (p.width + 7u) / 8u;
-        ra.images = p.images; ra.accumulate = p.accumulate; ra.accumulatedFrames = p.accumulatedFrames;
+        ra.images = p.images; ra.accumulate = p.accumulate; ra.accumulatedFrames = p.accumulatedFrames; ra.directRows = direct ? 1u : 0u;
         if (b == 0) for (uint32_t l = 0; l < infos[0].numAreaLights; ++l) maxRays += (uint64_t)s->hostLights[l].numTriangles * p.numShadowRays;
         ra.maxRaysPerSample = (uint32_t)maxRays;
     }
@@ -972,13 +1020,13 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
 
     /* the counting form IS the timed kernel template; the 2-wide comparison kernel has none, and counting another kernel's work
      * under its name would be a wrong number */
-    if (wave && p.collectStats && rtrdev::two_wide_selected())
-        return fail(RTR_ERR_UNSUPPORTED, "rtr_render: collectStats with RTR_TRACE_BVH4=0: the 2-wide comparison kernel has no counting form (unset the variable, or render with pipeline 1)");
+    if (wave && p.collectStats && f->ctx->tun.trace_bvh4 == 0u)
+        return fail(RTR_ERR_UNSUPPORTED, "rtr_render: collectStats with the tunable trace_bvh4 = 0: the 2-wide comparison kernel has no counting form (set it back to 1, or render with pipeline 1)");
     f->pendingWave = wave; f->pendingCounters = p.collectStats != 0;
     f->pendingImagesK = k; f->pendingHdr = wantHdr; f->pendingAccum = p.accumulate != 0;
     memset(&f->stats, 0, sizeof f->stats);
     f->stats.localRows = rows; f->stats.localPixels = rows * p.width * n;
-    f->viaBatch = false;
+    f->viaBatch = false; f->pendingSplit = 0;
     /* The launch runs on THIS frame's stream.  What another stream still holds for one of its frames comes first: a launch the frame
      * led on its own stream (ownPending), or a batch on a third stream that wrote it (batchStream).  In steady state — the same
      * frames batched behind the same leader, or frames joined between uses — neither is set and nothing is enqueued here (cross-stream
@@ -1000,26 +1048,34 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
          * gets 1/16 of the queue (at least 2^20 entries) and k_shadow_tail redoes the whole queue should that ever overflow */
         uint64_t ovCap = std::max<uint64_t>(std::max<uint64_t>(nPS, nRays / 16), 1ull << 20);
         if (ovCap > nRays) ovCap = std::max<uint64_t>(nRays, nPS);
-        uint64_t ovUse = ovCap;                 /* what the any-hit kernel may use of it */
-        if (const char* e = getenv("RTR_TRACE_OVERFLOW_CAP")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v < ovCap) ovUse = v; }   /* test hook: a list short enough to overflow */
         if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); HIP_TRY(f->rayOrigin.alloc(nPS)); }
         if (f->vis.n < nSlots) HIP_TRY(f->vis.alloc(nSlots));
-        if (f->rayDT.n < nRays) { HIP_TRY(f->rayDT.alloc(nRays)); HIP_TRY(f->raySlot.alloc(nRays)); HIP_TRY(f->overflow.alloc(ovCap + 1)); f->overflowCap = (uint32_t)ovUse;
-            /* batch lists of the binned queue (octant x consumer XCD): a run's batches are dealt round-robin to the eight lists of
+        if (f->rayDT.n < nRays) { HIP_TRY(f->rayDT.alloc(nRays)); HIP_TRY(f->raySlot.alloc(nRays)); }
+        /* every array is (re)sized by its OWN need: the redo list is also k_primary's (one entry per pixel-sample at most), and a
+         * launch with fewer queries per sample but more samples than an earlier one needs a longer list with a shorter queue */
+        if (f->overflow.n < ovCap + 1) HIP_TRY(f->overflow.alloc(ovCap + 1));
+        f->overflowCap = (uint32_t)std::min<uint64_t>(ovCap, f->overflow.n - 1);      /* what the any-hit kernel may use of it */
+#ifdef RTR_TEST_HOOKS
+        if (const char* e = getenv("RTR_TRACE_OVERFLOW_CAP")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v < f->overflowCap) f->overflowCap = (uint32_t)v; }   /* a list short enough to overflow */
+#endif
+        {   /* batch lists of the binned queue (octant x consumer XCD): a run's batches are dealt round-robin to the eight lists of
              * its octant, so a list holds at most 1/8 of one batch per 64 rays (the smallest batch) + one per k_shadow_gen_oct workgroup */
-            f->listStride = (uint32_t)(nRays / 64 / rtrdev::kQueueRegions + nPS / 256 + 16);
-            HIP_TRY(f->batchLists.alloc((size_t)f->listStride * rtrdev::kQueueLists)); }
-        else if (getenv("RTR_TRACE_OVERFLOW_CAP")) f->overflowCap = (uint32_t)std::min<uint64_t>(ovUse, f->overflow.n - 1);
+            const uint64_t ls = nRays / 64 / rtrdev::kQueueRegions + nPS / 256 + 16;
+            if ((uint64_t)f->listStride < ls) { HIP_TRY(f->batchLists.alloc((size_t)ls * rtrdev::kQueueLists)); f->listStride = (uint32_t)ls; }
+        }
         f->slotStride = (uint32_t)slotStride;
         if (!f->queueCount.p) HIP_TRY(f->queueCount.alloc(rtrdev::kQueueCtrlWords));
         if (!f->clk.p) { HIP_TRY(f->clk.alloc(2 * rtrdev::kQueueRegions)); HIP_TRY(hipMemsetAsync(f->clk.p, 0, 2 * rtrdev::kQueueRegions * sizeof(unsigned long long), st)); }
         if (!f->spill.p) HIP_TRY(f->spill.alloc(rtrdev::kSpillInts));      /* 64 entries x the redo kernels' grid */
         Workspace ws;
-        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.vis = f->vis.p; ws.visFill = f->visFill; ws.visBytes = (size_t)nSlots;
-        if (const char* e = getenv("RTR_TRACE_VIS_FILL")) if ((e[0] == '0' || e[0] == '1') && !e[1]) ws.visFill = (uint32_t)(e[0] - '0');      /* test hook: force the pre-fill */
+        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.vis = f->vis.p; ws.visFill = f->visFill;
+        ws.visPlaneBytes = (size_t)nPS; ws.visPlanes = (uint32_t)maxRays;      /* what a launch fills: the first nPS bytes of each of the maxRays planes, not the power-of-two pitch between them */
+#ifdef RTR_TEST_HOOKS
+        if (const char* e = getenv("RTR_TRACE_VIS_FILL")) if ((e[0] == '0' || e[0] == '1') && !e[1]) ws.visFill = (uint32_t)(e[0] - '0');      /* force the pre-fill */
+#endif
         ws.rayQueue.dt = f->rayDT.p; ws.rayQueue.slot = f->raySlot.p; ws.rayQueue.origin = f->rayOrigin.p; ws.rayQueue.slotStride = f->slotStride; ws.rayQueue.slotMask = f->slotStride - 1u;
         ws.queueCount = f->queueCount.p; ws.capPixelSamples = nPS; ws.capRays = nRays; ws.spill = f->spill.p; ws.overflow = f->overflow.p; ws.overflowCap = f->overflowCap; ws.batchLists = f->batchLists.p; ws.listStride = f->listStride; ws.clk = f->clk.p;
-        e = rtrdev::launch_wavefront(s->dev, fb, ws, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
+        e = rtrdev::launch_wavefront(s->dev, fb, ws, f->ctx->tun, (int)s->stats.stackEntries, dstats, st, f->ev, (uint32_t)f->ctx->prop.multiProcessorCount);
     } else {
         (void)hipEventRecord(f->evMega[0], st);
         e = rtrdev::launch_megakernel(s->dev, ra, fo, (int)s->stats.stackEntries, dstats, st);
@@ -1064,11 +1120,110 @@ int rtr_render_batch_limit(const rtr_scene* s, const rtr_render_params* pin, uin
     return RTR_OK;
 }
 
+/* One frame as `parts` band-shards, each on a stream of its own, all writing their rows of the SAME images: the kernels of one frame
+ * are a dependency chain and each ends in a tail, so part k+1's camera rays and queue build run under part k's traversal and its
+ * traversal fills the tail of part k's — frames in flight, inside one frame. */
+int rtr_render_split_async(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* pin, rtr_frame* f, uint32_t parts) {
+    if (!s || !cam || !info || !pin || !f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: null argument");
+    if (parts < 1 || parts > RTR_MAX_SPLIT) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: %u parts, 1 to %d", parts, RTR_MAX_SPLIT);
+    if (pin->shardCount > 1) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: the frame must be whole (shardCount %u); a shard of a multi-GPU frame is not split again", pin->shardCount);
+    if (f->extHdr) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: not a frame of the caller's");
+    rtr_render_params p = *pin;
+    if (p.bandRows == 0) p.bandRows = 8;
+    if (p.bandRows % 8u) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: bandRows %u must be a multiple of 8", p.bandRows);
+    if (p.height == 0 || p.width == 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: empty frame");
+    const uint32_t bands = (p.height + p.bandRows - 1) / p.bandRows;
+    if (parts > bands) parts = bands;                 /* never a part without a band */
+    if (parts <= 1) { p.shardIndex = 0; p.shardCount = 1; return enqueue_render(s, cam, info, &p, &f, 1); }
+    if (f->width != p.width || f->rows != p.height) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_render_split_async: frame is %ux%u, the whole frame is %ux%u", f->width, f->rows, p.width, p.height);
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    /* the parts: internal frame objects (scratch, events, counters; no images) on contexts (streams) of their own */
+    while (f->parts.size() < parts) {
+        rtr_ctx* pc = nullptr; rtr_frame* pf = nullptr;
+        int rc = rtr_ctx_create(f->ctx->device, &pc);
+        if (rc != RTR_OK) return rc;
+        rc = frame_new(pc, f->width, f->rows, f->images, false, &pf);
+        if (rc != RTR_OK) { rtr_ctx_destroy(pc); return rc; }
+        hipEvent_t ev = nullptr;
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) { rtr_frame_destroy(pf); rtr_ctx_destroy(pc); return fail(RTR_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+        f->partCtx.push_back(pc); f->parts.push_back(pf); f->evPart.push_back(ev);
+    }
+    for (auto& e : f->evSplit) if (!e) HIP_TRY(hipEventCreate(&e));
+    /* what another stream still holds for this frame comes first (enqueue_render's rule) */
+    if (f->batchStream && f->batchStream != st) HIP_TRY(hipStreamWaitEvent(st, f->evDone, 0));
+    f->batchStream = nullptr;
+    HIP_TRY(hipEventRecord(f->evSplit[0], st));          /* the fork */
+    int rc = RTR_OK;
+    uint32_t started = 0;
+    for (uint32_t k = 0; k < parts && rc == RTR_OK; ++k) {
+        rtr_frame* pf = f->parts[k];
+        pf->ctx->tun = f->ctx->tun;
+        pf->images = f->images;
+        for (int i = 0; i < 8; ++i) pf->ext[i] = f->image_ptr(i);
+        pf->extHdr = f->hdr.p;
+        hipStream_t ps = pf->ctx->stream;
+        HIP_TRY(hipStreamWaitEvent(ps, f->evSplit[0], 0));
+        p.shardIndex = k; p.shardCount = parts;
+        rc = enqueue_render(s, cam, info, &p, &pf, 1, true);
+        if (rc != RTR_OK) break;
+        HIP_TRY(hipEventRecord(f->evPart[k], ps));
+        HIP_TRY(hipStreamWaitEvent(st, f->evPart[k], 0));      /* the join: whatever follows on the frame's stream sees the whole frame */
+        ++started;
+    }
+    HIP_TRY(hipEventRecord(f->evSplit[1], st));
+    f->ownPending = true; f->viaBatch = false;
+    f->pendingSplit = started; f->pendingStats = started != 0;
+    return rc;
+}
+
+int rtr_render_split(rtr_scene* s, const RtrCameraData* cam, const RtrSceneInfo* info, const rtr_render_params* p, rtr_frame* f, uint32_t parts) {
+    int rc = rtr_render_split_async(s, cam, info, p, f, parts);
+    if (rc != RTR_OK) return rc;
+    return rtr_frame_wait(f);
+}
+
+/* joins a split render and makes the frame's statistics out of its parts': counters and per-kernel times are SUMS over the parts (the
+ * parts' kernels overlap: the sum of their durations exceeds the frame's), totalMs is the frame's own duration, fork to join */
+static int wait_split(rtr_frame* f) {
+    const uint32_t parts = f->pendingSplit;
+    f->pendingSplit = 0; f->pendingStats = false;
+    rtr_frame_stats t; memset(&t, 0, sizeof t);
+    double clk = 0; uint32_t nclk = 0;
+    for (uint32_t k = 0; k < parts; ++k) {
+        int rc = rtr_frame_wait(f->parts[k]);
+        if (rc != RTR_OK) return rc;
+        const rtr_frame_stats& a = f->parts[k]->stats;
+        t.numRays += a.numRays; t.numPrimaryRays += a.numPrimaryRays; t.numShadowRays += a.numShadowRays; t.numNodeVisits += a.numNodeVisits;
+        t.numTriTests += a.numTriTests; t.numHits += a.numHits; t.numLightFetches += a.numLightFetches; t.numLightTriFetches += a.numLightTriFetches;
+        t.numTexFetches += a.numTexFetches; t.numAlphaTests += a.numAlphaTests; t.algorithmicBytes += a.algorithmicBytes;
+        t.numShadowNodeVisits += a.numShadowNodeVisits; t.numShadowTriTests += a.numShadowTriTests; t.shadowTraceBytes += a.shadowTraceBytes;
+        t.primaryMs += a.primaryMs; t.shadowGenMs += a.shadowGenMs; t.shadowTraceMs += a.shadowTraceMs; t.resolveMs += a.resolveMs; t.shadowTailMs += a.shadowTailMs;
+        t.localRows += a.localRows; t.localPixels += a.localPixels; t.pipelineUsed = a.pipelineUsed;
+        t.shadowInnerIterations += a.shadowInnerIterations; t.shadowInnerActiveLanes += a.shadowInnerActiveLanes;
+        t.shadowTriIterations += a.shadowTriIterations; t.shadowTriActiveLanes += a.shadowTriActiveLanes; t.shadowRefills += a.shadowRefills;
+        t.primaryTailRays += a.primaryTailRays; t.shadowTailRays += a.shadowTailRays;
+        if (a.shadowTraceClockMHz > 0.f) {
+            clk += a.shadowTraceClockMHz; ++nclk;
+            t.shadowTraceClockMinMHz = (t.shadowTraceClockMinMHz == 0.f || a.shadowTraceClockMinMHz < t.shadowTraceClockMinMHz) ? a.shadowTraceClockMinMHz : t.shadowTraceClockMinMHz;
+            t.shadowTraceClockMaxMHz = a.shadowTraceClockMaxMHz > t.shadowTraceClockMaxMHz ? a.shadowTraceClockMaxMHz : t.shadowTraceClockMaxMHz;
+        }
+    }
+    if (nclk) t.shadowTraceClockMHz = (float)(clk / nclk);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, f->evSplit[0], f->evSplit[1]);
+    t.totalMs = ms;
+    f->stats = t;
+    return RTR_OK;
+}
+
 int rtr_frame_wait(rtr_frame* f) {
     if (!f) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_frame_wait: null frame");
     HIP_TRY(hipSetDevice(f->ctx->device));
     HIP_TRY(hipStreamSynchronize(f->ctx->stream));
     f->ownPending = false;
+    if (f->pendingSplit) return wait_split(f);
     if (f->viaBatch) { HIP_TRY(hipEventSynchronize(f->evDone)); f->batchStream = nullptr; return RTR_OK; }      /* rendered in another frame's launch: that launch's times and counters are the leading frame's */
     if (!f->pendingStats) return RTR_OK;
     f->pendingStats = false;
@@ -1153,6 +1308,7 @@ int rtr_denoise_combine(rtr_frame* f, int iterations) {
     for (int i = 0; i < 8; ++i)
         if (!f->image_ptr(i)) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_denoise_combine: the frame lacks image %d (create it with all of images 0-7)", i);
     HIP_TRY(hipSetDevice(f->ctx->device));
+    { const int rc = order_on_own_stream(f); if (rc != RTR_OK) return rc; }
     hipStream_t st = f->ctx->stream;
     uint32_t* sh = f->image_ptr(RTR_IMAGE_SHADOWED); uint32_t* un = f->image_ptr(RTR_IMAGE_UNSHADOWED);
     uint32_t* dsh = f->image_ptr(RTR_IMAGE_DENOISED_SHADOWED); uint32_t* dun = f->image_ptr(RTR_IMAGE_DENOISED_UNSHADOWED);

@@ -38,10 +38,15 @@ def gpu_ctx():
 def queue_mode(request):
     """Runs a GPU test twice: with the shadow-ray queue in emission order and binned by direction octant (k_shadow_gen_oct +
     per-octant batch lists).  By default the library picks by queue size, so small test frames would only ever see the plain
-    queue; RTR_TRACE_BINNED is read at every render."""
+    queue.  The choice is a tunable of the context (rtr_ctx_set_tunable "trace_binned"), which a context reads from the environment
+    when it is created: the session's context is set directly, contexts a test makes itself get it from RTR_TRACE_BINNED."""
+    v = 1 if request.param == "binned" else 0
     old = os.environ.get("RTR_TRACE_BINNED")
-    os.environ["RTR_TRACE_BINNED"] = "1" if request.param == "binned" else "0"
+    os.environ["RTR_TRACE_BINNED"] = str(v)
+    ctx = request.getfixturevalue("gpu_ctx")
+    ctx.set_tunable("trace_binned", v)
     yield request.param
+    ctx.set_tunable("trace_binned", 2)
     if old is None:
         os.environ.pop("RTR_TRACE_BINNED", None)
     else:

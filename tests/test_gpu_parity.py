@@ -507,14 +507,18 @@ def test_deep_stack_rays_take_the_tail_kernel(gpu_ctx, oracle):
     _assert_same(imgs[0], imgs[1], "timed form vs counting form (LDS stack + overflow tail)")
     # the list of abandoned rays holds 1/16 of the queue (at least 2^20 entries); past that k_shadow_tail redoes the whole queue.
     # Forced here with a list of 4 entries: the same image
+    # (RTR_TRACE_OVERFLOW_CAP exists only in librtr_hip_test.so, the product's sources built with -DRTR_TEST_HOOKS)
     os.environ["RTR_TRACE_OVERFLOW_CAP"] = "4"
     try:
-        fo = api.Frame(gpu_ctx, W, H)
-        api.render(scene, cam, info, api.make_params(W, H, spp=1, collect_stats=1, pipeline=2), fo)
+        hctx = api.Context(0, test_hooks=True)
+        hscene = api.Scene(hctx, d)
+        fo = api.Frame(hctx, W, H)
+        api.render(hscene, cam, info, api.make_params(W, H, spp=1, collect_stats=1, pipeline=2), fo)
         assert fo.stats().shadowTailRays > 4
         _assert_same(fo.download(), imgs[1], "abandoned-ray list overflowed: the redo kernel walks the whole queue")
-        api.render(scene, cam, info, api.make_params(W, H, spp=1, pipeline=2), fo)
+        api.render(hscene, cam, info, api.make_params(W, H, spp=1, pipeline=2), fo)
         _assert_same(fo.download(), imgs[1], "abandoned-ray list overflowed, timed form")
+        fo.close(); hscene.close(); hctx.close()
     finally:
         del os.environ["RTR_TRACE_OVERFLOW_CAP"]
     fm = api.Frame(gpu_ctx, W, H)
@@ -744,9 +748,11 @@ def test_visibility_prefill_polarity_does_not_change_a_pixel(gpu_ctx, oracle, sc
     if fill != "auto":
         os.environ["RTR_TRACE_VIS_FILL"] = fill
     try:
+        # forcing the pre-fill is a switch of librtr_hip_test.so (the product's sources built with -DRTR_TEST_HOOKS); "auto" is the product
+        ctx = api.Context(0, test_hooks=True) if fill != "auto" else gpu_ctx
         s = scenes.bunny_class(320, 184)
-        scene = api.Scene(gpu_ctx, s.desc)
-        frame = api.Frame(gpu_ctx, 320, 184)
+        scene = api.Scene(ctx, s.desc)
+        frame = api.Frame(ctx, 320, 184)
         bvh = scene.export_bvh()
         for f in (0, 1, 2):
             for collect in (0, 1):
@@ -879,6 +885,151 @@ def test_batch_orders_itself_against_the_frames_own_streams(gpu_ctx, scene_cache
         _assert_same(frames[1].download(), singles[1], f"round {rnd}: the batch comes after the frame's own earlier render")
         _assert_same(frames[2].download(), singles[3], f"round {rnd}: the frame's own later render comes after the batch")
     for o in frames + ctxs + [ref, scene]:
+        o.close()
+
+
+@pytest.mark.gpu
+def test_batch_then_denoise_and_clear_on_a_following_frame(gpu_ctx, oracle, scene_cache):
+    """rtr_render_batch_async's ordering contract covers everything enqueued for a frame, not only renders: rtr_denoise_combine and
+    rtr_frame_clear on a frame that FOLLOWED in a batch (the launch ran on the leader's stream) come behind that launch without a host
+    join, and a later batch comes behind them."""
+    import torch
+    W, H = 480, 270
+    s = scenes.sponza_class(W, H, ltc=scenes.shipped_ltc())
+    scene = api.Scene(gpu_ctx, s.desc)
+    p = api.make_params(W, H, spp=1, images=A.IMAGES_RAYGEN5, pipeline=2)
+    infos = [s.scene_info(40 + b) for b in range(3)]
+    one = api.Frame(gpu_ctx, W, H, 0xff)
+    want = []
+    for b in range(3):
+        api.render(scene, s.camera, infos[b], p, one)
+        one.denoise_combine(4)
+        want.append(one.download(A.IMAGE_FINAL))
+    ctxs, streams, frames = [], [], []
+    for _ in range(3):
+        c = api.Context(0); st = torch.cuda.Stream(); c.set_stream(st.cuda_stream)
+        ctxs.append(c); streams.append(st); frames.append(api.Frame(c, W, H, 0xff))
+    for rnd in range(3):
+        api.render_batch(scene, [s.camera] * 3, infos, p, frames)
+        frames[2].denoise_combine(4)             # on frame 2's own stream, straight behind the launch on frame 0's
+        _assert_same(frames[2].download(A.IMAGE_FINAL), want[2], f"round {rnd}: denoise + combine of a following frame sees the batch's images")
+        frames[1].clear()                        # likewise
+        assert not frames[1].download(A.IMAGE_SHADOWED).any(), f"round {rnd}: the clear comes after the batch"
+        frames[0].wait()
+    for o in frames + ctxs + [one, scene]:
+        o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", [2, 3, 5, 16])
+def test_split_render_equals_the_unsplit_frame_and_the_oracle(gpu_ctx, oracle, scene_cache, queue_mode, parts):
+    """rtr_render_split: ONE frame as `parts` band-shards on streams of their own, each writing its rows of the frame's images in
+    place — the same bytes as rtr_render (RGBA8 and the accumulated HDR floats) and as the oracle, the counters of the counting form
+    equal to the unsplit frame's, for interleaved 8-row bands and for taller ones; a plain render of the same frame object afterwards
+    and a split render with more parts than bands behave."""
+    W, H = 333, 201                                  # no multiple of a tile, of a band or of the parts
+    s = scenes.bunny_class(W, H)
+    imgs = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_HDR)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    whole, split = api.Frame(gpu_ctx, W, H, imgs), api.Frame(gpu_ctx, W, H, imgs)
+    for band in (8, 40):
+        whole.clear(); split.clear()
+        hdr = np.zeros((H, W, 4), np.float32)
+        for f in range(2):                           # two accumulation steps: the HDR image is read and written in place by every part
+            for collect in (0, 1):
+                if collect and f == 0:
+                    continue
+                p = api.make_params(W, H, spp=2, images=imgs, accumulate=1 if not collect else 0, accumulated_frames=f if not collect else 0, band_rows=band,
+                                    collect_stats=collect, pipeline=2)
+                if not collect:
+                    api.render(scene, s.camera, s.scene_info(5 + f), p, whole)
+                    api.render_split(scene, s.camera, s.scene_info(5 + f), p, split, parts)
+                    ref = oracle.render(s.desc, s.camera, s.scene_info(5 + f), p, bvh=bvh, images=imgs, hdr=hdr, threads=16)
+                    _assert_same(split.download(), whole.download(), f"{parts} parts, bands of {band}, step {f}: split vs unsplit")
+                    _assert_same(split.download(), ref.images[A.IMAGE_SHADOWED], f"{parts} parts, bands of {band}, step {f}: split vs oracle")
+                    assert np.array_equal(split.download(A.IMAGE_HDR).view(np.uint32), hdr.view(np.uint32)), "accumulated HDR of the split frame vs oracle"
+                else:
+                    cw, cs = api.Frame(gpu_ctx, W, H), api.Frame(gpu_ctx, W, H)
+                    pc = api.make_params(W, H, spp=2, band_rows=band, collect_stats=1, pipeline=2)
+                    api.render(scene, s.camera, s.scene_info(9), pc, cw)
+                    api.render_split(scene, s.camera, s.scene_info(9), pc, cs, parts)
+                    _assert_same(cs.download(), cw.download(), "counting forms, split vs unsplit")
+                    a, b = cw.stats(), cs.stats()
+                    for fld in ("numRays", "numPrimaryRays", "numShadowRays", "numNodeVisits", "numTriTests", "numShadowNodeVisits", "numShadowTriTests", "numHits"):
+                        assert getattr(a, fld) == getattr(b, fld), fld
+                    assert b.localPixels >= a.localPixels      # the parts are equal-size shards: padding rows included
+                    assert b.totalMs > 0 and b.pipelineUsed == 2
+                    cw.close(); cs.close()
+    # the frame object renders unsplit again, and asynchronously split with the join left to rtr_frame_wait
+    p = api.make_params(W, H, spp=1, pipeline=2)
+    api.render(scene, s.camera, s.scene_info(1), p, whole)
+    api.render(scene, s.camera, s.scene_info(1), p, split)
+    _assert_same(split.download(), whole.download(), "a plain render after split renders")
+    api.render_split(scene, s.camera, s.scene_info(2), p, split, parts, asynchronous=True)
+    api.render(scene, s.camera, s.scene_info(2), p, whole)
+    _assert_same(split.download(), whole.download(), "asynchronous split render, joined by the download")
+    # refused: a shard of a sharded frame, too many parts, a frame that is not the whole frame
+    with pytest.raises(api.RtrError):
+        api.render_split(scene, s.camera, s.scene_info(0), api.make_params(W, H, shard_index=0, shard_count=2), split, parts)
+    with pytest.raises(api.RtrError):
+        api.render_split(scene, s.camera, s.scene_info(0), p, split, A.MAX_SPLIT + 1)
+    small = api.Frame(gpu_ctx, W, api.shard_rows(H, 8, 2))
+    with pytest.raises(api.RtrError):
+        api.render_split(scene, s.camera, s.scene_info(0), p, small, 2)
+    for o in (whole, split, small, scene):
+        o.close()
+
+
+@pytest.mark.gpu
+def test_split_render_1080p_against_the_unsplit_frame(gpu_ctx, scene_cache):
+    """BASELINE config 4 at full size through the latency path: the Sponza-class 1080p frame as 2 and 4 parts equals the unsplit
+    frame byte for byte (which test_sponza_1080p_properties_and_sampled_oracle holds against the oracle)."""
+    W, H = 1920, 1080
+    s = scenes.sponza_class(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    p = api.make_params(W, H, spp=1)
+    whole, split = api.Frame(gpu_ctx, W, H), api.Frame(gpu_ctx, W, H)
+    api.render(scene, s.camera, s.scene_info(3), p, whole)
+    for parts in (2, 4):
+        split.clear()
+        api.render_split(scene, s.camera, s.scene_info(3), p, split, parts)
+        _assert_same(split.download(), whole.download(), f"1080p, {parts} parts")
+    for o in (whole, split, scene):
+        o.close()
+
+
+@pytest.mark.gpu
+def test_tunables_belong_to_the_context_and_change_no_pixel(gpu_ctx, scene_cache):
+    """rtr_ctx_set_tunable / rtr_ctx_get_tunable: scheduling knobs of the staged pipeline are read from the environment when a
+    context is created and set per context afterwards; none of them changes a pixel; unknown names and values out of range are refused."""
+    W, H = 256, 144
+    s = scenes.bunny_class(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    p = api.make_params(W, H, spp=1, pipeline=2)
+    base = api.Frame(gpu_ctx, W, H)
+    api.render(scene, s.camera, s.scene_info(0), p, base)
+    want = base.download()
+    os.environ["RTR_TRACE_REFILL"] = "33"
+    try:
+        c = api.Context(0)
+    finally:
+        del os.environ["RTR_TRACE_REFILL"]
+    assert c.get_tunable("trace_refill") == 33 and gpu_ctx.get_tunable("trace_refill") == 20
+    fr = api.Frame(c, W, H)
+    for name, value in (("trace_binned", 1), ("trace_batch", 64), ("trace_wgs_per_cu", 3), ("trace_inner_min", 5), ("trace_octant_forms", 0),
+                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("primary_persist", 1), ("trace_bvh4", 0), ("gen_oct_stage", 0)):
+        c.set_tunable(name, value)
+        assert c.get_tunable(name) == value
+        api.render(scene, s.camera, s.scene_info(0), p, fr)
+        _assert_same(fr.download(), want, f"tunable {name} = {value}")
+    with pytest.raises(api.RtrError):
+        c.set_tunable("no_such_knob", 1)
+    with pytest.raises(api.RtrError):
+        c.set_tunable("trace_refill", 0)
+    with pytest.raises(api.RtrError):
+        api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, collect_stats=1, pipeline=2), fr)     # trace_bvh4 = 0 has no counting form
+    for o in (fr, c, base, scene):
         o.close()
 
 
