@@ -75,6 +75,57 @@ def launch_sizes(count, batch):
     return [base + 1] * extra + [base] * (nl - extra)
 
 
+PATH_PERIOD = 192     # cameras of the scripted walk (scenes.SceneSetup.camera_path: 96 frames forward, 96 back); frame i uses camera i mod 192
+
+
+class CameraSource:
+    """The camera of frame i.  'path' (default): the reference's loop moves its camera every frame (Window::processInput, src/app/window.cppm:68-133,
+    then Camera::updateGPUData) — here the scripted walk of scenes.SceneSetup.camera_path, so the frames of a launch are DIFFERENT
+    views, as a real-time caller's are.  'static': every frame the set-up's camera (rounds 1-3; twenty copies of one visibility problem share the caches)."""
+
+    def __init__(self, setup, mode):
+        self.setup = setup
+        self.path = setup.camera_path(PATH_PERIOD) if (mode == "path" and setup.cam_args and setup.walk_scale > 0) else None
+        self.mode = "path" if self.path else "static"
+
+    def index(self, i):
+        return i % PATH_PERIOD if self.path else 0
+
+    def camera(self, i):
+        return self.path[i % PATH_PERIOD][0] if self.path else self.setup.camera
+
+    def info(self, i, frame_no=None):
+        """SceneInfo of frame i (frame_no: the seed when it is not i — the K frames accumulated into one step share step i's camera)"""
+        pos = self.path[i % PATH_PERIOD][1] if self.path else None
+        return self.setup.scene_info(i if frame_no is None else frame_no, cam_pos=pos)
+
+
+def pick_frames_per_launch(limit_ms, cap, time_launch):
+    """The largest launch (frames, <= cap) whose duration fits limit_ms.  time_launch(c) -> milliseconds of one launch of c frames, warmed.
+    A few probes: an estimate from a small launch (ms per frame falls with the launch length, so the estimate is low), then upwards while
+    it fits, or downwards until it does."""
+    small = min(4, cap)
+    c = max(1, min(cap, int(limit_ms / (time_launch(small) / small))))
+    ms = time_launch(c) if c != small else time_launch(small)
+    if ms <= limit_ms:
+        while c < cap:
+            nxt = min(cap, max(c + 1, int(c * limit_ms / ms)))
+            ms2 = time_launch(nxt)
+            if ms2 > limit_ms:
+                if nxt == c + 1:
+                    break
+                cap = nxt - 1                       # the jump overshot: go on in single steps below it
+                continue
+            c, ms = nxt, ms2
+    else:
+        while c > 1:
+            c = max(1, min(c - 1, int(c * limit_ms / ms)))
+            ms = time_launch(c)
+            if ms <= limit_ms:
+                break
+    return c
+
+
 def launch_plan(args, env, argv):
     """How this invocation runs — decided before torch or any HIP library is imported, testable without a GPU (--print-launch).
     mode: 'single' (N = 1), 'rank' (this process is one rank of a torch.distributed.run job), 'inproc' (N > 1 started plainly: one
@@ -154,6 +205,7 @@ def run_inproc(args, K, plan):
     except RuntimeError as e:
         raise SystemExit(f"bench.py: {e}")
     setup = build_setup(args, scenes, np)
+    cams = CameraSource(setup, args.camera)
     mg.scene_create(setup.desc)
     images = A.IMAGES_FRAMEBUFFER | (A.IMG_BIT(A.IMAGE_HDR) if K > 1 else 0)
 
@@ -166,9 +218,15 @@ def run_inproc(args, K, plan):
     scene = api.Scene(ctx, setup.desc)
     sstats = scene.stats()
     whole = api.Frame(ctx, W, H, images)
-    api.render(scene, setup.camera, setup.scene_info(0), params(collect=1), whole)
-    fs = whole.stats()
-    rays_per_frame, primary_per_frame = int(fs.numRays) * K, int(fs.numPrimaryRays) * K
+    timed = range(args.warmup, args.warmup + args.steps)
+    by_cam = {}
+    for c in sorted({cams.index(i) for i in timed}):      # ray counts depend on the view, not on the seed: one counting render per distinct camera
+        api.render(scene, cams.camera(c), cams.info(c), params(collect=1), whole)
+        fs = whole.stats()
+        by_cam[c] = (int(fs.numRays), int(fs.numPrimaryRays))
+    rays_total = sum(by_cam[cams.index(i)][0] for i in timed) * K
+    primary_total = sum(by_cam[cams.index(i)][1] for i in timed) * K
+    rays_per_frame, primary_per_frame = rays_total // max(args.steps, 1), primary_total // max(args.steps, 1)
 
     p_run = [params(0, j=j) for j in range(K)]
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
@@ -192,7 +250,7 @@ def run_inproc(args, K, plan):
         last_slot[0] = b
         collect(b)                                      # frame i - nbuf: done long ago unless the host runs ahead
         for j in range(K):
-            mg.render_async(b, setup.camera, setup.scene_info(j if K > 1 else i), p_run[j], exchange=(j == K - 1))
+            mg.render_async(b, cams.camera(i), cams.info(i, j if K > 1 else None), p_run[j], exchange=(j == K - 1))
         inflight[b] = True
 
     def run_steps(first, count):
@@ -209,7 +267,7 @@ def run_inproc(args, K, plan):
             last_slot[0] = bufs[-1]
             for b in bufs:
                 collect(b)
-            mg.render_batch_async(bufs, [setup.camera] * c, [setup.scene_info(i + j) for j in range(c)], p_run[0])
+            mg.render_batch_async(bufs, [cams.camera(i + j) for j in range(c)], [cams.info(i + j) for j in range(c)], p_run[0])
             for b in bufs:
                 inflight[b] = True
             i += c
@@ -230,6 +288,28 @@ def run_inproc(args, K, plan):
         for _ in range(groups):
             run_steps(0, biggest)
         drain()
+    # frames per launch under the latency bound (main(): "frames per launch under a latency bound"): single launches, probed
+    latency = {"limit_ms": args.max_latency_ms or None, "probes": [], "chosen_by": "--batch" if args.batch else ("default" if not args.max_latency_ms else "probe")}
+    if args.max_latency_ms > 0 and not args.batch and B > 1:
+        cap = B
+
+        def probe(c):
+            nonlocal B, groups
+            B, groups = c, 1
+            best = None
+            for k in range(4):
+                sync_all()
+                t = time.perf_counter()
+                run_steps(0, c)
+                drain()
+                sync_all()
+                dt = (time.perf_counter() - t) * 1e3
+                if k:
+                    best = dt if best is None else min(best, dt)
+            latency["probes"].append({"frames": c, "launch_ms": round(best, 4)})
+            return best
+        c = pick_frames_per_launch(args.max_latency_ms, cap, probe)
+        B, groups = c, max(nbuf // c, 1)
     run_steps(0, args.warmup)
     drain()
     kern.update({k: 0.0 for k in kern}); kern["n"] = 0
@@ -246,7 +326,7 @@ def run_inproc(args, K, plan):
     # the assembled frame of the last step against the same frame rendered unsharded on device 0
     last_i = args.warmup + args.steps - 1
     for j in range(K):
-        api.render(scene, setup.camera, setup.scene_info(j if K > 1 else last_i), params(0, j=j), whole)
+        api.render(scene, cams.camera(last_i), cams.info(last_i, j if K > 1 else None), params(0, j=j), whole)
     bad = int((mg.download(last_slot[0]) != whole.download()).sum())
     info = A.rtr_mgpu_info()
     A.mgpu_lib().rtr_mgpu_get_info(mg.h, C.byref(info))          # after the run: with the host time of the ranks' threads
@@ -256,16 +336,19 @@ def run_inproc(args, K, plan):
     n = max(kern["n"], 1)
     out = {
         "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S, K) == (1920, 1080, 1, 1) else f"Mrays/sec at {W}x{H} {S}spp" + (f" x{K} frames accumulated in HDR" if K > 1 else ""),
-        "value": round(rays_per_frame * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / K, 4), "higher_is_better": True,
+        "frames_per_launch": B, "frame_latency_ms": round(B * ms_per_step, 4), "latency": latency,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("file " + args.obj) if args.obj else "synthetic",
         "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
                                f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{N}",
-                   "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame, "pipeline": "wavefront" if fs.pipelineUsed == 2 else "megakernel",
+                   "camera": ("a new view every frame: scripted walk (applyInput = Window::processInput), period %d frames" % PATH_PERIOD) if cams.mode == "path" else "static: every frame the same view",
+                   "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame, "rays_per_frame_is": "mean over the frames of the timed region",
+                   "pipeline": "wavefront" if fs.pipelineUsed == 2 else "megakernel",
                    "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries), "build_ms": round(float(sstats.buildMs), 1)}},
-        "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
+        "primary_mrays_per_s": round(primary_total / elapsed / 1e6, 2),
         "frames_in_flight": nbuf,
-        "frames_per_launch": B, "timed_launches": launch_sizes(args.steps, B),
+        "timed_launches": launch_sizes(args.steps, B),
         "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
         "kernels_scope": "rank 0's shard, per frame (a launch covers frames_per_launch frames); HIP-event brackets",
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
@@ -310,6 +393,13 @@ def main():
                     help="frames per launch of the pipeline (rtr_render_batch_async; 0 = default: 32 below four GPUs, 16 and two launches in flight from four on; "
                          "1 = one launch per frame; capped by rtr_render_batch_limit).  The frames in flight are "
                          "rendered in groups of B: every kernel of the pipeline is launched once per group over B frames' work")
+    ap.add_argument("--max-latency-ms", type=float, default=16.7, metavar="L",
+                    help="frames are rendered in launches of several (throughput) — but a caller sees the FIRST frame of a launch when the launch ends: "
+                         "pick the largest launch whose duration (frames_per_launch x ms_per_step = frame_latency_ms) fits L, measured before the timed region "
+                         "(default 16.7 = one 60-Hz refresh; 0 = no bound).  An explicit --batch wins.")
+    ap.add_argument("--camera", default="path", choices=["path", "static"],
+                    help="'path' (default): the camera moves every frame along a scripted walk (applyInput, the reference's Window::processInput); "
+                         "'static': every frame the same view (rounds 1-3)")
     ap.add_argument("--accumulate", type=int, default=1, metavar="K",
                     help="a step = K frames (frame = 0..K-1) summed in the float HDR buffer and tonemapped once (BASELINE config 5: "
                          "--width 3840 --height 2160 --accumulate 16)")
@@ -394,6 +484,7 @@ def main():
 
     W, H, S = args.width, args.height, args.spp
     setup = build_setup(args, scenes, np)
+    cams = CameraSource(setup, args.camera)
     emu = args.emulate_rank_of if (world == 1 and args.emulate_rank_of > 1) else 0
     nshards = emu if emu else world
     # Several frames are kept in flight on separate streams (one context each, ONE shared scene): the tails of one
@@ -429,23 +520,42 @@ def main():
     def render_step(fr, i, plist, asynchronous):
         """one step: K frames (frame = 0..K-1 when accumulating, else frame = i) into `fr`, stream-ordered"""
         for j in range(K):
-            api.render(scene, setup.camera, setup.scene_info(j if K > 1 else i), plist[j], fr, asynchronous=asynchronous)
+            api.render(scene, cams.camera(i), cams.info(i, j if K > 1 else None), plist[j], fr, asynchronous=asynchronous)
 
-    # ---- untimed stats pass: exact ray / node / triangle counts of one frame -------------------------
-    api.render(scene, setup.camera, setup.scene_info(0), params(collect=1), frame)
-    fs = frame.stats()
-    counts = torch.tensor([fs.numRays, fs.numPrimaryRays, fs.numShadowRays, fs.algorithmicBytes, fs.shadowTraceBytes],
-                          dtype=torch.float64, device=device)
+    # ---- untimed stats pass: exact ray / node / triangle counts of the frames of the timed region -------------------------
+    # Ray counts depend on the view, not on the frame number (every hit issues numLights x light-triangles x shadow-rays rays; the
+    # seed only moves the sample positions): one counting render per distinct camera of the timed region, summed over the ranks.
+    timed = range(args.warmup, args.warmup + args.steps)
+    cam_ids = sorted({cams.index(i) for i in timed} | {cams.index(args.warmup + j) for j in range(max(args.isolated_frames, 0))})
+    FIELDS = ("numRays", "numPrimaryRays", "numShadowRays", "algorithmicBytes", "shadowTraceBytes", "shadowInnerIterations", "shadowInnerActiveLanes",
+              "shadowTriIterations", "shadowTriActiveLanes", "shadowRefills", "shadowTailRays", "numShadowNodeVisits", "numShadowTriTests")
+    rows_ = []
+    for c in cam_ids:
+        api.render(scene, cams.camera(c), cams.info(c), params(collect=1), frame)
+        fs = frame.stats()
+        rows_.append([float(getattr(fs, f)) for f in FIELDS])
+    counts = torch.tensor(rows_, dtype=torch.float64, device=device)
+    local_counts = counts.clone()                     # this rank's own shard (rank 0: what its launches' roofline is made of)
     if dist_on:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    # a step of K accumulated frames issues K times the rays of one frame: ray counts do not depend on the frame number
-    # (every hit issues numLights x light-triangles x shadow-rays rays; only the sample positions change)
-    rays_per_frame, primary_per_frame = int(counts[0].item()) * K, int(counts[1].item()) * K
+    by_cam = {c: {f: int(counts[k][n].item()) for n, f in enumerate(FIELDS)} for k, c in enumerate(cam_ids)}
+    by_cam_local = {c: {f: int(local_counts[k][n].item()) for n, f in enumerate(FIELDS)} for k, c in enumerate(cam_ids)}
+    # a step of K accumulated frames issues K times the rays of one frame
+    rays_total = sum(by_cam[cams.index(i)]["numRays"] for i in timed) * K
+    primary_total = sum(by_cam[cams.index(i)]["numPrimaryRays"] for i in timed) * K
+    rays_per_frame, primary_per_frame = rays_total // max(args.steps, 1), primary_total // max(args.steps, 1)      # means over the timed frames
+    alg_bytes_mean = sum(by_cam[cams.index(i)]["algorithmicBytes"] for i in timed) / max(args.steps, 1)
     pipeline_used = fs.pipelineUsed
-    sched = {"node_loop_trips": int(fs.shadowInnerIterations), "node_loop_lanes": int(fs.shadowInnerActiveLanes),
-             "triangle_loop_trips": int(fs.shadowTriIterations), "triangle_loop_lanes": int(fs.shadowTriActiveLanes),
-             "refill_passes": int(fs.shadowRefills), "tail_rays": int(fs.shadowTailRays),
-             "wide_visits": int(fs.numShadowNodeVisits), "triangle_tests": int(fs.numShadowTriTests), "shadow_rays": int(fs.numShadowRays)}
+
+    def mean_local(f):
+        return sum(by_cam_local[cams.index(i)][f] for i in timed) / max(args.steps, 1)
+    # rank 0's any-hit launches, per frame, mean over the timed frames
+    sched = {"node_loop_trips": mean_local("shadowInnerIterations"), "node_loop_lanes": mean_local("shadowInnerActiveLanes"),
+             "triangle_loop_trips": mean_local("shadowTriIterations"), "triangle_loop_lanes": mean_local("shadowTriActiveLanes"),
+             "refill_passes": mean_local("shadowRefills"), "tail_rays": mean_local("shadowTailRays"),
+             "wide_visits": mean_local("numShadowNodeVisits"), "triangle_tests": mean_local("numShadowTriTests"), "shadow_rays": mean_local("numShadowRays")}
+    sched = {k: int(round(v)) for k, v in sched.items()}
+    trace_bytes_mean = mean_local("shadowTraceBytes")
 
     p_run = [params(0, j=j) for j in range(K)]
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
@@ -536,7 +646,7 @@ def main():
             g0 = (ln % groups) * B
             key = (i, c, g0)
             if key not in marshalled:
-                marshalled[key] = api.marshal_batch([setup.camera] * c, [setup.scene_info(i + j) for j in range(c)], [frames[g0 + j] for j in range(c)])
+                marshalled[key] = api.marshal_batch([cams.camera(i + j) for j in range(c)], [cams.info(i + j) for j in range(c)], [frames[g0 + j] for j in range(c)])
             i += c; ln += 1
 
     def step_batch(i0, count):
@@ -550,7 +660,7 @@ def main():
         if use_lib:                                     # one launch of the pipeline per rank for the batch, then every slot's exchange
             for b in bufs:
                 lib_collect(b)
-            mg.render_batch_async(bufs, [setup.camera] * count, [setup.scene_info(i0 + j) for j in range(count)], p_run[0])
+            mg.render_batch_async(bufs, [cams.camera(i0 + j) for j in range(count)], [cams.info(i0 + j) for j in range(count)], p_run[0])
             for b in bufs:
                 inflight[b] = True
             return
@@ -562,7 +672,7 @@ def main():
             key = (i0, count, bufs[0])
             m = marshalled.get(key)
             if m is None:
-                m = marshalled[key] = api.marshal_batch([setup.camera] * count, [setup.scene_info(i0 + j) for j in range(count)], [frames[b] for b in bufs])
+                m = marshalled[key] = api.marshal_batch([cams.camera(i0 + j) for j in range(count)], [cams.info(i0 + j) for j in range(count)], [frames[b] for b in bufs])
             api.render_batch(scene, None, None, p_run[0], None, marshalled=m)
             for b in bufs:
                 inflight[b] = True
@@ -583,7 +693,7 @@ def main():
         if use_lib:
             lib_collect(b)                              # frame i-nbuf: done long ago unless the host runs ahead
             for j in range(K):
-                mg.render_async(b, setup.camera, setup.scene_info(j if K > 1 else i), p_run[j], exchange=(j == K - 1))
+                mg.render_async(b, cams.camera(i), cams.info(i, j if K > 1 else None), p_run[j], exchange=(j == K - 1))
             inflight[b] = True
             return
         with torch.cuda.stream(streams[b]):
@@ -621,9 +731,42 @@ def main():
         for _ in range(groups):
             run_steps(0, biggest)
         drain()
+    # ---- frames per launch under a latency bound -----------------------------------------------------------------------------
+    # A launch of B frames is ready when it ends: the first of its frames is B x ms_per_step old by then, and all B cameras had to be
+    # known when it started.  The reference presents ONE frame per loop iteration (application.cppm:352-389,437); a caller that wants
+    # the throughput of many frames per launch chooses how stale a frame may be.  Default: one 60-Hz refresh.  Probed here, before the
+    # timed region, with single launches of the same frames (max over the ranks); an explicit --batch is taken as it is.
+    latency = {"limit_ms": args.max_latency_ms or None, "probes": [], "chosen_by": "--batch" if args.batch else ("default" if not args.max_latency_ms else "probe")}
+    if args.max_latency_ms > 0 and not args.batch and B > 1:
+        cap = B
+
+        def probe(c):
+            nonlocal B, groups
+            B, groups = c, 1                             # always the same leading frame: its scratch grows once, in the untimed first launch
+            best = None
+            for k in range(4):
+                sync_all()
+                t = time.perf_counter()
+                run_steps(0, c)
+                drain()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t) * 1e3
+                if dist_on:
+                    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                if k:
+                    best = dt if best is None else min(best, dt)
+            latency["probes"].append({"frames": c, "launch_ms": round(best, 4)})
+            return best
+        c = pick_frames_per_launch(args.max_latency_ms, cap, probe)
+        B, groups = c, max(nbuf // c, 1)
+        if not dist_on:                                 # one launch at a time on one GPU: the frame objects of one launch
+            nbuf, groups = B, 1
     run_steps(0, args.warmup)
     drain()
     kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0})
+    del clocks[:], clock_span[:]
     if B > 1 and not use_lib:
         prepare_launches(args.warmup, args.steps, launch_no[0])
     sync_all()
@@ -643,7 +786,7 @@ def main():
     # kernels (k_shadow_trace4: 2.7 ms bracket, 2.1 ms dispatch begin->end in rocprof, 1.86 ms alone), so the per-kernel cost
     # and the roofline are taken from this pass; rocprofv3 of `--frames-in-flight 1` reproduces it (profiles/).
     kern_iso, iso_ms_per_frame, clocks_iso = None, None, []
-    if nbuf > 1 and args.isolated_frames > 0:
+    if args.isolated_frames > 0:
         kern_iso = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0}
         clocks_iso = []
         torch.cuda.synchronize()
@@ -657,6 +800,7 @@ def main():
             if st.shadowTraceClockMHz > 0:
                 clocks_iso.append(st.shadowTraceClockMHz)
         iso_ms_per_frame = (time.perf_counter() - t1) * 1e3 / args.isolated_frames
+        iso_rays = sum(by_cam_local[cams.index(args.warmup + j)]["numRays"] for j in range(args.isolated_frames))
 
     # The frame the reference presents, end to end, on the same scene (one at a time: rtr_denoise_combine is synchronous)
     presented = None
@@ -690,7 +834,7 @@ def main():
         pframe.close(); pscene.close()
 
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
-    mrays = rays_per_frame * args.steps / elapsed / 1e6
+    mrays = rays_total / elapsed / 1e6
 
     out = None
     if rank == 0:
@@ -698,137 +842,169 @@ def main():
         bracket_ms = kern["shadow_trace"] / n                      # in-region HIP-event bracket, per frame
         # With B frames per launch and no more frame objects than one launch takes, ONE launch of every kernel is on the GPU at a time:
         # the HIP-event brackets of the TIMED REGION are the kernels' own durations, and the roofline is that of the launches the
-        # headline number is made of (B frames' rays each).  Otherwise launches of different frames overlap and the kernel's own
-        # duration comes from the one-frame-at-a-time pass after the timed region.
-        timed_sizes = set(launch_sizes(args.steps, B))
-        own_launch = B > 1 and nbuf == B and not dist_on and len(timed_sizes) == 1          # equal launches, one at a time
-        launch_frames = timed_sizes.pop() if own_launch else 1
-        trace_ms = bracket_ms * launch_frames if own_launch else (kern_iso["shadow_trace"] if kern_iso else bracket_ms)
-        trace_bytes = fs.shadowTraceBytes * launch_frames         # rank 0's launch
+        # headline number is made of — all of them, summed: busy cycles of the region's any-hit launches over their cycles.  Otherwise
+        # launches of different frames overlap and the kernel's own duration comes from the one-frame-at-a-time pass after the timed region.
+        sizes = launch_sizes(args.steps, B)
+        own_launch = B > 1 and nbuf == B and not dist_on          # one launch at a time
+        n_launches = len(sizes) if own_launch else 1
+        launch_frames = (args.steps / n_launches) if own_launch else 1            # mean frames per launch of the launches described
+        trace_ms_total = kern["shadow_trace"] if own_launch else (kern_iso["shadow_trace"] if kern_iso else bracket_ms)      # all the launches described, summed
+        trace_ms = trace_ms_total / n_launches                                    # mean per launch
+        trace_rays = sched["shadow_rays"] * (args.steps if own_launch else 1)     # shadow rays those launches traced (counting form, mean of the timed frames)
+        trace_bytes = trace_bytes_mean * (args.steps if own_launch else 1)
         roofline, roofline2, frame_hbm = None, None, None
         if pipeline_used == 2 and trace_ms > 0:
             rev = A.hip_lib().rtr_kernel_revision().decode()
-            pmc, pmc_note = None, None
-            # The counter totals are NOT measured by this process (rocprofv3 has to wrap it): they are the committed passes of the same
-            # command (profiles/pmc_r03.sh -> profiles/r03/pmc_roofline.json) and are only used when they describe THIS run — same
-            # workload key, kernel revision, triangle count and queue length (= the shadow rays the counting form counted just now)
-            tpath = os.path.join(ROOT, "profiles", "r03", "pmc_roofline.json")
-            key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}" + (f"_batch{launch_frames}" if launch_frames > 1 else "")
-            try:
-                pmc = json.load(open(tpath)).get(key)
-                if pmc is None:
-                    pmc_note = f"no committed counter passes for {key}"
-                elif pmc.get("kernel_revision") != rev:
-                    pmc, pmc_note = None, f"committed counters are of kernel revision {pmc.get('kernel_revision')}, this library is {rev}"
-                elif pmc.get("triangles") != int(sstats.numTriangles) or pmc.get("rays_per_launch") != sched["shadow_rays"] * launch_frames:
-                    pmc, pmc_note = None, (f"committed counters are of a launch over {pmc.get('triangles')} triangles / {pmc.get('rays_per_launch')} queued rays, "
-                                           f"this run has {int(sstats.numTriangles)} / {sched['shadow_rays'] * launch_frames}")
-            except Exception as e:      # noqa: BLE001
-                pmc_note = f"{tpath}: {e}"
+            pmc, pmc_note, pmc_key, pmc_file = None, None, None, None
+            # The counter totals are NOT measured by this process (rocprofv3 has to wrap it): they are committed passes of this command
+            # (profiles/pmc_r04.sh -> profiles/r04/pmc_roofline.json).  Used when workload, kernel revision and triangle count match this
+            # run; among those, the passes whose launches are closest in length (same camera mode first), and the totals are SCALED by
+            # rays traced (`pmc_scaled_by`: 1.0 = the committed passes are of exactly these launches) — counter totals of this kernel are
+            # proportional to the rays it walks to within a per cent across launch lengths (profiles/r03/pmc_roofline.json: 33.9 - 34.4
+            # vector instructions per ray from 1 to 32 frames per launch).
+            base_key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
+            for tpath in (os.path.join(ROOT, "profiles", "r04", "pmc_roofline.json"), os.path.join(ROOT, "profiles", "r03", "pmc_roofline.json")):
+                try:
+                    table = json.load(open(tpath))
+                except Exception as e:      # noqa: BLE001
+                    pmc_note = f"{tpath}: {e}"
+                    continue
+                cands = []
+                for key, v in table.items():
+                    if not isinstance(v, dict) or not (key == base_key or key.startswith(base_key + "_")):
+                        continue
+                    if v.get("kernel_revision") != rev or v.get("triangles") != int(sstats.numTriangles) or not v.get("rays_per_launch"):
+                        continue
+                    fpl = v.get("frames_per_launch") or (int(key.split("_batch")[1].split("_")[0]) if "_batch" in key else 1)
+                    cands.append((0 if v.get("camera", "static") == cams.mode else 1, abs(fpl - launch_frames), key, v))
+                if cands:
+                    cands.sort(key=lambda t: t[:3])
+                    pmc_key, pmc, pmc_file = cands[0][2], cands[0][3], os.path.relpath(tpath, ROOT)
+                    break
+                pmc_note = f"no committed counter passes of revision {rev} for {base_key} ({sstats.numTriangles} triangles)"
+            scale = (trace_rays / n_launches) / pmc["rays_per_launch"] if pmc else None      # this run's mean launch over the committed one, in rays
+
+            def per_launch(name):
+                return pmc[name] * scale if pmc else None
             ck = clocks if own_launch else (clocks_iso if (kern_iso and clocks_iso) else clocks)
             clock_mhz = sorted(ck)[len(ck) // 2] if ck else None
             num_simds = 4 * torch.cuda.get_device_properties(device).multi_processor_count
             launch_cycles = trace_ms * 1e-3 * clock_mhz * 1e6 if clock_mhz else None
-            busy = pmc["SQ_ACTIVE_INST_VALU_quad"] * 4 / num_simds if pmc else None
-            traffic = pmc["hbm_bytes_per_launch"] if pmc else None
+            busy = per_launch("SQ_ACTIVE_INST_VALU_quad") * 4 / num_simds if pmc else None
+            traffic = per_launch("hbm_bytes_per_launch")
+            frac = busy / launch_cycles if (busy and launch_cycles) else None
+            lane_all = pmc["derived"]["valu_lane_utilisation"] if pmc else None
+            # what the 4 cycles per instruction of the counter's convention are worth for THIS kernel's visit: a microbenchmark that issues
+            # the visit's instruction mix as independent streams at eight waves per SIMD (profiles/microbench/visit_mix.hip, committed result)
+            mix = None
+            try:
+                mix = json.load(open(os.path.join(ROOT, "profiles", "r04", "visit_mix_issue.json")))
+            except Exception:      # noqa: BLE001
+                pass
             roofline = {
                 # the ceiling that binds: one SIMD issues one vector instruction at a time; SQ_ACTIVE_INST_VALU counts, in units of 4
                 # cycles, the time SIMDs spent issuing them
                 "bound": "valu_issue",
                 "kernel": "k_shadow_trace4<16, true, false>: any-hit traversal of the shadow-ray queue, revision " + rev,
                 "achieved": round(busy, 1) if busy else None, "peak": round(launch_cycles, 1) if launch_cycles else None,
-                "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch)",
-                "frac": round(busy / launch_cycles, 4) if (busy and launch_cycles) else None,
-                "avg_launch_ms": round(trace_ms, 4),
-                "frames_per_launch": launch_frames, "avg_ms_per_frame": round(trace_ms / launch_frames, 4),
-                "avg_launch_ms_source": ("HIP events on the launch stream over the TIMED REGION: one launch of every kernel at a time, each over "
-                                         f"{launch_frames} frames' rays" if own_launch else
+                "unit": "SIMD cycles per launch (achieved: issuing vector instructions = SQ_ACTIVE_INST_VALU x 4 / SIMDs; peak: cycles of the launch); mean over the launches of the timed region",
+                "frac": round(frac, 4) if frac else None,
+                # the part of it that can still move: issue slots whose lanes did work (frac x the hardware's lane utilisation over all vector instructions)
+                "frac_useful": round(frac * lane_all, 4) if (frac and lane_all) else None,
+                "issue_cycles_per_inst_measured": mix,
+                "avg_launch_ms": round(trace_ms, 4), "launches": n_launches,
+                "frames_per_launch": round(launch_frames, 2), "avg_ms_per_frame": round(trace_ms / launch_frames, 4),
+                "avg_launch_ms_source": ("HIP events on the launch stream over the TIMED REGION: one launch of every kernel at a time, "
+                                         f"launches of {sorted(set(sizes))} frames" if own_launch else
                                          (f"HIP events on the launch stream, {args.isolated_frames} frames rendered one at a time right after the timed region"
                                           if kern_iso else "HIP events on the launch stream over the timed region")),
                 "one_frame_launch_ms": round(kern_iso["shadow_trace"], 4) if kern_iso else None,
                 "in_flight_event_bracket_ms": round(bracket_ms, 4) if (kern_iso and not own_launch) else None,
                 "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
-                # the same stamps from the timed region, where four frames share the GPU: the clock the chip sustains under that load
-                "clock_mhz_in_flight": round(sorted(clocks)[len(clocks) // 2], 1) if clocks else None,
                 "clock_source": "s_memtime / s_memrealtime stamps around the launch's persistent loop (lane 0 of the first workgroup of each XCD; mean over the XCDs, median over the launches), same launches as avg_launch_ms",
                 # the XCDs clock independently: slowest and fastest of them over the timed launches
                 "clock_mhz_xcd_min_max": [round(min(a for a, _ in clock_span), 1), round(max(b for _, b in clock_span), 1)] if (clock_span and own_launch) else None,
-                # SQ_ACTIVE_INST_VALU charges every vector instruction four cycles; simple ones issue faster (profiles/r02/valu_issue_rates_v2_in_kernel_clock.log),
-                # so on a part that clocks a few per cent lower than the one the counters were collected on the ratio can come out above 1
-                "frac_note": "achieved = committed counter passes (SQ_ACTIVE_INST_VALU x 4 cycles per instruction, an upper estimate for simple instructions); peak = this run's launch time x this run's mean shader clock",
+                # SQ_ACTIVE_INST_VALU charges every vector instruction four cycles; simple ones issue faster, so on a part that clocks a few
+                # per cent lower than the one the counters were collected on the ratio can come out above 1
+                "frac_note": "achieved = committed counter passes (SQ_ACTIVE_INST_VALU x 4 cycles per instruction, an upper estimate for simple instructions), scaled by rays; peak = this run's launch time x this run's mean shader clock",
                 "simds": num_simds,
-                "valu_wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]) if pmc else None,
-                "valu_wave_insts_per_ray": round(pmc["SQ_INSTS_VALU"] / (sched["shadow_rays"] * launch_frames), 2) if pmc else None,
+                "valu_wave_insts_per_launch": int(per_launch("SQ_INSTS_VALU")) if pmc else None,
+                "valu_wave_insts_per_ray": round(pmc["SQ_INSTS_VALU"] / pmc["rays_per_launch"], 2) if pmc else None,
                 # dead lanes: what fraction of the lanes did work in the trips of the kernel's two loops (counting form of the same kernel,
                 # run in this process), and what the hardware says for all vector instructions (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))
                 "lane_util": {"node_loop": round(sched["node_loop_lanes"] / max(64 * sched["node_loop_trips"], 1), 4),
                               "triangle_loop": round(sched["triangle_loop_lanes"] / max(64 * sched["triangle_loop_trips"], 1), 4),
-                              "all_vector_instructions": round(pmc["derived"]["valu_lane_utilisation"], 4) if pmc else None},
+                              "all_vector_instructions": round(lane_all, 4) if lane_all else None},
                 "per_ray": {"wide_node_visits": round(sched["wide_visits"] / max(sched["shadow_rays"], 1), 3),
                             "triangle_tests": round(sched["triangle_tests"] / max(sched["shadow_rays"], 1), 3)},
-                "schedule": sched,
+                "schedule_per_frame": sched,
                 # the memory side, for the record: HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (gfx950 corrections in the json),
                 # L1 -> L2 read requests x 64 B, L1 tag look-ups per L1 per clock
-                "traffic": traffic,
+                "traffic": int(traffic) if traffic else None,
                 "hbm_frac": round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "l2_frac": round(pmc["TCP_TCC_READ_REQ"] * 64 / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if pmc else None,
+                "l2_frac": round(per_launch("TCP_TCC_READ_REQ") * 64 / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if pmc else None,
                 # the second unit that is nearly full: one L1 (TCP) per CU, one tag look-up per clock
-                "l1_tag_lookups_per_l1_clock": round(pmc["TCP_TOTAL_CACHE_ACCESSES"] / (num_simds / 4 * launch_cycles), 4) if (pmc and launch_cycles) else None,
-                # algorithmic bytes of the same kernel (its counting form): 64 B per 4-wide record visited + 48 B per triangle test + 33 B per
+                "l1_tag_lookups_per_l1_clock": round(per_launch("TCP_TOTAL_CACHE_ACCESSES") / (num_simds / 4 * launch_cycles), 4) if (pmc and launch_cycles) else None,
+                # algorithmic bytes of the same kernel (its counting form): 64 B per 4-wide record visited + 48 B per triangle test + 37 B per
                 # ray.  Served by LDS / L1 / L2 / Infinity Cache: this rate is NOT a fraction of any ceiling and is not the roofline
-                "algorithmic_bytes_per_launch": int(trace_bytes),
-                "algorithmic_gbps": round(trace_bytes / (trace_ms * 1e-3) / 1e9, 1),
-                "algorithmic_over_hbm_peak": round(trace_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "pmc_source": "profiles/r03/pmc_roofline.json" if pmc else None, "pmc_note": pmc_note,
+                "algorithmic_bytes_per_launch": int(trace_bytes / n_launches),
+                "algorithmic_gbps": round(trace_bytes / (trace_ms_total * 1e-3) / 1e9, 1),
+                "algorithmic_over_hbm_peak": round(trace_bytes / (trace_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pmc_source": pmc_file, "pmc_key": pmc_key, "pmc_scaled_by": round(scale, 4) if scale else None, "pmc_note": pmc_note if not pmc else None,
                 "counters": ("achieved, traffic, l2_frac, l1_tag_lookups and valu_* are DERIVED FROM COMMITTED rocprofv3 counter passes of this command "
-                             "(checked against this run: workload, kernel revision, triangles, queue length); avg_launch_ms, clock_mhz, lane_util, per_ray, schedule "
-                             "and algorithmic_* are measured by this process") if pmc else None,
+                             "(checked against this run: workload, kernel revision, triangles; scaled by rays traced, pmc_scaled_by); avg_launch_ms, clock_mhz, lane_util "
+                             "node / triangle loop, per_ray, schedule and algorithmic_* are measured by this process") if pmc else None,
                 "layout": {"bvh": int(sstats.bvhLayoutVersion), "wide": int(sstats.wideLayoutVersion)}}
             if pmc and pmc.get("kernels", {}).get("k_shadow_gen_oct") and (kern_iso or own_launch):
                 # the one kernel of the frame that IS bound by HBM: it writes the ray queue (20 B per ray + 16 B per pixel-sample) as fast as the memory takes it
                 g = pmc["kernels"]["k_shadow_gen_oct"]
-                gen_ms = (kern["shadow_gen"] / n) * launch_frames if own_launch else kern_iso["shadow_gen"]
-                gbytes = g["read_bytes"] + g["write_bytes"]
+                gen_ms = (kern["shadow_gen"] / n_launches) if own_launch else kern_iso["shadow_gen"]
+                gbytes = (g["read_bytes"] + g["write_bytes"]) * scale
                 roofline2 = {"bound": "hbm", "kernel": "k_shadow_gen_oct: shadow-ray generation into the queue binned by direction octant",
                              "achieved": round(gbytes / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "frac_of_measured_copy_rate": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS, 4),
-                             "traffic": gbytes, "read_bytes": g["read_bytes"], "write_bytes": g["write_bytes"],
-                             "algorithmic_bytes_per_launch": int(20 * sched["shadow_rays"] + (20 + 16) * fs.numPrimaryRays) * launch_frames,      # 20-B ray records + 16-B origins out, 20-B hit records in
-                             "frames_per_launch": launch_frames,
+                             "traffic": int(gbytes), "read_bytes": int(g["read_bytes"] * scale), "write_bytes": int(g["write_bytes"] * scale),
+                             "algorithmic_bytes_per_launch": int((20 * sched["shadow_rays"] + (20 + 16) * primary_per_frame / max(K, 1) / max(world, 1)) * launch_frames),      # 20-B ray records + 16-B origins out, 20-B hit records in
+                             "frames_per_launch": round(launch_frames, 2),
                              "avg_launch_ms": round(gen_ms, 4), "avg_launch_ms_source": "HIP events on the launch stream, " + ("timed region (one launch at a time)" if own_launch else "frames rendered one at a time (this run)"),
-                             "counters": "bytes from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; FETCH_SIZE's streamed part doubled, gfx950), duration from this run"}
+                             "counters": "bytes from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; FETCH_SIZE's streamed part doubled, gfx950), scaled by rays; duration from this run"}
                 fb = pmc.get("frame_hbm_bytes")
-                fb = fb / launch_frames if fb else fb          # the counters are per launch
-                frame_hbm = {"bytes_per_frame": int(fb) if fb else None, "per_kernel_per_launch": {kk: vv["read_bytes"] + vv["write_bytes"] for kk, vv in pmc["kernels"].items()},
+                fb = fb * scale / launch_frames if fb else fb          # the counters are per launch
+                frame_hbm = {"bytes_per_frame": int(fb) if fb else None, "per_kernel_per_launch": {kk: int((vv["read_bytes"] + vv["write_bytes"]) * scale) for kk, vv in pmc["kernels"].items()},
                              "gbps_at_ms_per_step": round(fb / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(fb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "scope": "sum of the frame's four kernels' HBM bytes (committed counter passes) over this run's frame time with frames in flight"} if fb else None
+                             "scope": "sum of the frame's four kernels' HBM bytes (committed counter passes, scaled by rays) over this run's frame time"} if fb else None
         elif trace_ms == 0 and kern["primary"] > 0:
             mk_ms = kern["primary"] / n
-            achieved = fs.algorithmicBytes / (mk_ms * 1e-3) / 1e9
+            achieved = alg_bytes_mean / (mk_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "k_megakernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                        "algorithmic_bytes_per_launch": int(fs.algorithmicBytes), "avg_launch_ms": round(mk_ms, 4),
+                        "algorithmic_bytes_per_launch": int(alg_bytes_mean), "avg_launch_ms": round(mk_ms, 4),
                         "bvh_layout_version": int(sstats.bvhLayoutVersion)}
         out = {
             "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S, K) == (1920, 1080, 1, 1) else f"Mrays/sec at {W}x{H} {S}spp" + (f" x{K} frames accumulated in HDR" if K > 1 else ""),
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / K, 4), "higher_is_better": True,
+            # a launch renders frames_per_launch frames and they are ready together when it ends: the age of the first of them, and how
+            # far ahead the cameras had to be known (one_frame_at_a_time below: the same frames with one frame per launch)
+            "frames_per_launch": B, "frame_latency_ms": round(B * ms_per_step, 4), "latency": latency,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("file " + args.obj) if args.obj else "synthetic",
             "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
                                    f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{world}",
-                       "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame,
+                       "camera": ("a new view every frame: scripted walk (W / S held, cursor drifting; applyInput = Window::processInput), period %d frames" % PATH_PERIOD) if cams.mode == "path" else "static: every frame the same view",
+                       "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame, "rays_per_frame_is": "mean over the frames of the timed region (the counting form, one pass per view)",
                        "pipeline": "wavefront" if pipeline_used == 2 else "megakernel",
                        "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries),
                                "build_ms": round(float(sstats.buildMs), 1)}},
-            "primary_mrays_per_s": round(primary_per_frame * args.steps / elapsed / 1e6, 2),
+            "primary_mrays_per_s": round(primary_total / elapsed / 1e6, 2),
             "frames_in_flight": nbuf,
-            "frames_per_launch": B, "timed_launches": launch_sizes(args.steps, B),
+            "timed_launches": launch_sizes(args.steps, B),
             "kernels_ms": {k: round(v, 4) for k, v in kern_iso.items()} if kern_iso else {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
             "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"} if kern_iso else None,
-            "one_frame_at_a_time": {"ms_per_step": round(iso_ms_per_frame, 4), "mrays_per_s": round(fs.numRays * K / iso_ms_per_frame / 1e3, 2),
-                                    "frames": args.isolated_frames, "scope": "rank 0's shard, no gather"} if iso_ms_per_frame else None,
-            "algorithmic_gbps_all_kernels": round(counts[3].item() * K / (ms_per_step * 1e-3) / 1e9, 2),
+            "one_frame_at_a_time": {"ms_per_step": round(iso_ms_per_frame, 4), "mrays_per_s": round(iso_rays / args.isolated_frames * K / iso_ms_per_frame / 1e3, 2),
+                                    "frames": args.isolated_frames, "frame_latency_ms": round(iso_ms_per_frame, 4),
+                                    "scope": "rank 0's shard, no gather; one launch per frame, joined before the next (the reference's loop: application.cppm:352-389)"} if iso_ms_per_frame else None,
+            "algorithmic_gbps_all_kernels": round(alg_bytes_mean * K / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": roofline,
             "roofline_secondary": roofline2,
             "frame_hbm": frame_hbm,

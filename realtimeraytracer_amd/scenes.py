@@ -339,15 +339,33 @@ def write_sponza_class(directory=None):
 # Scene set-ups (host scene + camera), one per BASELINE config family
 # ---------------------------------------------------------------------------------------------
 class SceneSetup:
-    def __init__(self, name, hscene, camera, cam_pos, width, height):
+    def __init__(self, name, hscene, camera, cam_pos, width, height, cam_args=None, walk_scale=1.0):
         self.name, self.host, self.camera_obj, self.cam_pos = name, hscene, camera, cam_pos
         self.width, self.height = width, height
         self.desc = hscene.desc
         self.camera = camera.getGPUData()
         self.num_lights = hscene.numLights()
+        self.cam_args, self.walk_scale = cam_args, walk_scale      # (fovY, position, lookAt, up) the camera was made with; CAM_SPEED factor of camera_path()
 
-    def scene_info(self, frame=0):
-        return host.scene_info(frame, self.num_lights, self.cam_pos)
+    def scene_info(self, frame=0, cam_pos=None):
+        return host.scene_info(frame, self.num_lights, self.cam_pos if cam_pos is None else cam_pos)
+
+    def camera_path(self, n, half_period=96):
+        """n cameras of a scripted walk, one per frame, made the way the reference's loop makes them: Window::processInput + the mouse
+        callback applied to the scene::Camera once per frame (src/app/window.cppm:68-133 = csrc/host/input.hpp applyInput), then
+        Camera::updateGPUData.  The script: W held with the cursor drifting right for `half_period` frames, then S held with the cursor
+        drifting left, and so on — a walk down the nave and back with the view swinging a few degrees, bounded for any n.  CAM_SPEED is the
+        reference's 10.5 per frame times the scene's walk_scale (the reference's scene is ~3000 units long, like the Sponza-class one).
+        Returns [(RtrCameraData, position)]."""
+        fov, pos, look, up = self.cam_args
+        cam = host.Camera(fov, pos, look, up, self.width, self.height)
+        out = []
+        for i in range(n):
+            d = cam.getGPUData()
+            out.append((d, (float(d.position[0]), float(d.position[1]), float(d.position[2]))))
+            fwd = (i // half_period) % 2 == 0
+            cam.applyInput("W" if fwd else "S", mouse=(0.6 if fwd else -0.6, 0.0), cam_speed=10.5 * self.walk_scale)
+        return out
 
 
 def synthetic_ltc():
@@ -385,7 +403,7 @@ def cornell_box(width=256, height=256, directory=None, ltc=None):
     hs.build()
     pos = (278.0, 273.0, -800.0)
     cam = host.Camera(40.0, pos, (278.0, 273.0, 0.0), (0.0, 1.0, 0.0), width, height)
-    return SceneSetup("cornell", hs, cam, pos, width, height)
+    return SceneSetup("cornell", hs, cam, pos, width, height, cam_args=(40.0, pos, (278.0, 273.0, 0.0), (0.0, 1.0, 0.0)), walk_scale=0.2)
 
 
 def bunny_class(width=1920, height=1080, directory=None, subdiv=6, ltc=None):
@@ -401,7 +419,7 @@ def bunny_class(width=1920, height=1080, directory=None, subdiv=6, ltc=None):
     hs.build()
     pos = (0.0, 220.0, -520.0)
     cam = host.Camera(45.0, pos, (0.0, 120.0, 0.0), (0.0, 1.0, 0.0), width, height)
-    return SceneSetup("bunny_class", hs, cam, pos, width, height)
+    return SceneSetup("bunny_class", hs, cam, pos, width, height, cam_args=(45.0, pos, (0.0, 120.0, 0.0), (0.0, 1.0, 0.0)), walk_scale=0.1)
 
 
 def sponza_class(width=1920, height=1080, directory=None, ltc=None):
@@ -420,7 +438,7 @@ def sponza_class(width=1920, height=1080, directory=None, ltc=None):
     hs.build()
     pos = (-1250.0, 420.0, 60.0)
     cam = host.Camera(60.0, pos, (300.0, 380.0, -20.0), (0.0, 1.0, 0.0), width, height)
-    return SceneSetup("sponza_class", hs, cam, pos, width, height)
+    return SceneSetup("sponza_class", hs, cam, pos, width, height, cam_args=(60.0, pos, (300.0, 380.0, -20.0), (0.0, 1.0, 0.0)), walk_scale=1.0)
 
 
 def custom_obj(obj_path, mtl_dir, cam_pos, look_at, fov_y=60.0, width=1920, height=1080, lights=()):
@@ -432,7 +450,7 @@ def custom_obj(obj_path, mtl_dir, cam_pos, look_at, fov_y=60.0, width=1920, heig
     hs.setSky((0.5, 0.7, 1.0))
     hs.build()
     cam = host.Camera(fov_y, cam_pos, look_at, (0.0, 1.0, 0.0), width, height)
-    return SceneSetup(os.path.basename(obj_path), hs, cam, cam_pos, width, height)
+    return SceneSetup(os.path.basename(obj_path), hs, cam, cam_pos, width, height, cam_args=(fov_y, cam_pos, look_at, (0.0, 1.0, 0.0)), walk_scale=0.0)
 
 
 def file_sha256(path):

@@ -37,8 +37,15 @@ def test_bench_line_keeps_the_contract(scene_cache):
         assert k in r, k
     assert r["bound"] == "valu_issue" and r["avg_launch_ms"] > 0 and 1500 < r["clock_mhz"] < 2600
     # up to thirty-two frames per launch of every kernel by default, a run cut into equal launches; the roofline is that of the launches of the timed region
-    assert d["frames_per_launch"] == 32 and d["frames_in_flight"] == 32 and d["timed_launches"] == [12] and r["frames_per_launch"] == 12
+    assert d["frames_per_launch"] == 32 and d["frames_in_flight"] == 32 and d["timed_launches"] == [12] and r["frames_per_launch"] == 12, (d["frames_per_launch"], d["latency"])
     assert abs(r["avg_ms_per_frame"] * 12 - r["avg_launch_ms"]) < 1e-3 and r["one_frame_launch_ms"] > 0
+    # a frame time beside the rate: the launch's duration is the age of its first frame; the launch size was chosen under the latency bound
+    # (a 640x360 frame: thirty-two of them fit one 60-Hz refresh), every frame of the timed region a new view along the scripted walk
+    assert abs(d["frame_latency_ms"] - d["frames_per_launch"] * d["ms_per_step"]) < 1e-3 and d["latency"]["limit_ms"] == 16.7 and d["latency"]["chosen_by"] == "probe"
+    assert all(p_["launch_ms"] > 0 for p_ in d["latency"]["probes"]) and d["latency"]["probes"][-1]["frames"] == d["frames_per_launch"]
+    assert d["latency"]["probes"][-1]["launch_ms"] <= 16.7 and "scripted walk" in d["config"]["camera"]
+    assert d["one_frame_at_a_time"]["frame_latency_ms"] == d["one_frame_at_a_time"]["ms_per_step"] > 0
+    assert "frac_useful" in r and "issue_cycles_per_inst_measured" in r
     assert r["frac"] is None or 0 < r["frac"] <= 1.05          # counters are committed for the default workload only (pmc_note says so otherwise)
     assert 0 < r["lane_util"]["node_loop"] <= 1 and 0 < r["lane_util"]["triangle_loop"] <= 1
     c = d["cpu_baseline"]

@@ -72,3 +72,27 @@ def test_a_run_is_cut_into_equal_launches():
         for b in (1, 2, 8, 16):
             sz = bench.launch_sizes(count, b)
             assert sum(sz) == count and max(sz) <= b and max(sz) - min(sz) <= 1 and len(sz) == -(-count // b)
+
+
+def test_frames_per_launch_under_a_latency_bound():
+    """bench.py --max-latency-ms: the largest launch whose measured duration fits, found with a handful of probes (no GPU: the launch
+    time is a function here)."""
+    import bench
+    for model, want in ((lambda c: 0.4 + 2.1 * c, 7), (lambda c: 0.5 + 0.28 * c, 32), (lambda c: 3 + 30.0 * c, 1), (lambda c: 4 + 1.0 * c, 12), (lambda c: 2.05 * c, 8)):
+        calls = []
+
+        def timed(c, model=model, calls=calls):
+            calls.append(c)
+            return model(c)
+        got = bench.pick_frames_per_launch(16.7, 32, timed)
+        assert got == want and len(calls) <= 6, (got, want, calls)
+        assert model(got) <= 16.7 or got == 1
+        assert got == 32 or model(got + 1) > 16.7
+    # the camera of frame i: a period of bench.PATH_PERIOD views, or one view
+    class S:
+        cam_args, walk_scale, camera = (60.0, (0, 0, 0), (1, 0, 0), (0, 1, 0)), 1.0, "still"
+        def camera_path(self, n): return [("view%d" % i, (float(i), 0.0, 0.0)) for i in range(n)]
+        def scene_info(self, frame, cam_pos=None): return (frame, cam_pos)
+    moving, still = bench.CameraSource(S(), "path"), bench.CameraSource(S(), "static")
+    assert moving.mode == "path" and moving.camera(5) == "view5" and moving.camera(bench.PATH_PERIOD + 5) == "view5" and moving.info(7) == (7, (7.0, 0.0, 0.0))
+    assert moving.info(7, 3) == (3, (7.0, 0.0, 0.0)) and still.mode == "static" and still.camera(9) == "still" and still.info(9) == (9, None) and still.index(9) == 0
