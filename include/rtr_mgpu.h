@@ -55,9 +55,9 @@ int  rtr_mgpu_scene_create(rtr_mgpu* m, const rtr_scene_desc* desc);
 #define RTR_MGPU_NO_EXCHANGE 1
 int  rtr_mgpu_render_async(rtr_mgpu* m, int slot, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo, const rtr_render_params* params, int flags);
 /* n frames into n distinct slots with ONE launch of the pipeline per rank (rtr_render_batch_async: a 1/N shard of a 1-spp frame is
- * too little work per launch — one rank of eight renders a frame in 0.39 ms one launch per frame and in 0.35 ms four per launch), then
- * every slot's own exchange.  Every slot of the batch executes the same plan (rtr_mgpu_plan), interleaved: the operations before
- * RENDER for every slot, one RENDER on the first slot's render stream, the rest slot by slot.  n <= RTR_MAX_BATCH. */
+ * too little work per launch — one rank of eight renders a frame in 0.39 ms one launch per frame and in 0.35 ms four per launch) and
+ * ONE exchange for the launch: every slot's shards in one RCCL group (rtr_mgpu_plan_batch is the list that is carried out), then a
+ * de-interleave per slot.  n <= RTR_MAX_BATCH. */
 int  rtr_mgpu_render_batch_async(rtr_mgpu* m, const int* slots, int n, const RtrCameraData* cameras, const RtrSceneInfo* sceneInfos,
                                  const rtr_render_params* params, int flags);
 int  rtr_mgpu_wait(rtr_mgpu* m, int slot);
@@ -127,7 +127,7 @@ typedef struct rtr_mgpu_op {
     int32_t  peer;
     int32_t  buffer;     /* rtr_mgpu_buffer */
     int32_t  event;      /* rtr_mgpu_event */
-    int32_t  _pad;
+    int32_t  slot;       /* which frame slot of the launch the operation is about: an index 0 .. nslots-1 into the slots the launch was given (0 in a one-frame plan) */
     uint64_t offset;
     uint64_t bytes;
 } rtr_mgpu_op;
@@ -138,6 +138,13 @@ typedef struct rtr_mgpu_op {
  * when maxOps is too small. */
 int  rtr_mgpu_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange,
                    rtr_mgpu_op* ops, int maxOps, int* numOps);
+/* The plan of a launch of `nslots` frames (rtr_mgpu_render_batch_async; nslots = 1 is rtr_mgpu_plan): the WAITs of every slot, ONE
+ * RENDER (slot 0 leads), one render -> communication edge, ONE group holding every slot's transfers in slot order — on rank 0 the
+ * (nranks - 1) receives of slot 0, then of slot 1 ...; on the others one send per slot — then a DEINTERLEAVE and a RECORD per slot.
+ * At most RTR_MGPU_BATCH_PLAN_MAX_OPS operations. */
+#define RTR_MGPU_BATCH_PLAN_MAX_OPS (6 + RTR_MAX_BATCH * (3 + RTR_MGPU_MAX_RANKS))
+int  rtr_mgpu_plan_batch(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, int nslots,
+                         rtr_mgpu_op* ops, int maxOps, int* numOps);
 
 /* Watchdog of rtr_mgpu_wait: a slot whose exchange has not finished after this many milliseconds is given up — every local
  * communicator is aborted (ncclCommAbort releases peers blocked in a send / recv that will never be matched), the handle refuses

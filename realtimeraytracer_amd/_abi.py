@@ -219,7 +219,7 @@ class rtr_mgpu_info(C.Structure):
 class rtr_mgpu_op(C.Structure):
     """one operation of rtr_mgpu_plan (include/rtr_mgpu.h)"""
     _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("peer", C.c_int32), ("buffer", C.c_int32), ("event", C.c_int32),
-                ("_pad", C.c_int32), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+                ("slot", C.c_int32), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 MGPU_OP_WAIT, MGPU_OP_RENDER, MGPU_OP_RECORD, MGPU_OP_GROUP_START, MGPU_OP_RECV, MGPU_OP_SEND, MGPU_OP_GROUP_END, MGPU_OP_DEINTERLEAVE = range(1, 9)
@@ -228,6 +228,7 @@ MGPU_BUF_NONE, MGPU_BUF_LOCAL, MGPU_BUF_GATHER, MGPU_BUF_SELF_SRC, MGPU_BUF_FULL
 MGPU_EV_NONE, MGPU_EV_RENDER_DONE, MGPU_EV_COMM_DONE = range(3)
 MGPU_PLAN_MAX_OPS = 32
 MGPU_MAX_RANKS = 16
+MGPU_BATCH_PLAN_MAX_OPS = 6 + 32 * (3 + MGPU_MAX_RANKS)
 
 
 MAX_BATCH = 32
@@ -253,6 +254,7 @@ MGPU_SYMBOLS = {
     "rtr_mgpu_frame_stats": (C.c_int, [VP, C.c_int, C.c_int, P(rtr_frame_stats)]),
     "rtr_mgpu_get_info": (C.c_int, [VP, P(rtr_mgpu_info)]),
     "rtr_mgpu_plan": (C.c_int, [C.c_int, C.c_int, u32, u32, u32, C.c_int, C.c_int, P(rtr_mgpu_op), C.c_int, P(C.c_int)]),
+    "rtr_mgpu_plan_batch": (C.c_int, [C.c_int, C.c_int, u32, u32, u32, C.c_int, C.c_int, C.c_int, P(rtr_mgpu_op), C.c_int, P(C.c_int)]),
     "rtr_mgpu_set_timeout_ms": (C.c_int, [VP, u32]),
     "rtr_mgpu_last_error": (C.c_char_p, []),
 }

@@ -89,7 +89,9 @@ struct Rank {
     rtr_ctx* commCtx = nullptr;       /* one more context whose stream is the communication stream (RCCL ops, k_deinterleave) */
     hipStream_t commStream = nullptr;
     rtr_scene* scene = nullptr;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;        /* written when the rank is made and in destroy_rank (after its worker has joined), read by the worker in between */
+    std::atomic<bool> inRccl{false};  /* the worker is inside (or about to enter) an RCCL call on `comm` */
+    std::atomic<bool> commAborted{false};     /* ncclCommAbort was called on `comm`: it is gone, destroy_rank must not destroy it again */
     Slot slots[RTR_MGPU_MAX_SLOTS];
     std::unique_ptr<Worker> worker;
     /* what this rank's worker is doing right now (a string literal): the watchdog of rtr_mgpu_wait names it when it gives up, so a
@@ -107,7 +109,7 @@ struct Rank {
 struct rtr_mgpu {
     int nranks = 0, framesInFlight = 1;
     bool selfExchange = false;
-    bool aborted = false;                           /* the communicators were aborted: the handle only waits for / frees things now */
+    std::atomic<bool> aborted{false};               /* the communicators were aborted: the handle only waits for / frees things now; workers issue no further RCCL call */
     uint32_t timeoutMs = 120000;
     std::vector<std::unique_ptr<Rank>> ranks;       /* the local ones */
 };
@@ -174,42 +176,48 @@ int prepare_slot(rtr_mgpu* m, Rank& r, Slot& s, const rtr_render_params& p, std:
     return RTR_OK;
 }
 
-/* The plan (include/rtr_mgpu.h): what `rank` of `nranks` enqueues for one frame, in order. */
-int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, std::vector<rtr_mgpu_op>& ops) {
-    if (nranks < 1 || nranks > RTR_MGPU_MAX_RANKS || rank < 0 || rank >= nranks || width == 0 || height == 0) return RTR_ERR_INVALID_ARGUMENT;
+/* The plan (include/rtr_mgpu.h): what `rank` of `nranks` enqueues for one launch of `nslots` frames, in order.  ONE exchange per
+ * launch: the shards of all its slots travel in one ncclGroupStart / ncclGroupEnd — on rank 0 the (N - 1) x nslots receives, on the
+ * others nslots sends, slot by slot (RCCL matches the transfers between a pair of ranks in posting order) — not one group per slot:
+ * a launch of sixteen shards at N = 8 is one RCCL launch on the rank that also renders and de-interleaves, not sixteen. */
+int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, int nslots, std::vector<rtr_mgpu_op>& ops) {
+    if (nranks < 1 || nranks > RTR_MGPU_MAX_RANKS || rank < 0 || rank >= nranks || width == 0 || height == 0 || nslots < 1 || nslots > RTR_MAX_BATCH) return RTR_ERR_INVALID_ARGUMENT;
     if (bandRows == 0) bandRows = 8;
     const uint64_t shardBytes = (uint64_t)rtr_shard_rows(height, bandRows, (uint32_t)nranks) * width * 4u;
     const bool self = selfExchange && nranks == 1;
-    auto op = [&](int kind, int stream, int peer, int buffer, int event, uint64_t offset, uint64_t bytes) {
+    auto op = [&](int kind, int stream, int slot, int peer, int buffer, int event, uint64_t offset, uint64_t bytes) {
         rtr_mgpu_op o; memset(&o, 0, sizeof o);
-        o.kind = kind; o.stream = stream; o.peer = peer; o.buffer = buffer; o.event = event; o.offset = offset; o.bytes = bytes;
+        o.kind = kind; o.stream = stream; o.slot = slot; o.peer = peer; o.buffer = buffer; o.event = event; o.offset = offset; o.bytes = bytes;
         ops.push_back(o);
     };
     ops.clear();
-    /* the slot's previous exchange must be done with the buffers this render overwrites */
-    op(RTR_MGPU_OP_WAIT, RTR_MGPU_STREAM_RENDER, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
-    /* rank 0 renders straight into its place (shard 0) of the gather buffer */
-    op(RTR_MGPU_OP_RENDER, RTR_MGPU_STREAM_RENDER, rank, rank == 0 ? (self ? RTR_MGPU_BUF_SELF_SRC : RTR_MGPU_BUF_GATHER) : RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
+    /* every slot's previous exchange must be done with the buffers this render overwrites */
+    for (int j = 0; j < nslots; ++j) op(RTR_MGPU_OP_WAIT, RTR_MGPU_STREAM_RENDER, j, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
+    /* ONE render of all the launch's shards (slot 0 leads: its render stream is "the render stream" of the launch); rank 0 renders
+     * every shard straight into its place (shard 0) of that slot's gather buffer */
+    op(RTR_MGPU_OP_RENDER, RTR_MGPU_STREAM_RENDER, 0, rank, rank == 0 ? (self ? RTR_MGPU_BUF_SELF_SRC : RTR_MGPU_BUF_GATHER) : RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
     if (flags & RTR_MGPU_NO_EXCHANGE) return RTR_OK;
-    op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_RENDER, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_RENDER_DONE, 0, 0);
-    op(RTR_MGPU_OP_WAIT, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_RENDER_DONE, 0, 0);
-    /* the one exchange step: every other rank's shard -> rank 0 (xGMI: one direct link per peer), grouped so that RCCL posts all
+    op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_RENDER, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_RENDER_DONE, 0, 0);
+    op(RTR_MGPU_OP_WAIT, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_RENDER_DONE, 0, 0);
+    /* the one exchange step: every other rank's shards -> rank 0 (xGMI: one direct link per peer), grouped so that RCCL posts all
      * of a rank's transfers together — a send and a receive that depend on each other and sit one behind the other on a stream
      * never complete */
     if (nranks > 1 || self) {
-        op(RTR_MGPU_OP_GROUP_START, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
-        if (self) {
-            op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, 0, RTR_MGPU_BUF_SELF_SRC, RTR_MGPU_EV_NONE, 0, shardBytes);
-            op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, 0, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, 0, shardBytes);
-        } else if (rank == 0) {
-            for (int src = 1; src < nranks; ++src) op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, src, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, shardBytes * (uint64_t)src, shardBytes);
-        } else {
-            op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, 0, RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
+        op(RTR_MGPU_OP_GROUP_START, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
+        for (int j = 0; j < nslots; ++j) {
+            if (self) {
+                op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, j, 0, RTR_MGPU_BUF_SELF_SRC, RTR_MGPU_EV_NONE, 0, shardBytes);
+                op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, j, 0, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, 0, shardBytes);
+            } else if (rank == 0) {
+                for (int src = 1; src < nranks; ++src) op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, j, src, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, shardBytes * (uint64_t)src, shardBytes);
+            } else {
+                op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, j, 0, RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
+            }
         }
-        op(RTR_MGPU_OP_GROUP_END, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
+        op(RTR_MGPU_OP_GROUP_END, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
     }
-    if (rank == 0) op(RTR_MGPU_OP_DEINTERLEAVE, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_FULL, RTR_MGPU_EV_NONE, 0, (uint64_t)width * height * 4u);     /* one rank: a plain copy */
-    op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_COMM, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
+    if (rank == 0) for (int j = 0; j < nslots; ++j) op(RTR_MGPU_OP_DEINTERLEAVE, RTR_MGPU_STREAM_COMM, j, -1, RTR_MGPU_BUF_FULL, RTR_MGPU_EV_NONE, 0, (uint64_t)width * height * 4u);     /* one rank: a plain copy */
+    for (int j = 0; j < nslots; ++j) op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_COMM, j, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
     return RTR_OK;
 }
 
@@ -222,11 +230,9 @@ struct BatchJob {                     /* what one call renders: n frames into n 
     int flags = 0;
 };
 
-/* Carries the plan out on this rank's streams; the slots are prepared (prepare_slot) before this runs.  Every slot of the batch has
- * the SAME plan (rtr_mgpu_plan).  They are executed interleaved: the operations before RENDER for every slot (each slot's previous
- * exchange must be done with the buffers the launch overwrites), ONE render of all the batch's shards — on the first slot's
- * render stream, which is "the render stream" of every slot's plan for this batch — then the rest of each slot's plan (its own
- * events, its own exchange). */
+/* Carries the launch's plan out on this rank's streams; the slots are prepared (prepare_slot) before this runs.  A plain walk over
+ * the list rtr_mgpu_plan_batch returns for (rank, nranks, extent, flags, number of slots): operation by operation, each on the slot
+ * its `slot` field names (an index into the launch's slots) — there is no second description of the exchange beside that list. */
 int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
     struct Clock {
         Rank& r; int frames; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -237,14 +243,20 @@ int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
     rtr_render_params p = job.p;
     for (int j = 0; j < job.n; ++j) if (!slot_matches(m, r.slots[job.slots[j]], p)) { err = "internal: slot not prepared for this extent"; return RTR_ERR_INVALID_ARGUMENT; }
     std::vector<rtr_mgpu_op> ops;
-    if (make_plan(r.rank, m->nranks, p.width, p.height, p.bandRows, job.flags, m->selfExchange ? 1 : 0, ops) != RTR_OK) { err = "internal: no plan for this rank / extent"; return RTR_ERR_INVALID_ARGUMENT; }
-    size_t renderAt = ops.size();
-    for (size_t i = 0; i < ops.size(); ++i) if (ops[i].kind == RTR_MGPU_OP_RENDER) { renderAt = i; break; }
-    if (renderAt == ops.size()) { err = "internal: a plan without a render"; return RTR_ERR_INVALID_ARGUMENT; }
+    if (make_plan(r.rank, m->nranks, p.width, p.height, p.bandRows, job.flags, m->selfExchange ? 1 : 0, job.n, ops) != RTR_OK) { err = "internal: no plan for this rank / extent"; return RTR_ERR_INVALID_ARGUMENT; }
     hipStream_t renderStream = r.renderStream[job.slots[0]];
     bool inGroup = false;
-    int rc = RTR_OK;
-    auto run = [&](Slot& s, const rtr_mgpu_op& o) -> int {
+    /* an RCCL call is made only while the handle is not being aborted: the watchdog (abort_all, on the caller's thread) first raises
+     * `aborted`, then waits for this flag to drop before it gives the communicator up — so a call never STARTS on a communicator
+     * that is gone; one that is blocked inside RCCL at that moment is what ncclCommAbort is allowed to interrupt */
+    struct InRccl {
+        Rank& r; bool ok;
+        InRccl(Rank& rr, rtr_mgpu* mm) : r(rr) { r.inRccl.store(true); ok = !mm->aborted.load(); if (!ok) r.inRccl.store(false); }
+        ~InRccl() { if (ok) r.inRccl.store(false); }
+    };
+    for (const rtr_mgpu_op& o : ops) {
+        if (o.slot < 0 || o.slot >= job.n) { err = "internal: the plan names a slot outside the launch"; return RTR_ERR_INVALID_ARGUMENT; }
+        Slot& s = r.slots[job.slots[o.slot]];
         auto buffer = [&](int which) -> char* {
             switch (which) {
                 case RTR_MGPU_BUF_LOCAL: return static_cast<char*>(s.local);
@@ -264,15 +276,16 @@ int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
                 if (o.event == RTR_MGPU_EV_COMM_DONE && !s.commPending) break;       /* first use of the slot */
                 he = hipStreamWaitEvent(st, ev, 0);
                 break;
-            case RTR_MGPU_OP_RENDER: {              /* once per batch: s is the first slot */
+            case RTR_MGPU_OP_RENDER: {              /* once per launch: every slot's shard, led by slot 0 */
                 r.stage = "rtr_render_batch_async";
                 rtr_frame* frames[RTR_MAX_BATCH];
-                for (int j = 0; j < job.n; ++j) {
+                for (int j = 0; j < job.n && c == RTR_OK; ++j) {
                     Slot& sj = r.slots[job.slots[j]];
                     char* target = o.buffer == RTR_MGPU_BUF_LOCAL ? static_cast<char*>(sj.local) : (o.buffer == RTR_MGPU_BUF_GATHER ? reinterpret_cast<char*>(sj.gathered) : reinterpret_cast<char*>(sj.selfSrc));
-                    if (target + o.offset != static_cast<char*>(sj.local)) { err = "internal: the frame is not bound to the buffer the plan renders into"; return RTR_ERR_INVALID_ARGUMENT; }
+                    if (target + o.offset != static_cast<char*>(sj.local)) { err = "internal: the frame is not bound to the buffer the plan renders into"; c = RTR_ERR_INVALID_ARGUMENT; }
                     frames[j] = sj.frame;
                 }
+                if (c != RTR_OK) break;
                 p.shardIndex = (uint32_t)o.peer; p.shardCount = (uint32_t)m->nranks;
                 p.images = s.images; p.collectStats = 0;
                 if (!(s.images & RTR_IMG_BIT(RTR_IMAGE_HDR))) { p.accumulate = 0; p.accumulatedFrames = 0; }
@@ -287,6 +300,8 @@ int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
                 break;
             case RTR_MGPU_OP_GROUP_START: case RTR_MGPU_OP_RECV: case RTR_MGPU_OP_SEND: case RTR_MGPU_OP_GROUP_END: {
                 const auto t0 = std::chrono::steady_clock::now();
+                InRccl guard(r, m);
+                if (!guard.ok) { err = "the communicators are being aborted"; c = RTR_ERR_HIP; inGroup = false; break; }     /* (an open group dies with the communicator) */
                 if (o.kind == RTR_MGPU_OP_GROUP_START) { r.stage = "ncclGroupStart"; ne = ncclGroupStart(); inGroup = ne == ncclSuccess; }
                 else if (o.kind == RTR_MGPU_OP_RECV) { r.stage = "ncclRecv"; ne = ncclRecv(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); }
                 else if (o.kind == RTR_MGPU_OP_SEND) { r.stage = "ncclSend"; ne = ncclSend(buffer(o.buffer) + o.offset, o.bytes, ncclUint8, o.peer, r.comm, st); }
@@ -303,17 +318,10 @@ int enqueue(rtr_mgpu* m, Rank& r, const BatchJob& job, std::string& err) {
         }
         if (he != hipSuccess) { err = std::string(r.stage.load()) + ": " + hipGetErrorString(he); c = RTR_ERR_HIP; }
         if (ne != ncclSuccess) { err = std::string(r.stage.load()) + ": " + ncclGetErrorString(ne); c = RTR_ERR_HIP; }
-        return c;
-    };
-    /* before the render, for every slot; the render, once; after it, slot by slot */
-    for (int j = 0; j < job.n && rc == RTR_OK; ++j)
-        for (size_t i = 0; i < renderAt && rc == RTR_OK; ++i) rc = run(r.slots[job.slots[j]], ops[i]);
-    if (rc == RTR_OK) rc = run(r.slots[job.slots[0]], ops[renderAt]);
-    for (int j = 0; j < job.n && rc == RTR_OK; ++j)
-        for (size_t i = renderAt + 1; i < ops.size() && rc == RTR_OK; ++i) rc = run(r.slots[job.slots[j]], ops[i]);
-    if (rc != RTR_OK) {
-        if (inGroup) (void)ncclGroupEnd();     /* never leave this thread inside a group */
-        return rc;                              /* the caller aborts the communicators: peers may already have posted their half */
+        if (c != RTR_OK) {
+            if (inGroup && !m->aborted.load()) (void)ncclGroupEnd();     /* never leave this thread inside a group */
+            return c;                                                      /* the caller aborts the communicators: peers may already have posted their half */
+        }
     }
     r.stage = "idle";
     return RTR_OK;
@@ -326,7 +334,8 @@ void destroy_rank(Rank& r) {
     for (int sl = 0; sl < RTR_MGPU_MAX_SLOTS; ++sl) if (r.renderStream[sl]) (void)hipStreamSynchronize(r.renderStream[sl]);
     for (int s = 0; s < RTR_MGPU_MAX_SLOTS; ++s) release_slot(r, r.slots[s]);
     if (r.scene) { rtr_scene_destroy(r.scene); r.scene = nullptr; }
-    if (r.comm) { (void)ncclCommDestroy(r.comm); r.comm = nullptr; }
+    if (r.comm && !r.commAborted.load()) (void)ncclCommDestroy(r.comm);       /* (an aborted communicator is already gone) */
+    r.comm = nullptr;
     if (r.commCtx) { rtr_ctx_destroy(r.commCtx); r.commCtx = nullptr; }
     for (int sl = 0; sl < RTR_MGPU_MAX_SLOTS; ++sl) if (r.ctx[sl]) { rtr_ctx_destroy(r.ctx[sl]); r.ctx[sl] = nullptr; }
 }
@@ -371,12 +380,20 @@ void read_env(rtr_mgpu* m) {
     if (const char* t = getenv("RTR_MGPU_TIMEOUT_MS")) m->timeoutMs = (uint32_t)strtoul(t, nullptr, 10);
 }
 
-/* Gives the communicators up: peers blocked in a send / receive that will never be matched are released (ncclCommAbort may be
- * called while another thread is blocked inside a call on the same communicator).  The handle only waits and frees from here on. */
+/* Gives the communicators up: peers blocked in a send / receive that will never be matched are released.  Cooperative with the
+ * ranks' workers: `aborted` is raised first, so a worker makes no further RCCL call (enqueue() checks it before each one); then, per
+ * rank, this waits until the worker is outside RCCL — or, after a grace period, concludes it is blocked inside a call, which is the
+ * one situation ncclCommAbort may be called in from another thread.  The communicator pointer stays as it is (the worker reads it);
+ * destroy_rank, after the worker has joined, knows from commAborted that there is nothing left to destroy. */
 void abort_all(rtr_mgpu* m) {
-    if (m->aborted) return;
-    m->aborted = true;
-    for (auto& rp : m->ranks) if (rp->comm) { (void)ncclCommAbort(rp->comm); rp->comm = nullptr; }
+    if (m->aborted.exchange(true)) return;
+    for (auto& rp : m->ranks) {
+        if (!rp->comm || rp->commAborted.load()) continue;
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+        while (rp->inRccl.load() && std::chrono::steady_clock::now() < until) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        rp->commAborted.store(true);
+        (void)ncclCommAbort(rp->comm);
+    }
 }
 
 std::string stages(const rtr_mgpu* m) {
@@ -418,9 +435,15 @@ int rtr_mgpu_unique_id(void* id) {
 int rtr_mgpu_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange,
                   rtr_mgpu_op* ops, int maxOps, int* numOps) {
     if (!ops || !numOps || maxOps < 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: null argument");
+    return rtr_mgpu_plan_batch(rank, nranks, width, height, bandRows, flags, selfExchange, 1, ops, maxOps, numOps);
+}
+
+int rtr_mgpu_plan_batch(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, int nslots,
+                        rtr_mgpu_op* ops, int maxOps, int* numOps) {
+    if (!ops || !numOps || maxOps < 0) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: null argument");
     std::vector<rtr_mgpu_op> v;
-    if (make_plan(rank, nranks, width, height, bandRows, flags, selfExchange, v) != RTR_OK)
-        return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: rank %d of %d (at most %d), frame %ux%u", rank, nranks, RTR_MGPU_MAX_RANKS, width, height);
+    if (make_plan(rank, nranks, width, height, bandRows, flags, selfExchange, nslots, v) != RTR_OK)
+        return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: rank %d of %d (at most %d), frame %ux%u, %d slots (1 to %d)", rank, nranks, RTR_MGPU_MAX_RANKS, width, height, nslots, RTR_MAX_BATCH);
     if ((int)v.size() > maxOps) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_mgpu_plan: %zu operations, room for %d", v.size(), maxOps);
     memcpy(ops, v.data(), v.size() * sizeof(rtr_mgpu_op));
     *numOps = (int)v.size();
@@ -509,7 +532,7 @@ int rtr_mgpu_get_info(const rtr_mgpu* m, rtr_mgpu_info* out) {
     memset(out, 0, sizeof *out);
     out->nranks = m->nranks; out->nlocal = (int)m->ranks.size(); out->firstRank = m->ranks.empty() ? 0 : m->ranks[0]->rank;
     out->framesInFlight = m->framesInFlight; out->selfExchange = m->selfExchange ? 1 : 0;
-    out->aborted = m->aborted ? 1 : 0; out->timeoutMs = (int)m->timeoutMs;
+    out->aborted = m->aborted.load() ? 1 : 0; out->timeoutMs = (int)m->timeoutMs;
     int v = 0; if (ncclGetVersion(&v) == ncclSuccess) out->rcclVersion = v;
     for (auto& rp : m->ranks) {
         const double ms = (double)rp->enqueueNs.load() * 1e-6;
@@ -639,12 +662,16 @@ int rtr_mgpu_wait(rtr_mgpu* m, int slot) {
             hipError_t e = hipErrorNotReady;
             if (m->timeoutMs == 0 || m->aborted) e = hipEventSynchronize(s.evComm);
             else {
+                /* the first ~50 us a plain spin (a shard of eight is done in a third of a millisecond), then short sleeps that grow to
+                 * 200 us: eight ranks' callers waiting must not hold eight cores against the ranks' enqueue threads */
+                unsigned napUs = 10;
                 for (unsigned spin = 0;; ++spin) {
                     e = hipEventQuery(s.evComm);
                     if (e != hipErrorNotReady) break;
-                    if (spin > 2000u) {        /* ~ the first 50 us are a plain spin */
+                    if (spin > 2000u) {
                         if (std::chrono::steady_clock::now() > deadline) break;
-                        std::this_thread::yield();
+                        std::this_thread::sleep_for(std::chrono::microseconds(napUs));
+                        if (napUs < 200u) napUs += napUs / 2u;
                     }
                 }
             }

@@ -76,13 +76,16 @@ struct Msg {
 
 struct World {
     int n = 0, alive = 0;
+    int users = 0;                   /* operations queued or running that still hold this world (add() takes the reference, run_group() gives it back) */
     bool aborted = false;
     std::mutex mu;
     std::condition_variable cv;
     std::map<std::pair<int, int>, std::deque<Msg*>> posted;      /* (src, dst) -> sends not yet received, in posting order */
 };
 
-struct Op { bool send; void* buf; size_t bytes; int peer; FakeComm* comm; hipStream_t stream; };
+/* an operation keeps what it needs of its communicator BY VALUE (rank, world) and a reference on the world: the communicator may be
+ * aborted — and deleted — by the watchdog's thread while the rank's own thread is still inside ncclGroupEnd */
+struct Op { bool send; void* buf; size_t bytes; int peer; int rank; World* w; hipStream_t stream; };
 thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
 
@@ -99,41 +102,41 @@ int run_group(std::vector<Op>& ops) {
     int rc = 0;
     for (Op& o : ops) if (o.send) {                      /* 1: post every send of the group */
         Msg* m = new Msg{o.buf, o.bytes};
-        if (h.eventCreate(&m->ready, 2u) || h.eventCreate(&m->copied, 2u) || h.eventRecord(m->ready, o.stream)) { fprintf(stderr, "fake rccl: rank %d: event create / record failed\n", o.comm->rank); rc = 1; delete m; break; }
-        World* w = o.comm->w;
-        { std::lock_guard<std::mutex> g(w->mu); w->posted[{o.comm->rank, o.peer}].push_back(m); }
+        if (h.eventCreate(&m->ready, 2u) || h.eventCreate(&m->copied, 2u) || h.eventRecord(m->ready, o.stream)) { fprintf(stderr, "fake rccl: rank %d: event create / record failed\n", o.rank); rc = 1; delete m; break; }
+        World* w = o.w;
+        { std::lock_guard<std::mutex> g(w->mu); w->posted[{o.rank, o.peer}].push_back(m); }
         w->cv.notify_all();
         sent.push_back({&o, m});
     }
     for (Op& o : ops) if (!o.send && rc == 0) {          /* 2: every receive: wait for its send, copy behind it */
-        World* w = o.comm->w;
+        World* w = o.w;
         Msg* m = nullptr;
         {
             std::unique_lock<std::mutex> g(w->mu);
-            auto& q = w->posted[{o.peer, o.comm->rank}];
+            auto& q = w->posted[{o.peer, o.rank}];
             w->cv.wait(g, [&] { return !q.empty() || w->aborted; });
             if (w->aborted) { rc = 1; break; }
             m = q.front(); q.pop_front();
         }
         bool bad = m->bytes != o.bytes;
-        if (bad) fprintf(stderr, "fake rccl: rank %d receives %zu bytes from %d, which sent %zu\n", o.comm->rank, o.bytes, o.peer, m->bytes);
+        if (bad) fprintf(stderr, "fake rccl: rank %d receives %zu bytes from %d, which sent %zu\n", o.rank, o.bytes, o.peer, m->bytes);
         if (!bad) {
             const int e1 = h.streamWaitEvent(o.stream, m->ready, 0u), e2 = e1 ? 0 : h.memcpyAsync(o.buf, m->buf, o.bytes, 3 /* device to device */, o.stream), e3 = (e1 || e2) ? 0 : h.eventRecord(m->copied, o.stream);
             bad = e1 || e2 || e3;
-            if (bad) fprintf(stderr, "fake rccl: rank %d: wait %d copy %d record %d\n", o.comm->rank, e1, e2, e3);
+            if (bad) fprintf(stderr, "fake rccl: rank %d: wait %d copy %d record %d\n", o.rank, e1, e2, e3);
         }
         { std::lock_guard<std::mutex> g(w->mu); m->matched = true; m->failed = bad; }
         w->cv.notify_all();
         if (bad) rc = 4;
     }
     for (auto& sm : sent) {                                /* 3: the sender's stream waits for the copies of what it sent */
-        World* w = sm.first->comm->w;
+        World* w = sm.first->w;
         Msg* m = sm.second;
         {
             std::unique_lock<std::mutex> g(w->mu);
             w->cv.wait(g, [&] { return m->matched || w->aborted; });
             if (!m->matched) {                              /* aborted before anyone took it: withdraw the post */
-                auto& q = w->posted[{sm.first->comm->rank, sm.first->peer}];
+                auto& q = w->posted[{sm.first->rank, sm.first->peer}];
                 for (auto it = q.begin(); it != q.end(); ++it) if (*it == m) { q.erase(it); break; }
                 rc = rc ? rc : 1;
             }
@@ -143,6 +146,12 @@ int run_group(std::vector<Op>& ops) {
         /* the events are left to the runtime: destroying an event other streams still wait on is legal in HIP, but this is a test
          * double that sends a few hundred messages — it keeps them */
         delete m;
+    }
+    for (Op& o : ops) {                                    /* give the references back; the last one out frees a world every communicator of which is gone */
+        World* w = o.w;
+        bool last;
+        { std::lock_guard<std::mutex> g(w->mu); last = --w->users == 0 && w->alive == 0; }
+        if (last) delete w;
     }
     return rc;
 }
@@ -169,11 +178,15 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId, int ra
 }
 static void leave(FakeComm* c, bool abort) {
     World* w = c->w;
-    bool last;
-    { std::lock_guard<std::mutex> g(w->mu); if (abort) w->aborted = true; last = --w->alive == 0; }
-    w->cv.notify_all();
+    bool freeNow;
+    {   /* one critical section decides who frees the world: this call, or the last operation still holding it (run_group) */
+        std::lock_guard<std::mutex> g(w->mu);
+        if (abort) w->aborted = true;
+        freeNow = --w->alive == 0 && w->users == 0;
+        w->cv.notify_all();
+    }
     delete c;
-    if (last) delete w;
+    if (freeNow) delete w;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t c) { if (!c) return 4; leave(c, false); return 0; }
 ncclResult_t ncclCommAbort(ncclComm_t c) { if (!c) return 4; leave(c, true); return 0; }
@@ -187,7 +200,8 @@ ncclResult_t ncclGroupEnd(void) {
 }
 static ncclResult_t add(bool send, void* buf, size_t count, int type, int peer, ncclComm_t c, hipStream_t s) {
     if (!buf || !c || type != 1 /* ncclUint8 */ || peer < 0 || peer >= c->nranks) return 4;
-    Op o{send, buf, count, peer, c, s};
+    Op o{send, buf, count, peer, c->rank, c->w, s};
+    { std::lock_guard<std::mutex> g(c->w->mu); ++c->w->users; }
     if (g_depth > 0) { g_ops.push_back(o); return 0; }
     std::vector<Op> one{o};
     return run_group(one);

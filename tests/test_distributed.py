@@ -76,6 +76,21 @@ def _worker(rank, world, port, cache, out_path):
             ref = O.render(s.desc, s.camera, s.scene_info(f), api.make_params(W, H, spp=2), bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
             diffs.append(int((runner.full() != ref[:H]).sum()))
         dist.barrier()
+    # ... and a LAUNCH of two frames (rtr_mgpu_plan_batch: one render of both shards, ONE group holding both slots' transfers, a
+    # de-interleave per slot), twice through the same two slots
+    def render_slot(index, count, slot):
+        p = api.make_params(W, H, spp=2, shard_index=index, shard_count=count)
+        return O.render(s.desc, s.camera, s.scene_info(frame_no[0] + slot), p, bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
+    brunner = PE.PlanRunner(rank, world, W, H, 8, render_slot, dist, nslots=2)
+    bops = PE.plan_batch(rank, world, W, H, 2, 8)
+    for f in (5, 9):
+        frame_no[0] = f
+        brunner.run(bops)
+        if rank == 0:
+            for slot in (0, 1):
+                ref = O.render(s.desc, s.camera, s.scene_info(f + slot), api.make_params(W, H, spp=2), bvh=(nodes, tris, st.grid), threads=2).images[A.IMAGE_SHADOWED]
+                diffs.append(int((brunner.full(slot) != ref[:H]).sum()))
+        dist.barrier()
     if rank == 0:
         np.save(out_path, np.array(diffs + [H, W]))
     dist.destroy_process_group()
@@ -86,6 +101,6 @@ def test_sharded_frame_equals_single_frame_gloo(world, tmp_path, scene_cache):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.npy")
     mp.spawn(_worker, args=(world, _free_port(), scene_cache, out), nprocs=world, join=True)
-    d1, d2, h, w = np.load(out)
-    assert (h, w) == (52, 96)
-    assert d1 == 0 and d2 == 0, f"{d1} / {d2} pixels differ between the frame assembled by the library's exchange plan and the single frame"
+    *d, h, w = np.load(out)
+    assert (h, w) == (52, 96) and len(d) == 6
+    assert not any(d), f"{d} pixels differ between the frames assembled by the library's exchange plans (one-frame plan x 2, two-frame launch x 2 x 2 slots) and the single frames"

@@ -104,3 +104,80 @@ def test_plans_executed_in_one_process_assemble_the_frame(n):
             runners[r].run(PE.plan(r, n, W, H, band))
         assert np.array_equal(runners[0].full(), truth)
         assert not mail
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize("nslots", [1, 2, 5, 16, 32])
+def test_batch_plan_is_one_exchange_per_launch(n, nslots):
+    """rtr_mgpu_plan_batch — what rtr_mgpu_render_batch_async executes: ONE ncclGroupStart ... ncclGroupEnd per launch holding every
+    slot's transfers (sixteen grouped exchanges per sixteen-slot launch on the rank that also renders and de-interleaves
+    became one), slots named in the same order on both ends of every pair of ranks."""
+    W, H, band = 96, 52, 8
+    plans = [PE.plan_batch(r, n, W, H, nslots, band) for r in range(n)]
+    PE.check_batch_plans(plans, W, H, nslots, band)
+    assert len(plans[0]) == (5 + nslots * (n + 2) if n > 1 else 3 + 3 * nslots) and len(plans[0]) <= A.MGPU_BATCH_PLAN_MAX_OPS
+    if n > 1:
+        assert len(plans[1]) == 5 + 3 * nslots
+    # the one-frame plan is the batch plan of one slot
+    assert PE.plan_batch(min(1, n - 1), n, W, H, 1, band) == PE.plan(min(1, n - 1), n, W, H, band)
+    PE.check_plans([PE.plan_batch(r, n, W, H, 1, band) for r in range(n)], W, H, band)
+
+
+def test_batch_checker_catches_a_receive_outside_the_group_and_a_slot_order_mismatch():
+    W, H, band, n, nslots = 96, 52, 8, 4, 3
+    good = [PE.plan_batch(r, n, W, H, nslots, band) for r in range(n)]
+    PE.check_batch_plans(good, W, H, nslots, band)
+
+    def mutated(fn):
+        plans = [[dict(o) for o in p] for p in good]
+        fn(plans)
+        return plans
+    recv = [i for i, o in enumerate(good[0]) if o["kind"] == A.MGPU_OP_RECV]
+    ge = next(i for i, o in enumerate(good[0]) if o["kind"] == A.MGPU_OP_GROUP_END)
+
+    def recv_outside_group(p): p[0].insert(ge + 1, p[0].pop(recv[-1]))            # a slot's receive behind ncclGroupEnd
+    def second_group(p):                                                          # the old form: a group per slot
+        i = recv[n - 1]
+        p[0].insert(i, dict(p[0][ge])); p[0].insert(i + 1, dict(good[0][recv[0] - 1]))
+    def slot_order(p): p[2][:] = sorted(p[2], key=lambda o: -o["slot"] if o["kind"] == A.MGPU_OP_SEND else 0)      # rank 2 sends its slots backwards
+    def missing_guard(p): del p[1][1]
+    def missing_done(p): del p[3][-1]
+    def wrong_slot_offset(p): p[0][recv[n]]["offset"] += 4
+    for fn in (recv_outside_group, second_group, slot_order, missing_guard, missing_done, wrong_slot_offset):
+        with pytest.raises((AssertionError, ValueError, StopIteration)):
+            PE.check_batch_plans(mutated(fn), W, H, nslots, band)
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_batch_plans_executed_in_one_process_assemble_every_slot(n):
+    """All ranks' batch plans against an in-memory mailbox that matches transfers between a pair in POSTING ORDER (as RCCL does): three
+    slots whose pixels encode (slot, y, x) come back assembled in their own slots, twice."""
+    W, H, band, nslots = 40, 52, 8, 3
+    truth = [((np.arange(H, dtype=np.uint32)[:, None] << 16) | np.arange(W, dtype=np.uint32)[None, :]) + (j << 28) for j in range(nslots)]
+
+    def shard_of(idx, cnt, slot):
+        ys = mgpu.global_rows_of_shard(H, band, cnt, idx)
+        out = np.zeros((len(ys), W), np.uint32)
+        out[ys >= 0] = truth[slot][ys[ys >= 0]]
+        return out
+
+    class _W:
+        def __init__(self, fn): self.fn = fn
+        def wait(self): self.fn()
+    mail = {}
+
+    class Dist:
+        def __init__(self, me): self.me = me
+        def isend(self, v, dst):
+            mail.setdefault((self.me, dst), []).append(v.clone())
+            return _W(lambda: None)
+        def irecv(self, v, src):
+            me = self.me
+            return _W(lambda: v.copy_(mail[(src, me)].pop(0)))
+    runners = [PE.PlanRunner(r, n, W, H, band, shard_of, Dist(r), nslots=nslots) for r in range(n)]
+    for _ in range(2):
+        for r in range(n - 1, -1, -1):          # senders first: the mailbox has no blocking
+            runners[r].run(PE.plan_batch(r, n, W, H, nslots, band))
+        for j in range(nslots):
+            assert np.array_equal(runners[0].full(j), truth[j]), j
+        assert not any(mail.values())
