@@ -43,7 +43,7 @@ def main():
     N[np.einsum("ij,ij->i", N, P - cam) > 0] *= -1
     org = P + N * 0.01
     rng = np.random.default_rng(1)
-    rays, groups = [], []
+    rays, groups, bundles = [], [], []
     pix = np.arange(len(P), dtype=np.uint32)
     lt = np.nonzero(custom < nl)[0]
     for k in lt:
@@ -61,15 +61,18 @@ def main():
             d /= dist[:, None]
             rays.append(np.concatenate([org[front], d[front], (dist[front] - 0.5)[:, None]], axis=1))
             groups.append(np.stack([pix[front], np.full(front.sum(), custom[k], np.uint32)], axis=1))
+            bundles.append(np.stack([pix[front], np.full(front.sum(), k, np.uint32)], axis=1))       # the 3 rays one surface point sends at ONE light triangle: bundle_sim.cpp
     dl = np.array([-1.0, 1.0, -0.5], dtype=np.float32)
     dl /= np.linalg.norm(dl)
     m = N @ dl > 0
     rays.append(np.concatenate([org[m], np.broadcast_to(dl, (m.sum(), 3)), np.full((m.sum(), 1), 10000.0, np.float32)], axis=1))
     groups.append(np.stack([pix[m], np.full(m.sum(), 0xFFFF, np.uint32)], axis=1))
+    bundles.append(np.stack([pix[m], np.full(m.sum(), 0xFFFFFFFF, np.uint32)], axis=1))
     rays = np.concatenate(rays).astype(np.float32)
     groups = np.concatenate(groups).astype(np.uint32)
     keep = rays[:, 6] > 0.001
     rays, groups = rays[keep], groups[keep]
+    np.concatenate(bundles).astype(np.uint32)[keep].tofile(os.path.join(out, "bundles.bin"))    # per ray: surface point, light TRIANGLE (0xFFFFFFFF = the directional light)
     groups.tofile(os.path.join(out, "groups.bin"))        # per ray: surface point, light (0xFFFF = the directional light) — shadow_cache_sim.cpp
     nodes_np.tofile(os.path.join(out, "nodes.bin"))
     tris_np.tofile(os.path.join(out, "tris.bin"))
