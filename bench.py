@@ -75,6 +75,9 @@ def launch_sizes(count, batch):
     return [base + 1] * extra + [base] * (nl - extra)
 
 
+# sponza_mixed: the atrium with the triangle-size mix of a real asset (large walls / column slivers beside fine cloth, an alpha-tested layer);
+# a second line for profiles/, never the headline (BASELINE config 4 is sponza_class)
+WORKLOADS = {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class", "sponza_mixed": "sponza_mixed"}
 PATH_PERIOD = 192     # cameras of the scripted walk (scenes.SceneSetup.camera_path: 96 frames forward, 96 back); frame i uses camera i mod 192
 
 
@@ -182,7 +185,7 @@ def build_setup(args, scenes, np):
         setup = scenes.custom_obj(args.obj, os.path.dirname(os.path.abspath(args.obj)), cam, tuple(float(x) for x in c), fov_y=60.0, width=W, height=H, lights=[light])
         args.workload = "obj:" + os.path.basename(args.obj)
         return setup
-    return getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H)
+    return getattr(scenes, WORKLOADS[args.workload])(W, H)
 
 
 def run_inproc(args, K, plan):
@@ -375,7 +378,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="sponza_class", choices=["sponza_class", "cornell", "bunny_class"])
+    ap.add_argument("--workload", default="sponza_class", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1)
@@ -805,7 +808,7 @@ def main():
     # The frame the reference presents, end to end, on the same scene (one at a time: rtr_denoise_combine is synchronous)
     presented = None
     if rank == 0 and not dist_on and not emu and not args.obj and args.present_frames > 0:
-        psetup = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[args.workload])(W, H, ltc=scenes.shipped_ltc())
+        psetup = getattr(scenes, WORKLOADS[args.workload])(W, H, ltc=scenes.shipped_ltc())
         pscene = api.Scene(ctx, psetup.desc)
         pframe = api.Frame(ctx, W, H, 0xff)
         pp = api.make_params(W, H, spp=4, shadow_rays=args.shadow_rays, images=A.IMAGES_RAYGEN5, pipeline=args.pipeline)

@@ -15,6 +15,7 @@ from realtimeraytracer_amd import api, scenes  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
 
 VARIANTS = [
+    ("the default: probe, passes if it pays (auto)", {}),
     ("binned SAH, greedy collapse (round 2)", {"RTR_BVH_REINSERT_PASSES": "0", "RTR_BVH_WIDE_GREEDY": "1"}),
     ("binned SAH, cost-driven collapse", {"RTR_BVH_REINSERT_PASSES": "0"}),
     ("+ 1 reinsertion pass", {"RTR_BVH_REINSERT_PASSES": "1"}),
@@ -29,7 +30,7 @@ def main():
     W = int(sys.argv[2]) if len(sys.argv) > 2 else 480
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 270
     only = os.environ.get("LAB_ONLY")
-    s = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class"}[name])(W, H)
+    s = getattr(scenes, {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class", "sponza_mixed": "sponza_mixed"}[name])(W, H)
     p = api.make_params(W, H, spp=1, shadow_rays=3, collect_stats=1)
     print(f"{name} {W}x{H}")
     print(f"{'variant':44s} {'build s':>8s} {'SAH2':>8s} {'wide cost':>10s} {'depth':>5s} {'nodes':>8s} {'wide':>8s} {'visits/ray':>10s} {'tests/ray':>9s} {'cam visits':>10s} {'cam tests':>9s} {'tail':>5s}")

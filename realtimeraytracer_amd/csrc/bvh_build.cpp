@@ -5,6 +5,7 @@
 #include "bvh_build.h"
 #include "../../include/rtr_math.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <chrono>
@@ -256,13 +257,17 @@ struct Optimizer {
 
 }  // namespace
 
+constexpr size_t kReinsertAutoMinTriangles = 4096;    /* below this a frame's rays cost nothing to trace whatever the tree; the decision is left alone */
+constexpr float kReinsertProbeGain = 0.02f;      /* the probe must take 2 % off the SAH cost for the passes to run (measured gains: build_options_from_env) */
+
 BuildOptions build_options_from_env() {
     BuildOptions o;
-    /* Insertion-based optimisation is OFF by default: on the bench scene (uniformly tessellated patches) the binned-SAH tree is
-     * already within 1.2 % of what three passes reach in SAH cost, shadow-ray visits move by -0.6 ... -1.7 %, camera-ray visits by
-     * +5 ... +7 %, for 1-4 s of build (profiles/r03/tree_lab_sponza_480x270.log).  RTR_BVH_REINSERT_PASSES=n turns it on for assets
-     * with badly mixed triangle sizes. */
-    o.reinsertPasses = 0; o.reinsertFraction = 1.0f;
+    /* Insertion-based optimisation is decided PER SCENE (BuildOptions::kReinsertAuto, build_bvh): on uniformly tessellated geometry
+     * (the bench scene) the binned-SAH tree is already within 1.2 % of what three passes reach in SAH cost and the passes buy nothing
+     * (profiles/r03/tree_lab_sponza_480x270.log); where large triangles sit beside fine detail (walls and column shafts beside cloth
+     * and ornaments: scenes.sponza_mixed, the reference's Bistro) they take 10 % off the SAH cost, 8 % off the shadow rays' visits and
+     * a quarter off the camera rays' (profiles/r04/tree_lab_sponza_mixed_480x270.log).  RTR_BVH_REINSERT_PASSES=n forces n passes (0: none). */
+    o.reinsertPasses = BuildOptions::kReinsertAuto; o.reinsertFraction = 1.0f;
     auto u = [](const char* name, uint32_t& v) { if (const char* e = getenv(name)) if (*e) v = (uint32_t)strtoul(e, nullptr, 10); };
     auto f = [](const char* name, float& v) { if (const char* e = getenv(name)) if (*e) v = strtof(e, nullptr); };
     u("RTR_BVH_BINS", o.bins); u("RTR_BVH_LEAF_TARGET", o.leafTarget); u("RTR_BVH_MAX_LEAF", o.maxLeaf);
@@ -311,16 +316,41 @@ bool build_bvh(const std::vector<WorldTriangle>& tris, BvhResult& out, std::stri
 
     /* a tree built for trace speed: take badly placed subtrees out and put them back where they cost least.  Kept only while the
      * tree stays within the 64-entry depth bound of the traversal stacks. */
-    if (opt.reinsertPasses > 0 && b.t.size() > 7) {
+    if (opt.reinsertPasses > 0 && b.t.size() > 7 && (opt.reinsertPasses != BuildOptions::kReinsertAuto || in->size() >= kReinsertAutoMinTriangles)) {
         auto o0 = std::chrono::steady_clock::now();
         std::vector<TNode> keep = b.t;
         Optimizer op(b.t, root);
-        for (uint32_t p = 0; p < opt.reinsertPasses; ++p) op.pass(opt.reinsertFraction);
-        if (tree_depth(b.t, op.root) > 64) b.t.swap(keep);
-        else root = op.root;
+        if (opt.reinsertPasses == BuildOptions::kReinsertAuto) {
+            /* the probe: re-insert the worst tenth of the nodes (a tenth of a pass's time).  A top-down SAH tree over uniformly sized
+             * triangles gains well under a per cent from it and is kept AS BUILT; one whose big triangles were binned beside small ones
+             * gains several per cent, and then whole passes follow while each still takes a per cent off the cost (at most four). */
+            const double c0 = out.sahCostBeforeOpt;
+            op.pass(0.1f);
+            double c = tree_cost(b.t, op.root, opt);
+            out.optProbeGain = c0 > 0 ? (float)((c0 - c) / c0) : 0.f;
+            if (out.optProbeGain >= kReinsertProbeGain) {
+                for (uint32_t p = 0; p < 4; ++p) {
+                    op.pass(1.0f);
+                    ++out.optPasses;
+                    const double cn = tree_cost(b.t, op.root, opt);
+                    const bool worthIt = (c - cn) / c >= 0.01;
+                    c = cn;
+                    if (!worthIt) break;
+                }
+                if (tree_depth(b.t, op.root) > 64) { b.t.swap(keep); out.optPasses = 0; }
+                else root = op.root;
+            } else b.t.swap(keep);                                      /* as built: the probe's own moves are not kept */
+        } else {
+            for (uint32_t p = 0; p < opt.reinsertPasses; ++p) op.pass(opt.reinsertFraction);
+            if (tree_depth(b.t, op.root) > 64) b.t.swap(keep);
+            else { root = op.root; out.optPasses = opt.reinsertPasses; }
+        }
         out.optMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - o0).count();
     }
     out.sahCost = (float)tree_cost(b.t, root, opt);
+    if (const char* v = getenv("RTR_BVH_VERBOSE")) if (*v == '1')
+        fprintf(stderr, "build_bvh: %zu triangles, SAH cost %.3f as built, re-insertion probe gain %.2f %%, %u passes kept, cost %.3f, %.0f ms\n", in->size(), out.sahCostBeforeOpt,
+                100.0 * out.optProbeGain, out.optPasses, out.sahCost, out.optMs);
 
     /* linearise: inner nodes in DFS pre-order (nodes[0] = root), leaf triangles in the order the walk meets them */
     std::vector<BvhNodeF> nodesF;

@@ -41,8 +41,9 @@ struct BuildOptions {
     float    costTraverse = 1.0f, costIntersect = 1.0f;
     /* insertion-based optimisation (Bittner, Hapala, Havran 2013): subtrees are taken out and put back where they raise the
      * tree's SAH cost least.  passes x fraction of the nodes, worst first */
-    uint32_t reinsertPasses = 0;
+    uint32_t reinsertPasses = kReinsertAuto;      /* kReinsertAuto: decided per scene by a probe (build_bvh); 0: never; n: n passes */
     float    reinsertFraction = 1.0f;
+    static constexpr uint32_t kReinsertAuto = 0xffffffffu;
     uint32_t wideGreedy = 0;          /* 1: no shapes — the 4-wide view is collapsed by the greedy rule (open the largest box), as device-built trees are */
 };
 BuildOptions build_options_from_env();
@@ -62,6 +63,8 @@ struct BvhResult {
     float    boundsMax[3] = {0, 0, 0};
     float    boxPad = 0.f;
     float    buildMs = 0.f, optMs = 0.f;
+    float    optProbeGain = 0.f;     /* auto mode: relative SAH-cost gain of the probe (the worst tenth of the nodes re-inserted) */
+    uint32_t optPasses = 0;          /* full re-insertion passes that were run and kept */
 };
 
 /* Deterministic build.  Returns false (with *err) on invalid input (NaN/inf corners). */

@@ -116,11 +116,13 @@ class ObjWriter:
         self.shapes = []
         self.materials = {}
 
-    def material(self, name, kd, ks=0.0, metallic=None):
-        self.materials[name] = (tuple(kd), float(ks), metallic)
+    def material(self, name, kd, ks=0.0, metallic=None, maps=None):
+        """maps: {"map_Kd": path, "map_d": path, ...} written as they are (paths relative to the MTL)"""
+        self.materials[name] = (tuple(kd), float(ks), metallic, dict(maps or {}))
 
-    def shape(self, name, material, verts, normals, tris):
-        self.shapes.append((name, material, np.asarray(verts, np.float64), np.asarray(normals, np.float64), np.asarray(tris, np.int64)))
+    def shape(self, name, material, verts, normals, tris, uvs=None):
+        self.shapes.append((name, material, np.asarray(verts, np.float64), np.asarray(normals, np.float64), np.asarray(tris, np.int64),
+                            None if uvs is None else np.asarray(uvs, np.float64)))
 
     def num_triangles(self):
         return int(sum(len(s[4]) for s in self.shapes))
@@ -128,18 +130,28 @@ class ObjWriter:
     def write(self, obj_path, mtl_name):
         lines = ["mtllib %s\n" % mtl_name]
         base = 0
-        for name, mat, v, n, t in self.shapes:
+        ubase = 0
+        for name, mat, v, n, t, uv in self.shapes:
             lines.append("o %s\nusemtl %s\n" % (name, mat))
             lines.append("".join("v %.6f %.6f %.6f\n" % tuple(p) for p in v))
+            if uv is not None:
+                lines.append("".join("vt %.6f %.6f\n" % tuple(p) for p in uv))
             lines.append("".join("vn %.6f %.6f %.6f\n" % tuple(p) for p in n))
             tt = t + 1 + base
-            lines.append("".join("f %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c) for a, b, c in tt))
+            if uv is None:
+                lines.append("".join("f %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c) for a, b, c in tt))
+            else:
+                d = ubase - base
+                lines.append("".join("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a + d, a, b, b + d, b, c, c + d, c) for a, b, c in tt))
+                ubase += len(v)
             base += len(v)
         mtl = []
-        for name, (kd, ks, metallic) in self.materials.items():
+        for name, (kd, ks, metallic, maps) in self.materials.items():
             mtl.append("newmtl %s\nKa 0 0 0\nKd %.4f %.4f %.4f\nKs %.4f %.4f %.4f\n" % (name, kd[0], kd[1], kd[2], ks, ks, ks))
             if metallic is not None:
                 mtl.append("metallic %.4f\n" % metallic)
+            for k, path in maps.items():
+                mtl.append("%s %s\n" % (k, path))
             mtl.append("\n")
         _atomic_write(os.path.join(os.path.dirname(obj_path), mtl_name), "".join(mtl))   # MTL first: the OBJ's existence is the "done" mark
         _atomic_write(obj_path, "".join(lines))
@@ -333,6 +345,156 @@ def write_sponza_class(directory=None):
     w.shape("centre_piece", "bronze", p, _vertex_normals(p, f), f)
     w.write(obj, "sponza_class.mtl")
     return obj, d + "/"
+
+
+def write_sponza_mixed(directory=None):
+    """A second 'Sponza'-class stand-in with the triangle-SIZE MIX of the real asset (VERDICT r03 missing-3): the same atrium and
+    the same ~262 k triangle budget as write_sponza_class, but the architecture is LARGE triangles — floor, walls and balcony slabs as
+    a few hundred, the 48 column shafts as 24 tall slivers each — beside the fine rest (arches as ornaments, draped cloth, a centre
+    piece, vases), plus an alpha-tested layer: 'ivy' cards on the walls and between the columns with a cut-out opacity map (map_d ->
+    opacity.rahit).  Big triangles straddling small ones is what the uniformly tessellated scene does not have and what spatial
+    splits repair; bench.py --workload sponza_mixed reports it as a second line, never as the headline."""
+    d = directory or _cache_dir()
+    obj = os.path.join(d, "sponza_mixed.obj")
+    if os.path.exists(obj):
+        return obj, d + "/"
+    tdir = os.path.join(d, "mixed_tex")
+    os.makedirs(tdir, exist_ok=True)
+    ly, lx = np.mgrid[0:128, 0:128]
+    blob = ((((lx % 32) - 16) ** 2 + ((ly % 32) - 16) ** 2) < 13 ** 2) | ((((lx + 16) % 32 - 16) ** 2 + ((ly + 16) % 32 - 16) ** 2) < 7 ** 2)
+    leaf = np.zeros((128, 128, 4), np.uint8)
+    leaf[..., 0] = np.where(blob, 255, 30)             # opacity.rahit reads .r: >= 0.9 keeps the hit
+    leaf[..., 1] = 150 + (lx % 32) * 2
+    leaf[..., 2] = 50
+    leaf[..., 3] = np.where(blob, 255, 0)
+    write_png(os.path.join(tdir, "ivy.png"), leaf)
+    w = ObjWriter()
+    mats = {"floor": (0.55, 0.5, 0.45), "wall": (0.7, 0.65, 0.55), "column": (0.8, 0.78, 0.7), "arch": (0.72, 0.7, 0.62),
+            "slab": (0.5, 0.5, 0.5), "cloth_red": (0.7, 0.12, 0.1), "cloth_green": (0.15, 0.5, 0.2), "cloth_blue": (0.15, 0.2, 0.6),
+            "vase": (0.3, 0.5, 0.55), "bronze": (0.8, 0.5, 0.2)}
+    for k, c in mats.items():
+        w.material(k, c, ks=0.6 if k in ("vase", "bronze") else 0.15, metallic=0.9 if k == "bronze" else None)
+    w.material("ivy", (0.2, 0.7, 0.25), ks=0.1, maps={"map_Kd": "mixed_tex/ivy.png", "map_d": "mixed_tex/ivy.png"})
+    LX, LY, LZ = 3000.0, 1300.0, 1400.0
+
+    def plane(origin, du, dv, nu, nv, flip=False, uv_tiles=None):
+        o, du, dv = np.array(origin, float), np.array(du, float), np.array(dv, float)
+        nrm = np.cross(du, dv)
+        nrm = nrm / np.linalg.norm(nrm)
+        uvs = []
+
+        def fn(u, v):
+            uvs.append(np.stack([u, v], 1))
+            return o + u[:, None] * du + v[:, None] * dv, np.tile(nrm, (len(u), 1))
+        p, n, t = grid_patch(fn, nu, nv)
+        uv = uvs[0] * (uv_tiles if uv_tiles is not None else 1.0)
+        return ((p, -n, t[:, ::-1]) if flip else (p, n, t)) + ((uv,) if uv_tiles is not None else ())
+
+    # architecture: LARGE triangles (a wall triangle spans 375 x 325 units of a 3000-unit scene: 12 % of its extent)
+    w.shape("floor", "floor", *plane((-LX / 2, 0, -LZ / 2), (0, 0, LZ), (LX, 0, 0), 4, 8))
+    w.shape("wall_back", "wall", *plane((-LX / 2, 0, -LZ / 2), (LX, 0, 0), (0, LY, 0), 8, 4, flip=True))
+    w.shape("wall_front", "wall", *plane((-LX / 2, 0, LZ / 2), (LX, 0, 0), (0, LY, 0), 8, 4))
+    w.shape("wall_left", "wall", *plane((-LX / 2, 0, -LZ / 2), (0, 0, LZ), (0, LY, 0), 4, 4))
+    w.shape("wall_right", "wall", *plane((LX / 2, 0, -LZ / 2), (0, 0, LZ), (0, LY, 0), 4, 4, flip=True))
+    for side, z0 in enumerate((-LZ / 2, LZ / 2 - 260)):
+        w.shape("slab_%d" % side, "slab", *plane((-LX / 2, 560.0, z0), (0, 0, 260.0), (LX, 0, 0), 1, 8))
+
+    def cylinder(cx, cz, y0, y1, radius, nseg, nring):
+        def fn(u, v):
+            ang = 2 * np.pi * u
+            p = np.stack([cx + radius * np.cos(ang), y0 + (y1 - y0) * v, cz + radius * np.sin(ang)], 1)
+            n = np.stack([np.cos(ang), np.zeros_like(u), np.sin(ang)], 1)
+            return p, n
+        p, n, t = grid_patch(fn, nseg, nring)
+        return p, n, t[:, ::-1]
+    xs = np.linspace(-LX / 2 + 200, LX / 2 - 200, 12)
+    # column shafts: twelve slivers the height of a storey each (520 x 20 units: the long thin triangles of real architecture)
+    for storey, (y0, y1, rad) in enumerate(((0.0, 520.0, 38.0), (580.0, 1040.0, 30.0))):
+        for side, z in enumerate((-LZ / 2 + 260, LZ / 2 - 260)):
+            P, N, T, base = [], [], [], 0
+            for cx in xs:
+                p, n, t = cylinder(cx, z, y0, y1, rad, 12, 1)
+                P.append(p); N.append(n); T.append(t + base); base += len(p)
+            w.shape("columns_s%d_%d" % (storey, side), "column", np.concatenate(P), np.concatenate(N), np.concatenate(T))
+
+    # the fine rest: arches as ornaments, draped cloth, vases, the centre piece (as in write_sponza_class, cloth a little finer)
+    def arch(cx0, cx1, z, ybase, tube, nseg, ntube):
+        cxm, R = 0.5 * (cx0 + cx1), 0.5 * (cx1 - cx0)
+
+        def fn(u, v):
+            a, b = np.pi * u, 2 * np.pi * v
+            cxr, cyr = np.cos(a), np.sin(a)
+            p = np.stack([cxm + (R + tube * np.cos(b)) * cxr, ybase + (R + tube * np.cos(b)) * cyr, z + tube * np.sin(b)], 1)
+            n = np.stack([np.cos(b) * cxr, np.cos(b) * cyr, np.sin(b)], 1)
+            return p, n
+        return grid_patch(fn, nseg, ntube)
+    for storey, (ybase, tube) in enumerate(((520.0, 26.0), (1040.0, 20.0))):
+        for side, z in enumerate((-LZ / 2 + 260, LZ / 2 - 260)):
+            P, N, T, base = [], [], [], 0
+            for i in range(len(xs) - 1):
+                p, n, t = arch(xs[i], xs[i + 1], z, ybase, tube, 24, 16)
+                P.append(p); N.append(n); T.append(t + base); base += len(p)
+            w.shape("arches_s%d_%d" % (storey, side), "arch", np.concatenate(P), np.concatenate(N), np.concatenate(T))
+
+    def cloth(x0, width, ytop, drop, z0, z1, nu, nv, phase):
+        def pos(u, v):
+            x = x0 + width * u + 25.0 * np.sin(6 * np.pi * v + phase) * np.sin(np.pi * u)
+            y = ytop - drop * (1.0 - (2 * v - 1) ** 2) + 18.0 * np.sin(10 * np.pi * u + phase) * np.sin(np.pi * v)
+            return np.stack([x, y, z0 + (z1 - z0) * v], 1)
+
+        def fn(u, v):
+            p, e = pos(u, v), 1e-3
+            return p, np.cross(pos(u, v + e) - p, pos(u + e, v) - p)
+        return grid_patch(fn, nu, nv)
+    cloth_mats = ["cloth_red", "cloth_green", "cloth_blue", "cloth_red", "cloth_blue", "cloth_green"]
+    for i in range(6):
+        x0 = -LX / 2 + 300 + i * 420.0
+        w.shape("cloth_%d" % i, cloth_mats[i], *cloth(x0, 260.0, 1180.0, 260.0 + 30.0 * (i % 3), -LZ / 2 + 300, LZ / 2 - 300, 130, 130, 0.7 * i))
+
+    def vase(cx, cz, h, nseg, nring):
+        def fn(u, v):
+            ang = 2 * np.pi * u
+            prof = 22.0 + 26.0 * np.sin(np.pi * v) ** 2 + 8.0 * np.sin(3 * np.pi * v)
+            p = np.stack([cx + prof * np.cos(ang), h * v, cz + prof * np.sin(ang)], 1)
+            n = np.stack([np.cos(ang), 0.3 * np.cos(np.pi * v), np.sin(ang)], 1)
+            return p, n
+        p, n, t = grid_patch(fn, nseg, nring)
+        return p, n, t[:, ::-1]
+    for i in range(8):
+        cx = -LX / 2 + 380 + (i // 2) * 760.0
+        w.shape("vase_%d" % i, "vase", *vase(cx, -140.0 if i % 2 == 0 else 140.0, 120.0, 16, 20))
+    v, f = icosphere(5)
+    r = 1.0 + 0.25 * np.sin(4 * v[:, 0]) * np.sin(3 * v[:, 1] + 1.0)
+    p = v * r[:, None] * 90.0 + np.array([0.0, 140.0, 0.0])
+    w.shape("centre_piece", "bronze", p, _vertex_normals(p, f), f)
+    # the alpha-tested layer: ivy cards a hand's breadth in front of the back wall and hanging between the columns of the near side
+    # (each card two triangles, uvs tiled: the opacity map decides, texel by texel, whether a candidate hit counts)
+    cards = [plane((-LX / 2 + 150 + 230.0 * k, 60.0 + 90.0 * (k % 3), -LZ / 2 + 6.0), (180.0, 0, 0), (0, 420.0, 0), 1, 1, uv_tiles=np.array([2.0, 4.0])) for k in range(12)]
+    cards += [plane((xs[k] + 40.0, 330.0, LZ / 2 - 262.0), (xs[k + 1] - xs[k] - 80.0, 0, 0), (0, 190.0, 0), 1, 1, flip=True, uv_tiles=np.array([3.0, 2.0])) for k in range(len(xs) - 1)]
+    P, N, T, U, base = [], [], [], [], 0
+    for (pp, nn, tt, uu) in cards:
+        P.append(pp); N.append(nn); T.append(tt + base); U.append(uu); base += len(pp)
+    w.shape("ivy", "ivy", np.concatenate(P), np.concatenate(N), np.concatenate(T), uvs=np.concatenate(U))
+    w.write(obj, "sponza_mixed.mtl")
+    return obj, d + "/"
+
+
+def sponza_mixed(width=1920, height=1080, directory=None, ltc=None):
+    """The mixed-size atrium (write_sponza_mixed) under the lights and camera of sponza_class."""
+    obj, mtldir = write_sponza_mixed(directory)
+    hs = host.HostScene()
+    l1 = hs.addAreaLight(9.0, (0.8, 0.5, 0.2), False)
+    l1.move((-600.0, 1150.0, 0.0)).scale((700.0, 500.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    l2 = hs.addAreaLight(3.0, (0.3, 0.3, 0.5), False)
+    l2.move((900.0, 900.0, 0.0)).scale((500.0, 400.0, 1.0)).rotate((90.0, 0.0, 0.0))
+    hs.addObjMtlPair(obj, mtldir)
+    hs.setSky((0.5, 0.7, 1.0))
+    if ltc is not None:
+        hs.setLTC(*ltc)
+    hs.build()
+    pos = (-1250.0, 420.0, 60.0)
+    cam = host.Camera(60.0, pos, (300.0, 380.0, -20.0), (0.0, 1.0, 0.0), width, height)
+    return SceneSetup("sponza_mixed", hs, cam, pos, width, height, cam_args=(60.0, pos, (300.0, 380.0, -20.0), (0.0, 1.0, 0.0)), walk_scale=1.0)
 
 
 # ---------------------------------------------------------------------------------------------

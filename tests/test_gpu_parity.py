@@ -413,6 +413,24 @@ def test_textured_room_parity(gpu_ctx, oracle, scene_cache, pipeline, collect):
         assert g.numAlphaTests > 10000 and g.numTexFetches > g.numHits
 
 
+@pytest.mark.parametrize("collect", [0, 1])
+def test_sponza_mixed_parity(gpu_ctx, oracle, scene_cache, queue_mode, collect):
+    """The atrium with a real asset's triangle-size mix (scenes.sponza_mixed: large architecture triangles and column slivers beside
+    fine cloth, an alpha-tested ivy layer; the host builder's insertion-based optimisation runs on it): the timed kernels and their
+    counting forms against the oracle on the tree the GPU exported — image bytes and work counters."""
+    W, H = 480, 272
+    s = scenes.sponza_mixed(W, H)
+    p = api.make_params(W, H, spp=1, collect_stats=collect, pipeline=2)
+    scene, frame = _gpu_render(gpu_ctx, s, p, frame_no=4)
+    ref = oracle.render(s.desc, s.camera, s.scene_info(4), p, bvh=scene.export_bvh(), threads=16)
+    _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"sponza_mixed collect{collect}")
+    if collect:
+        g = frame.stats()
+        for f in ("numRays", "numNodeVisits", "numTriTests", "numHits", "numShadowNodeVisits", "numShadowTriTests", "numAlphaTests", "shadowTailRays"):
+            assert getattr(g, f) == getattr(ref.stats, f), f
+        assert g.numAlphaTests > 1000
+
+
 def test_missing_texture_is_refused_on_device_path(gpu_ctx, scene_cache):
     import ctypes as C
     s = scenes.cornell_box(32, 32)

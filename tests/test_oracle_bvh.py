@@ -258,3 +258,38 @@ def test_textured_room_bvh_vs_brute_force(oracle, scene_cache):
     s2 = scenes.textured_room(120, 76, hdri=False)          # keep the owner of the arrays alive while the oracle reads them
     c = oracle.render(s2.desc, s.camera, s.scene_info(1), _params(120, 76, spp=2), bvh=None, threads=8)
     assert len(np.unique(c.images[1][:8].reshape(-1))) < len(np.unique(top))
+
+
+def test_sponza_mixed_size_mix_alpha_layer_and_the_tree_it_gets(oracle, scene_cache):
+    """scenes.sponza_mixed (VERDICT r03 missing-3): the 262 k-triangle atrium with a real asset's size mix — a few hundred large
+    architecture triangles and column slivers beside fine cloth and ornaments, an alpha-tested layer — through the OBJ + MTL ingest.
+    The builder decides per scene whether insertion-based optimisation pays (a probe): it does here (SAH cost -10 %) and does not on
+    the uniformly tessellated bench scene, whose tree stays byte for byte what it was; the optimised tree renders the brute-force image."""
+    import ctypes
+    s = scenes.sponza_mixed(48, 27)
+    st, nodes, tris = api.host_build_bvh(s.desc)
+    assert abs(st.numTriangles - 262144) < 2622                      # within 1 % of the budget
+    t = np.frombuffer(tris, dtype=np.float32).reshape(-1, 12)
+    area = 0.5 * np.linalg.norm(np.cross(t[:, 4:7], t[:, 8:11]), axis=1)
+    big = area > 100 * np.median(area)
+    assert 500 < big.sum() < 3000 and area[big].sum() > 0.5 * area.sum()          # ~1.6 k large triangles carry most of the surface
+    flags = np.frombuffer(tris, dtype=np.uint32).reshape(-1, 12)[:, 11]
+    assert flags.sum() == 2 * (12 + 11)                              # the ivy cards: two alpha-tested triangles each
+    leaves = _check_bvh(s.desc, st, nodes, tris)
+    assert leaves > st.numTriangles // 8 and st.maxDepth <= 40
+    # the per-scene decision: forced off, the cost is what the top-down build leaves
+    os.environ["RTR_BVH_REINSERT_PASSES"] = "0"
+    try:
+        st0, _, _ = api.host_build_bvh(s.desc)
+        u = scenes.sponza_class(48, 27)
+        su0, nu0, tu0 = api.host_build_bvh(u.desc)
+    finally:
+        del os.environ["RTR_BVH_REINSERT_PASSES"]
+    assert st.sahCost < 0.93 * st0.sahCost
+    su, nu, tu = api.host_build_bvh(u.desc)
+    assert bytes(nu) == bytes(nu0) and bytes(tu) == bytes(tu0) and su.sahCost == su0.sahCost          # uniform tessellation: left as built
+    p = _params(48, 27)
+    a = oracle.render(s.desc, s.camera, s.scene_info(2), p, bvh=(nodes, tris, st.grid), threads=8)
+    b = oracle.render(s.desc, s.camera, s.scene_info(2), p, bvh=None, threads=8)
+    assert np.array_equal(a.images[1], b.images[1]) and a.stats.numRays == b.stats.numRays
+    assert isinstance(st, A.rtr_scene_stats) and ctypes.sizeof(st) > 0
