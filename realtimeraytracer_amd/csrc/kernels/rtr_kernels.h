@@ -8,7 +8,7 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
-#define RTR_ANYHIT_KERNEL_REVISION "r03.6"
+#define RTR_ANYHIT_KERNEL_REVISION "r04.1"
 
 /* Batch cursors per queue (and batch lists per octant).  Workgroups are dealt round-robin to the XCDs, and a workgroup starts on
  * cursor blockIdx mod 8: with 8, 4, 2 or 1 XCDs visible (SPX, DPX, QPX, CPX partitions of an MI355X) a cursor is still used by the
@@ -81,7 +81,6 @@ struct Tunables {
     uint32_t trace_octant_forms = 1;
     uint32_t trace_top_nodes = 0xffffffffu;       /* 4-wide records kept in LDS (at most the kernel's kTopNodes) */
     uint32_t resolve_row_waves = 0;
-    uint32_t gen_oct_stage = 1;                   /* k_shadow_gen_oct: 1 = a wave's records of one emission step leave as whole runs per octant (LDS-staged) */
 };
 Tunables tunables_from_env();
 /* name: a field of Tunables (lower case).  false: no such tunable, or a value outside its range. */

@@ -341,7 +341,19 @@ constexpr uint32_t kBinnedMinNodes = 1u << 16;       /* ... and this tree size: 
 constexpr uint32_t kGenOctBlock = RTR_GEN_OCT_BLOCK;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
 /* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
  * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
-__global__ __launch_bounds__(kGenOctBlock) void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom,
+/* Eight waves per SIMD: the kernel is neither issue- nor HBM-bound (its 527 MB of records per frame leave in whole lines: WRITE_SIZE =
+ * 1.01 x the algorithmic bytes) but waits — on the hit -> object -> index -> vertex chain of its surface fetch, on its reservation
+ * atomics and three barriers — so it wants waves more than registers: at the 88 VGPRs it would take by itself (5 waves per SIMD)
+ * 0.171 ms per 1080p frame, capped at 64 (13 dwords spilled) 0.148 (profiles/r04/ab_tri2_gen_waves.log). */
+#ifndef RTR_GEN_OCT_WAVES
+#define RTR_GEN_OCT_WAVES 8
+#endif
+#if RTR_GEN_OCT_WAVES > 0
+#define RTR_GEN_OCT_ATTR __attribute__((amdgpu_waves_per_eu(RTR_GEN_OCT_WAVES, 8)))
+#else
+#define RTR_GEN_OCT_ATTR
+#endif
+__global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom,
                                                               RayQueue queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
                                                               uint32_t listStride, uint32_t kBatch, uint32_t nt) {
     constexpr uint32_t kWaves = kGenOctBlock / 64;
@@ -630,6 +642,21 @@ __device__ __forceinline__ bool tri_any(const DeviceScene& sc, const __amdgpu_bu
     if (!(rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v) && t < tmax)) return false;
     if (__float_as_uint(q2.w) & 1u) return alpha_pass<STATS>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
     return true;
+}
+
+/* tri_any with the record already loaded (RTR_TRI_LOAD2: a leaf's first two records are fetched together, tested one after the other) */
+template <bool STATS>
+__device__ __forceinline__ bool tri_test(const DeviceScene& sc, const rtr_f4 q0, const rtr_f4 q1, const rtr_f4 q2, const rtr_v3 o, const rtr_v3 d,
+                                         const float tmin, const float tmax, LocalStats& st) {
+    float t, u, v;
+    if (!(rtr_mt_intersect(o, d, rtr_mk(q0.x, q0.y, q0.z), rtr_mk(q1.x, q1.y, q1.z), rtr_mk(q2.x, q2.y, q2.z), tmin, &t, &u, &v) && t < tmax)) return false;
+    if (__float_as_uint(q2.w) & 1u) return alpha_pass<STATS>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
+    return true;
+}
+__device__ __forceinline__ rtr_f4 load_f4(const __amdgpu_buffer_rsrc_t buf, int32_t off) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(buf, off, 0, 0);
+    return rtr_f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
 }
 
 struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
@@ -925,7 +952,21 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             bool hit = false;
+#ifdef RTR_TRI_LOAD2
+            {   /* nine leaves in ten hold a quad's two triangles: both records are asked for at once (six loads in flight instead of three
+                 * and then three more), tested one after the other so that the second test is still skipped when the first decides */
+                const int32_t off = (int32_t)(first * 48u);
+                const bool two = cnt > 1u;
+                const rtr_f4 a0 = load_f4(triBuf, off), a1 = load_f4(triBuf, off + 16), a2 = load_f4(triBuf, off + 32);
+                rtr_f4 b0 = a0, b1 = a1, b2 = a2;
+                if (two) { b0 = load_f4(triBuf, off + 48); b1 = load_f4(triBuf, off + 64); b2 = load_f4(triBuf, off + 80); }
+                hit = tri_test<false>(sc, a0, a1, a2, o, d, tmin, tmax, st);
+                if (!hit && two) hit = tri_test<false>(sc, b0, b1, b2, o, d, tmin, tmax, st);
+                for (uint32_t i = 2; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
+            }
+#else
             for (uint32_t i = 0; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
+#endif
             if (hit) { res = 1u; cur = kDone; }
             else { cur = *sp; sp -= kTraceBlock; }                        /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }
@@ -1216,7 +1257,6 @@ const TunableField kTunables[] = {
     {"queue_nt", &Tunables::queue_nt, 0u, 3u}, {"trace_wgs_per_cu", &Tunables::trace_wgs_per_cu, 0u, 8u}, {"trace_refill", &Tunables::trace_refill, 1u, 64u},
     {"trace_inner_min", &Tunables::trace_inner_min, 0u, 63u}, {"trace_octant_forms", &Tunables::trace_octant_forms, 0u, 1u},
     {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u},
-    {"gen_oct_stage", &Tunables::gen_oct_stage, 0u, 1u},
 };
 }  // namespace
 

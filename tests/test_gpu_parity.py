@@ -1036,7 +1036,7 @@ def test_tunables_belong_to_the_context_and_change_no_pixel(gpu_ctx, scene_cache
     assert c.get_tunable("trace_refill") == 33 and gpu_ctx.get_tunable("trace_refill") == 20
     fr = api.Frame(c, W, H)
     for name, value in (("trace_binned", 1), ("trace_batch", 64), ("trace_wgs_per_cu", 3), ("trace_inner_min", 5), ("trace_octant_forms", 0),
-                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("primary_persist", 1), ("trace_bvh4", 0), ("gen_oct_stage", 0)):
+                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
         c.set_tunable(name, value)
         assert c.get_tunable(name) == value
         api.render(scene, s.camera, s.scene_info(0), p, fr)
