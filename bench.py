@@ -963,15 +963,20 @@ def main():
                 g = pmc["kernels"]["k_shadow_gen_oct"]
                 gen_ms = (kern["shadow_gen"] / n_launches) if own_launch else kern_iso["shadow_gen"]
                 gbytes = (g["read_bytes"] + g["write_bytes"]) * scale
+                # 20-B ray records + 16-B origins out, 20-B hit records in: what the kernel HAS to move (achieved = algorithmic bytes over
+                # the launch's duration); `traffic` = what the FETCH_SIZE / WRITE_SIZE passes saw (more: object / vertex / light fetches that
+                # missed the L2s, and — capped at 64 VGPRs for eight waves per SIMD — 13 spilled dwords per lane on their way through the memory side)
+                galg = (20 * sched["shadow_rays"] + (20 + 16) * primary_per_frame / max(K, 1) / max(world, 1)) * launch_frames
                 roofline2 = {"bound": "hbm", "kernel": "k_shadow_gen_oct: shadow-ray generation into the queue binned by direction octant",
-                             "achieved": round(gbytes / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "frac_of_measured_copy_rate": round(gbytes / (gen_ms * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS, 4),
-                             "traffic": int(gbytes), "read_bytes": int(g["read_bytes"] * scale), "write_bytes": int(g["write_bytes"] * scale),
-                             "algorithmic_bytes_per_launch": int((20 * sched["shadow_rays"] + (20 + 16) * primary_per_frame / max(K, 1) / max(world, 1)) * launch_frames),      # 20-B ray records + 16-B origins out, 20-B hit records in
+                             "achieved": round(galg / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(galg / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "frac_of_measured_copy_rate": round(galg / (gen_ms * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS, 4),
+                             "traffic": int(gbytes), "traffic_gbps": round(gbytes / (gen_ms * 1e-3) / 1e9, 1), "traffic_over_algorithmic": round(gbytes / galg, 3),
+                             "read_bytes": int(g["read_bytes"] * scale), "write_bytes": int(g["write_bytes"] * scale),
+                             "algorithmic_bytes_per_launch": int(galg),
                              "frames_per_launch": round(launch_frames, 2),
                              "avg_launch_ms": round(gen_ms, 4), "avg_launch_ms_source": "HIP events on the launch stream, " + ("timed region (one launch at a time)" if own_launch else "frames rendered one at a time (this run)"),
-                             "counters": "bytes from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; FETCH_SIZE's streamed part doubled, gfx950), scaled by rays; duration from this run"}
+                             "counters": "traffic: bytes from the committed FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; FETCH_SIZE's streamed part doubled, gfx950), scaled by rays; achieved: this run's algorithmic bytes over this run's duration"}
                 fb = pmc.get("frame_hbm_bytes")
                 fb = fb * scale / launch_frames if fb else fb          # the counters are per launch
                 frame_hbm = {"bytes_per_frame": int(fb) if fb else None, "per_kernel_per_launch": {kk: int((vv["read_bytes"] + vv["write_bytes"]) * scale) for kk, vv in pmc["kernels"].items()},

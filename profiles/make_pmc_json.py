@@ -9,9 +9,12 @@ import sys
 
 src, key, rev, rays, nps, ntri = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
 frames = int(sys.argv[7]) if len(sys.argv) > 7 else 1          # frames per launch of the pipeline (bench.py --batch)
+camera = sys.argv[8] if len(sys.argv) > 8 else "static"         # bench.py --camera: "path" = a new view every frame (rays: the mean over the timed frames)
 rays, nps = rays * frames, nps * frames
 if frames > 1:
     key += f"_batch{frames}"
+if camera != "static":
+    key += "_" + camera
 pmc = json.load(open(src))
 
 
@@ -51,7 +54,7 @@ out = {
                 "rendered one at a time); read by bench.py for its roofline, roofline_secondary and frame_hbm blocks, which check workload, "
                 "kernel revision, triangle count and queue length against the run before using them",
     key: {
-        "kernel": name, "kernel_revision": rev, "rays_per_launch": rays, "pixel_samples": nps, "triangles": ntri, "frames_per_launch": frames,
+        "kernel": name, "kernel_revision": rev, "rays_per_launch": rays, "pixel_samples": nps, "triangles": ntri, "frames_per_launch": frames, "camera": camera,
         "rocprof_avg_launch_ms": k["avg_ms"], "rocprof_calls": k["calls"],
         "SQ_WAVES": k["SQ_WAVES"], "SQ_WAVE_CYCLES_quad": k["SQ_WAVE_CYCLES"],
         "SQ_INSTS_VALU": k["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad": k["SQ_ACTIVE_INST_VALU"],
