@@ -18,7 +18,7 @@ def child(frames):
     api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H), whole)
     want = whole.download()
     out = []
-    combos = [(1, 8)] + [(k, b) for k in (2, 3, 4, 6, 8) for b in (8, 16, 32, 64, 0)]
+    combos = [(1, 8)] + [(k, b) for k in (2, 3, 4, 6) for b in (8, 64, 0)]
     fr = api.Frame(ctx, W, H)
     for k, band in combos:
         b = band if band else ((H + k - 1) // k + 7) // 8 * 8       # 0: contiguous slabs (one band per part)
@@ -44,7 +44,7 @@ if __name__ == "__main__":
         child(int(sys.argv[2]))
     else:
         frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-        for q in ("4", "8"):
-            print(f"# GPU_MAX_HW_QUEUES={q}", flush=True)
-            env = dict(os.environ, GPU_MAX_HW_QUEUES=q)
+        for q, prio in (("4", "1"), ("8", "1"), ("8", "0")):
+            print(f"# GPU_MAX_HW_QUEUES={q} RTR_SPLIT_PRIORITIES={prio} (1: part k's stream has the k-th highest priority)", flush=True)
+            env = dict(os.environ, GPU_MAX_HW_QUEUES=q, RTR_SPLIT_PRIORITIES=prio)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(frames)], env=env, check=False)

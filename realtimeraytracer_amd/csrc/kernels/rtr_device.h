@@ -746,4 +746,23 @@ __device__ __forceinline__ void write_pixel(const RenderArgs& ra, const FrameOut
     if (fo.img[7]) fo.img[7][p] = rtr_pack_bgra8(o.avgPosition.x / n, o.avgPosition.y / n, o.avgPosition.z / n);
 }
 
+/* write_pixel for a launch whose only outputs are the framebuffer (img[1]) and the HDR accumulator: the same operations on the
+ * shadowed sum, in the same order */
+__device__ __forceinline__ void write_pixel_framebuffer(const RenderArgs& ra, const FrameOut& fo, size_t p, rtr_v3 shadowed) {
+    const float n = (float)ra.spp;
+    rtr_v3 sh = rtr_mk(shadowed.x / n, shadowed.y / n, shadowed.z / n);
+    if (fo.hdr) {
+        if (ra.accumulate) {
+            float4 h = fo.hdr[p];
+            h.x += sh.x; h.y += sh.y; h.z += sh.z; h.w += 1.0f;
+            fo.hdr[p] = h;
+            const float inv = (float)(ra.accumulatedFrames + 1u);
+            sh = rtr_mk(h.x / inv, h.y / inv, h.z / inv);
+        } else {
+            fo.hdr[p] = make_float4(sh.x, sh.y, sh.z, 1.0f);
+        }
+    }
+    if (fo.img[1]) fo.img[1][p] = tonemap_pack(sh);
+}
+
 }  // namespace rtrdev

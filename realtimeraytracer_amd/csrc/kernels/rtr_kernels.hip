@@ -1181,8 +1181,23 @@ __global__ __launch_bounds__(kBlock) void k_shadow_tail(DeviceScene sc, const Ra
 }
 
 /* ---- wavefront stage 4: resolve (shade with looked-up visibility, tonemap, store) ------------- */
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, FrameBatch fb, uint32_t planeStride, const float4* hitTuvp,
+/* Occupancy of k_resolve: it waits on its fetches (hit record -> object -> indices -> vertices, the visibility bytes) more than it
+ * issues, so it wants waves.  All five images: 150 VGPRs by itself = 3 waves per SIMD; capped at 128 (33 dwords spilled) it runs 6 %
+ * faster, capped lower the spills cost more than the waves bring (profiles/r04/ab_resolve_waves.log).  Framebuffer only (FULL ==
+ * false): 103 VGPRs by itself, RTR_RESOLVE_WAVES_FB waves per SIMD. */
+#ifndef RTR_RESOLVE_WAVES
+#define RTR_RESOLVE_WAVES 4
+#endif
+#ifndef RTR_RESOLVE_WAVES_FB
+#define RTR_RESOLVE_WAVES_FB 6
+#endif
+#define RTR_RESOLVE_ATTR __attribute__((amdgpu_waves_per_eu(FULL ? RTR_RESOLVE_WAVES : RTR_RESOLVE_WAVES_FB, 8)))
+/* FULL == false: the launch writes only the framebuffer of the north-star path (RTR_IMAGE_SHADOWED, + the HDR accumulator) — what
+ * bench.py renders.  Known at compile time, the analytic / unshadowed / normal / position sums and the LTC fetches are dead code and
+ * the kernel needs 40 registers fewer (one more wave per SIMD of a kernel that waits on its fetches); the shadowed sum is formed by
+ * the same operations in the same order either way (the tests render both forms against the oracle). */
+template <bool STATS, bool FULL>
+__global__ __launch_bounds__(kBlock) RTR_RESOLVE_ATTR void k_resolve(DeviceScene sc, FrameBatch fb, uint32_t planeStride, const float4* hitTuvp,
                                                     const uint32_t* hitCustom, const uint8_t* vis, uint32_t slotStride, Counters* stats, uint32_t rowWaves) {
     /* which pixel slot this lane resolves.  Upstream a wave is one 8x8 tile (slot q = tile * 64 + row-in-tile * 8 + column-in-tile).
      * rowWaves (set when the tile rows are whole groups of eight tiles): a pair of workgroups takes eight tiles side by side, and a
@@ -1203,7 +1218,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, FrameBatch f
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
     Accum acc = zero_accum();
-    const uint32_t want = (fo.img[0] != nullptr ? 1u : 0u) | (fo.img[2] != nullptr ? 2u : 0u);   /* analytic / unshadowed outputs */
+    const uint32_t want = FULL ? ((fo.img[0] != nullptr ? 1u : 0u) | (fo.img[2] != nullptr ? 2u : 0u)) : 0u;   /* analytic / unshadowed outputs */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = ((size_t)frame * ra.spp + i) * planeStride + q;
         const float4 r = hitTuvp[k];
@@ -1212,7 +1227,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, FrameBatch f
         LookupPolicy pol{vis, (uint32_t)k, slotStride};
         shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
-    write_pixel(ra, fo, out_index(ra, px, lrow, py), acc);
+    if (FULL) write_pixel(ra, fo, out_index(ra, px, lrow, py), acc);
+    else write_pixel_framebuffer(ra, fo, out_index(ra, px, lrow, py), acc.shadowed);
     if (STATS) st.flush(stats);
 }
 
@@ -1256,7 +1272,7 @@ const TunableField kTunables[] = {
     {"trace_bvh4", &Tunables::trace_bvh4, 0u, 1u}, {"trace_batch", &Tunables::trace_batch, 0u, 1u << 20}, {"trace_binned", &Tunables::trace_binned, 0u, 2u},
     {"queue_nt", &Tunables::queue_nt, 0u, 3u}, {"trace_wgs_per_cu", &Tunables::trace_wgs_per_cu, 0u, 8u}, {"trace_refill", &Tunables::trace_refill, 1u, 64u},
     {"trace_inner_min", &Tunables::trace_inner_min, 0u, 63u}, {"trace_octant_forms", &Tunables::trace_octant_forms, 0u, 1u},
-    {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u},
+    {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u}, {"split_priorities", &Tunables::split_priorities, 0u, 1u},
 };
 }  // namespace
 
@@ -1409,8 +1425,15 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     if (ev) hipEventRecord(ev[3], s);
     const uint32_t kRowWaves = tun.resolve_row_waves;
     const uint32_t rowWaves = (kRowWaves && ra.tilesPerRow % 8u == 0u && blocks % 2u == 0u) ? 1u : 0u;
-    if (stats) hipLaunchKernelGGL((k_resolve<true>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
-    else hipLaunchKernelGGL((k_resolve<false>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+    /* every frame of a launch has the same image set (params.images): framebuffer-only launches take the trimmed form */
+    const bool full = (ra.images & ~((1u << 1) | (1u << 16))) != 0u;          /* anything beside RTR_IMAGE_SHADOWED (1) and RTR_IMAGE_HDR (16) */
+    if (stats) {
+        if (full) hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+        else hipLaunchKernelGGL((k_resolve<true, false>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+    } else {
+        if (full) hipLaunchKernelGGL((k_resolve<false, true>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+        else hipLaunchKernelGGL((k_resolve<false, false>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
+    }
     if (ev) hipEventRecord(ev[4], s);
     return hipGetLastError();
 }

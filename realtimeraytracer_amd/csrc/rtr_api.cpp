@@ -211,7 +211,13 @@ uint32_t rtr_shard_rows(uint32_t height, uint32_t bandRows, uint32_t shardCount)
 }
 
 /* ---- context ------------------------------------------------------------------------------ */
-int rtr_ctx_create(int ordinal, rtr_ctx** out) {
+static int ctx_create_prio(int ordinal, int priorityRank, rtr_ctx** out);
+
+int rtr_ctx_create(int ordinal, rtr_ctx** out) { return ctx_create_prio(ordinal, -1, out); }
+
+/* priorityRank < 0: a stream of default priority.  >= 0: rank 0 gets the device's highest stream priority, rank 1 the next ... (the
+ * parts of a split render: the dispatcher then prefers the workgroups of an earlier part wherever two parts compete for a slot) */
+static int ctx_create_prio(int ordinal, int priorityRank, rtr_ctx** out) {
     if (!out) return fail(RTR_ERR_INVALID_ARGUMENT, "rtr_ctx_create: out is null");
     *out = nullptr;
     int count = 0;
@@ -226,7 +232,13 @@ int rtr_ctx_create(int ordinal, rtr_ctx** out) {
     e = hipGetDeviceProperties(&c->prop, ordinal);
     if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
     if (hipDeviceGetAttribute(&c->numXccs, hipDeviceAttributeNumberOfXccs, ordinal) != hipSuccess) c->numXccs = 0;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (priorityRank >= 0) {
+        int least = 0, greatest = 0;                     /* numerically: greatest priority = the smaller number */
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+        int prio = greatest + priorityRank;
+        if (prio > least) prio = least;
+        e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
+    } else e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(RTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->ownStream = true;
     c->tun = rtrdev::tunables_from_env();
@@ -1141,7 +1153,7 @@ int rtr_render_split_async(rtr_scene* s, const RtrCameraData* cam, const RtrScen
     /* the parts: internal frame objects (scratch, events, counters; no images) on contexts (streams) of their own */
     while (f->parts.size() < parts) {
         rtr_ctx* pc = nullptr; rtr_frame* pf = nullptr;
-        int rc = rtr_ctx_create(f->ctx->device, &pc);
+        int rc = ctx_create_prio(f->ctx->device, f->ctx->tun.split_priorities ? (int)f->parts.size() : -1, &pc);
         if (rc != RTR_OK) return rc;
         rc = frame_new(pc, f->width, f->rows, f->images, false, &pf);
         if (rc != RTR_OK) { rtr_ctx_destroy(pc); return rc; }
