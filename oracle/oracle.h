@@ -35,6 +35,11 @@ typedef struct oracle_scene {
      * work counters (numShadowNodeVisits = 64-B records visited, numShadowTriTests) can be held equal to the kernel's.  The
      * visibility of a ray does not depend on which structure is walked (tests compare all of them with the brute-force mode). */
     const RtrWideNode* wide;  uint32_t numWide;
+    /* How the staged pipeline (params.pipeline != 1) walks its CAMERA rays over `nodes` — it decides the work counters, never the hits:
+     * 0 (what the product does by default): one ray per lane with 16 stack entries, deeper rays re-traced from scratch (k_primary +
+     * k_primary_tail);  1 (tunable primary_packet = 1): the 64 rays of an 8x8 tile as one packet (k_primary_packet: a node is visited
+     * when any lane's ray hits it, one stack of {child, lane mask} per tile; counters count every lane of a visited mask). */
+    uint32_t primaryPackets;
 } oracle_scene;
 
 typedef struct oracle_out {

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 class oracle_scene(C.Structure):
     _fields_ = [("desc", A.rtr_scene_desc), ("nodes", C.POINTER(A.RtrBvhNode)), ("numNodes", A.u32),
                 ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid),
-                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32)]
+                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("primaryPackets", A.u32)]
 
 
 class oracle_out(C.Structure):
@@ -66,11 +66,13 @@ def lib():
     return _lib
 
 
-def make_scene(desc, bvh=None):
+def make_scene(desc, bvh=None, primary_packets=False):
     """bvh = (nodes, tris, grid) from api.Scene.export_bvh() (ctypes arrays + the RtrBvhGrid of rtr_scene_stats), or None
-    for brute force."""
+    for brute force.  primary_packets: the staged pipeline's camera rays are walked one ray per lane (the product's default, k_primary) or
+    tile by tile (tunable primary_packet = 1, k_primary_packet) — it decides work counters only."""
     s = oracle_scene()
     s.desc = desc
+    s.primaryPackets = 1 if primary_packets else 0
     if bvh is not None:
         nodes, tris, grid = bvh
         wide = getattr(bvh, "wide", None)
@@ -90,12 +92,12 @@ class Result:
     pass
 
 
-def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1):
+def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False):
     """Returns a Result with numpy uint32 images (rows x width) keyed like rtr_image, .hdr and .stats."""
     L = lib()
     rows = _shard_rows(params.height, params.bandRows or 8, params.shardCount or 1)
     W = params.width
-    sc = make_scene(desc, bvh)
+    sc = make_scene(desc, bvh, primary_packets)
     out = oracle_out()
     r = Result()
     r.images = {}

@@ -45,6 +45,7 @@ struct Scene {
     rtr_v3 skyLinear;
     bool useWide = false;                   /* shadow rays over the wide view (oracle_scene::wide) */
     int primaryStackLimit = 0;              /* 16 in the staged pipeline (k_primary_persist / k_primary + k_primary_tail), 0 = unbounded (megakernel) */
+    bool primaryPackets = false;            /* camera rays walked tile by tile (trace_packet, k_primary_packet) */
 };
 
 struct Hit { bool hit; float t, u, v; uint32_t custom, prim; };
@@ -178,6 +179,87 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
         cur = stack[--sp];
     }
     return best;
+}
+
+/* The camera rays of one 8x8 tile walking the BVH2 as ONE packet, restating k_primary_packet
+ * (realtimeraytracer_amd/csrc/kernels/rtr_kernels.hip): lanes 0..63 = the tile's pixels row by row (`valid`: the lane has a pixel);
+ * a node is visited with the mask of the lanes whose rays hit its box at the parent (the root: every valid lane); every lane of the
+ * mask tests both child boxes against its own ray and its own closest t so far; the masks of the two children are the lanes that hit
+ * them; one child hit: enter it; both: enter the one that is nearer (strictly, t_right < t_left) for more of the lanes that hit both
+ * — ties: child 0 — and stack {other child, its mask}; a leaf's triangles are tested in storage order by the lanes of its mask, each
+ * keeping its own closest hit (min over (t, customIndex, primitiveID)).  Counters: a node visit / triangle test per lane of the mask. */
+void trace_packet(const Scene& sc, rtr_v3 o, const rtr_v3* d, const bool* valid, float tmin, float tmax, Hit* out, Counters& c) {
+    const RtrBvhNode* nodes = sc.s->nodes;
+    const RtrBvhTri* tris = sc.s->tris;
+    rtr_v3 ga[64], gb[64];
+    uint64_t active = 0;
+    for (int l = 0; l < 64; ++l) {
+        out[l].hit = false; out[l].t = tmax; out[l].u = out[l].v = 0.f; out[l].custom = out[l].prim = 0xffffffffu;
+        if (!valid[l]) continue;
+        active |= 1ull << l;
+        c.rays++; c.primary++;
+        const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d[l].x), rtr_safe_rcp_dir(d[l].y), rtr_safe_rcp_dir(d[l].z));
+        rtr_ray_grid(o, idir, sc.s->grid.origin, sc.s->grid.scale, &ga[l], &gb[l]);
+    }
+    if (!active) return;
+    struct Entry { int32_t code; uint64_t mask; };
+    Entry stack[128];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        bool pop = true;
+        if (cur >= 0) {
+            const RtrBvhNode& n = nodes[cur];
+            const uint16_t* q = n.q;
+            uint64_t mL = 0, mR = 0;
+            int rNear = 0, lNear = 0;
+            for (int l = 0; l < 64; ++l) {
+                if (!((active >> l) & 1ull)) continue;
+                c.nodes++;
+                float tl, tr;
+                const float limit = out[l].t;                 /* tmax until something is hit: the kernel's best.t */
+                const int hl = rtr_slab_q(q[RTR_BVH_QSLOT(0, 0, 0)], q[RTR_BVH_QSLOT(0, 0, 1)], q[RTR_BVH_QSLOT(0, 0, 2)],
+                                          q[RTR_BVH_QSLOT(0, 1, 0)], q[RTR_BVH_QSLOT(0, 1, 1)], q[RTR_BVH_QSLOT(0, 1, 2)], ga[l], gb[l], tmin, limit, &tl);
+                const int hr = rtr_slab_q(q[RTR_BVH_QSLOT(1, 0, 0)], q[RTR_BVH_QSLOT(1, 0, 1)], q[RTR_BVH_QSLOT(1, 0, 2)],
+                                          q[RTR_BVH_QSLOT(1, 1, 0)], q[RTR_BVH_QSLOT(1, 1, 1)], q[RTR_BVH_QSLOT(1, 1, 2)], ga[l], gb[l], tmin, limit, &tr);
+                if (hl) mL |= 1ull << l;
+                if (hr) mR |= 1ull << l;
+                if (hl && hr) { if (tr < tl) ++rNear; else ++lNear; }
+            }
+            if (mL | mR) {
+                pop = false;
+                if (!mR) { cur = n.child[0]; active = mL; }
+                else if (!mL) { cur = n.child[1]; active = mR; }
+                else {
+                    const bool rFirst = rNear > lNear;
+                    stack[sp++] = Entry{rFirst ? n.child[0] : n.child[1], rFirst ? mL : mR};
+                    cur = rFirst ? n.child[1] : n.child[0]; active = rFirst ? mR : mL;
+                }
+            }
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const RtrBvhTri& tr = tris[first + i];
+                for (int l = 0; l < 64; ++l) {
+                    if (!((active >> l) & 1ull)) continue;
+                    c.tris++;
+                    float t, u, v;
+                    if (!rtr_mt_intersect(o, d[l], rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) continue;
+                    if (!(t < tmax)) continue;
+                    if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
+                    Hit& b = out[l];
+                    if (t < b.t || (t == b.t && id_less(tr.customIndex, tr.primitiveId, b.custom, b.prim))) {
+                        b.hit = true; b.t = t; b.u = u; b.v = v; b.custom = tr.customIndex; b.prim = tr.primitiveId;
+                    }
+                }
+            }
+        }
+        if (pop) {
+            if (sp == 0) break;
+            --sp; cur = stack[sp].code; active = stack[sp].mask;
+        }
+    }
 }
 
 /* IEEE binary16 -> binary32 (exact), no compiler support needed */
@@ -410,8 +492,9 @@ inline Surface closest_hit_shader(const Scene& sc, const Hit& h, rtr_v3 rayDir, 
 /* ---- raygen.rgen:71-366 for one pixel --------------------------------------------------------- */
 struct PixelOut { rtr_v3 analytic, shadowed, unshadowed, avgNormal, avgPosition; };
 
+/* preHits: the pixel's camera-ray hits (one per sample) when they were found tile by tile (trace_packet), else null */
 PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneInfo& info,
-                     const rtr_render_params& prm, uint32_t px, uint32_t py, bool wantAnalytic, bool wantUnshadowed, Counters& c) {
+                     const rtr_render_params& prm, uint32_t px, uint32_t py, bool wantAnalytic, bool wantUnshadowed, Counters& c, const Hit* preHits = nullptr) {
     const rtr_scene_desc& D = sc.s->desc;
     (void)wantUnshadowed;          /* every sum is evaluated for every sample, as the shader does; the flag only says which are stored */
     PixelOut o;
@@ -427,7 +510,7 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
         float offx = ((float)px + jx) - 0.5f, offy = ((float)py + jy) - 0.5f;            /* :84 */
         rtr_v3 pw = rtr_madd(rtr_madd(TL, dH, offx), dV, offy);                          /* :86-89 */
         rtr_v3 rayDir = rtr_normalize(rtr_sub(pw, camPos));                              /* :91-92 */
-        Hit h = trace(sc, camPos, rayDir, 0.001f, 10000.0f, false, c);                   /* :99-107 */
+        Hit h = preHits ? preHits[i] : trace(sc, camPos, rayDir, 0.001f, 10000.0f, false, c);   /* :99-107 */
         if (!h.hit) {                                                                    /* :110-115, miss.rmiss:15-27 */
             rtr_v3 sky = sc.skyLinear;
             if (D.hdri) {
@@ -666,12 +749,40 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     if (!prepare(s, sc)) return -1;
     sc.useWide = s->wide != nullptr && s->nodes != nullptr && s->numWide > 0 && prm.pipeline != 1;
     sc.primaryStackLimit = (s->nodes != nullptr && prm.pipeline != 1) ? 16 : 0;
+    sc.primaryPackets = s->nodes != nullptr && prm.pipeline != 1 && s->primaryPackets != 0;
     const uint32_t rows = shard_rows(prm.height, prm.bandRows, prm.shardCount);
     const uint32_t W = prm.width;
     BandMap bm{prm.bandRows, prm.shardIndex, prm.shardCount, prm.height};
     int nthreads = threads < 1 ? 1 : threads;
     std::vector<Counters> counters((size_t)nthreads);
     const float invFrames = (float)(prm.accumulatedFrames + 1u);
+    /* camera rays tile by tile, as k_primary_packet walks them: a wave is one 8x8 tile of the LOCAL image (rows of the shard), one
+     * sample plane at a time; lane = row in tile * 8 + column in tile */
+    std::vector<Hit> pre;
+    if (sc.primaryPackets) {
+        pre.resize((size_t)rows * W * prm.spp);
+        const uint32_t tilesPerRow = (W + 7u) / 8u, bands8 = (rows + 7u) / 8u;
+        const rtr_v3 camPos = rtr_ld3(cam->position), TL = rtr_ld3(cam->topLeftViewportCorner);
+        const rtr_v3 dH = rtr_ld3(cam->horizontalViewportDelta), dV = rtr_ld3(cam->verticalViewportDelta);
+        parallel_rows(bands8, nthreads, [&](uint32_t band8, int tid) {
+            for (uint32_t i = 0; i < prm.spp; ++i)
+                for (uint32_t tx = 0; tx < tilesPerRow; ++tx) {
+                    rtr_v3 d[64]; bool valid[64]; Hit h[64];
+                    for (uint32_t l = 0; l < 64; ++l) {
+                        const uint32_t x = tx * 8u + (l & 7u), lr = band8 * 8u + (l >> 3);
+                        const int64_t gy = lr < rows ? bm.global_y(lr) : -1;
+                        valid[l] = x < W && gy >= 0;
+                        d[l] = rtr_mk(0.f, 0.f, 1.f);
+                        if (!valid[l]) continue;
+                        const float jx = rtr_random(x + i), jy = rtr_random(x + i * 322u);
+                        const float offx = ((float)x + jx) - 0.5f, offy = ((float)(uint32_t)gy + jy) - 0.5f;
+                        d[l] = rtr_normalize(rtr_sub(rtr_madd(rtr_madd(TL, dH, offx), dV, offy), camPos));
+                    }
+                    trace_packet(sc, camPos, d, valid, 0.001f, 10000.0f, h, counters[(size_t)tid]);
+                    for (uint32_t l = 0; l < 64; ++l) if (valid[l]) pre[((size_t)(band8 * 8u + (l >> 3)) * W + tx * 8u + (l & 7u)) * prm.spp + i] = h[l];
+                }
+        });
+    }
 
     parallel_rows(rows, nthreads, [&](uint32_t lr, int tid) {
         int64_t gy = bm.global_y(lr);
@@ -686,7 +797,8 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
                 if (out->hdr && !prm.accumulate) { out->hdr[4 * p] = out->hdr[4 * p + 1] = out->hdr[4 * p + 2] = out->hdr[4 * p + 3] = 0; }
                 continue;
             }
-            PixelOut po = shade_pixel(sc, *cam, *info, prm, x, (uint32_t)gy, wantAnalytic, out->unshadowed != nullptr, counters[(size_t)tid]);
+            PixelOut po = shade_pixel(sc, *cam, *info, prm, x, (uint32_t)gy, wantAnalytic, out->unshadowed != nullptr, counters[(size_t)tid],
+                                      sc.primaryPackets ? &pre[p * prm.spp] : nullptr);
             rtr_v3 sh = po.shadowed;
             if (out->hdr) {
                 float* h = out->hdr + 4 * p;

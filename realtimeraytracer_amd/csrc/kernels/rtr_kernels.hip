@@ -233,6 +233,114 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, FrameBatch f
     if (STATS) st.flush(stats);
 }
 
+/* ---- wavefront stage 1, packet form: the camera rays of one 8x8 tile walk the BVH2 TOGETHER ------------------------------------
+ * Camera rays of a tile are the most coherent rays there are: they share their origin and differ by a few hundredths in direction,
+ * so the 64 lanes of a wave visit nearly the same nodes.  One ray per lane (k_primary) each lane still chases its own chain of dependent
+ * vector fetches with its own LDS stack, and the kernel is as slow as its deepest lane (0.32 ms for a 1080p frame rendered alone,
+ * any 8-row band by itself 40-270 us).  Here the wave walks ONE path through the tree:
+ *   * a node is visited when ANY lane's ray hits its box; the record's address is wave-uniform, so the fetch is a SCALAR load (the
+ *     constant cache, no per-lane look-ups) and there is one stack per wave, in LDS, of {child, 64-bit mask of the lanes that hit it};
+ *   * each lane tests the two child boxes against ITS ray and ITS closest hit so far (the same slab test, the same limit as one ray
+ *     per lane); a ballot turns the results into the two children's lane masks; where both are hit the child that is nearer for
+ *     more of the lanes that hit both is entered first (ties: child 0), the other is stacked with its mask;
+ *   * a leaf's triangles are tested — records fetched with scalar loads — by the lanes of the leaf's mask, each keeping its own
+ *     closest hit by the rule of trace(): min over (t, customIndex, primitiveID).
+ * The stack holds at most one entry per level of the tree (<= 64: the builders' depth bound), so no ray is ever abandoned to a tail
+ * kernel.  MEASURED: no faster than one ray per lane (0.168 ms per 1080p frame in an eight-frame launch, 0.334 alone, against 0.167 /
+ * 0.320 — profiles/r04/ab_primary_packet.log): the wave now walks the union of its lanes' nodes strictly one after the other, ONE fetch
+ * in flight, where 64 lanes chase 64 chains side by side; what it saves in look-ups and stack traffic it pays in serial latency.  Kept
+ * as a second implementation (tunable primary_packet = 1), held to the oracle like the first.  A lane's hit is the same as one ray per
+ * lane finds: culling is conservative with respect to the lane's own best t and the
+ * closest hit does not depend on the order triangles are met in (tests: bit-identical images against k_primary, the megakernel and
+ * the oracle).  What does depend on the walk is the WORK — a lane now also looks at nodes its neighbours needed — so the counting
+ * form counts a node visit / triangle test for every lane of the visited mask, and the oracle restates this walk tile by tile
+ * (oracle_render.cpp: trace_packet) for the counters to be held equal. */
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, Counters* stats, uint32_t planeBlocks) {
+    __shared__ uint4 s_stack[kBlock / 64][64];           /* per wave: {child code, mask low, mask high, -} */
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t plane = blockIdx.x / planeBlocks;                 /* frame of the batch * spp + sample */
+    const RenderArgs& ra = fb.ra[plane / fb.ra[0].spp];
+    const uint32_t i = plane % fb.ra[0].spp;
+    const uint32_t q = (blockIdx.x - plane * planeBlocks) * kBlock + threadIdx.x;
+    uint32_t px = 0, lrow = 0, py = 0;
+    const bool valid = pixel_of(ra, q, px, lrow, py);
+    unsigned long long active = __ballot(valid);
+    if (active == 0ull) return;                                       /* a wave of padding slots (wave-uniform) */
+    LocalStats st;
+    const rtr_v3 o = rtr_ld3(ra.cam.position);
+    const rtr_v3 d = valid ? primary_dir(ra, px, py, i) : rtr_mk(0.f, 0.f, 1.f);
+    const float tmin = 0.001f, tmax = 10000.0f;
+    if (STATS && valid) { st.rays++; st.primary++; }
+    const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+    rtr_v3 ga, gb;
+    rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
+    HitRec best; best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+    const uint4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ tris = sc.tris;
+    uint32_t sp = 0;
+    int32_t cur = 0;                                                  /* wave-uniform */
+    for (;;) {
+        const bool mine = ((active >> lane) & 1ull) != 0ull;
+        bool pop = true;
+        if (cur >= 0) {
+            const uint4 a = nodes[2 * cur], b = nodes[2 * cur + 1];  /* uniform address: scalar loads */
+            if (STATS && mine) st.nodes++;
+            float tl = 0.f, tr = 0.f;
+            const bool hl = mine && slab_pair(a.x, a.y, b.x, ga, gb, tmin, best.t, tl);
+            const bool hr = mine && slab_pair(a.z, a.w, b.y, ga, gb, tmin, best.t, tr);
+            const unsigned long long mL = __ballot(hl), mR = __ballot(hr);
+            if ((mL | mR) != 0ull) {
+                pop = false;
+                if (mR == 0ull) { cur = (int32_t)b.z; active = mL; }
+                else if (mL == 0ull) { cur = (int32_t)b.w; active = mR; }
+                else {
+                    /* the vote of the lanes that hit both boxes: which child is nearer for more of them (ties: child 0) */
+                    const uint32_t rNear = (uint32_t)__popcll(__ballot(hl && hr && tr < tl)), lNear = (uint32_t)__popcll(__ballot(hl && hr && !(tr < tl)));
+                    const bool rFirst = rNear > lNear;
+                    if (lane == 0u) {
+                        const unsigned long long m2 = rFirst ? mL : mR;
+                        s_stack[wave][sp] = make_uint4(rFirst ? b.z : b.w, (uint32_t)m2, (uint32_t)(m2 >> 32), 0u);
+                    }
+                    ++sp;
+                    cur = (int32_t)(rFirst ? b.w : b.z); active = rFirst ? mR : mL;
+                }
+            }
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4 q0 = tris[3u * (first + k)], q1 = tris[3u * (first + k) + 1u], q2 = tris[3u * (first + k) + 2u];      /* uniform: scalar loads */
+                if (mine) {
+                    if (STATS) st.tris++;
+                    float t, u, v;
+                    if (rtr_mt_intersect(o, d, f4xyz(q0), f4xyz(q1), f4xyz(q2), tmin, &t, &u, &v) && t < tmax) {
+                        const uint32_t cu = __float_as_uint(q0.w), pr = __float_as_uint(q1.w);
+                        if (!(__float_as_uint(q2.w) & 1u) || alpha_pass<STATS>(sc, cu, pr, u, v, st)) {
+                            if (t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)))) {
+                                best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (pop) {
+            if (sp == 0u) break;
+            --sp;
+            const uint4 e = s_stack[wave][sp];                        /* the same address in every lane: a broadcast read */
+            cur = __builtin_amdgcn_readfirstlane((int32_t)e.x);
+            active = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)e.y) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)e.z) << 32);
+        }
+    }
+    if (valid) {
+        const size_t k = (size_t)plane * planeBlocks * kBlock + q;
+        hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim));
+        hitCustom[k] = best.custom;
+    }
+    if (STATS) st.flush(stats);
+}
+
 /* Re-traces the pixel-samples the primary kernels abandoned: BVH2 walk with a full-depth stack in global memory (no LDS, so it
  * can always run).  STATS: the counting form (the ray itself was counted by the kernel that abandoned it). */
 template <bool STATS>
@@ -1266,7 +1374,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_planes(uint4* __restrict__ vis,
 namespace {
 struct TunableField { const char* name; uint32_t Tunables::* field; uint32_t lo, hi; };
 const TunableField kTunables[] = {
-    {"primary_persist", &Tunables::primary_persist, 0u, 2u}, {"primary_persist_min_rays", &Tunables::primary_persist_min_rays, 0u, 0xffffffffu},
+    {"primary_packet", &Tunables::primary_packet, 0u, 1u}, {"primary_persist", &Tunables::primary_persist, 0u, 2u}, {"primary_persist_min_rays", &Tunables::primary_persist_min_rays, 0u, 0xffffffffu},
     {"primary_batch", &Tunables::primary_batch, 64u, 1u << 16}, {"primary_refill", &Tunables::primary_refill, 1u, 64u},
     {"primary_inner_min", &Tunables::primary_inner_min, 0u, 63u}, {"primary_wgs_per_cu", &Tunables::primary_wgs_per_cu, 1u, 8u},
     {"trace_bvh4", &Tunables::trace_bvh4, 0u, 1u}, {"trace_batch", &Tunables::trace_batch, 0u, 1u << 20}, {"trace_binned", &Tunables::trace_binned, 0u, 2u},
@@ -1356,6 +1464,7 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
      * takes one lane per (sample, pixel) it is the other way round at every size (0.77 against 0.98 ms; whole frames 3-9 % slower with
      * RTR_PRIMARY_PERSIST=2, profiles/r03/ab_primary_persist_auto.log), so nothing selects it by default. */
     const unsigned long long camRays = (unsigned long long)planeStride * ra.spp;
+    bool packet = false;
     if ((kPersist == 1u || (kPersist == 2u && camRays >= kPersistMinRays)) && nb == 1u && camRays < 0xffffffffull) {
         uint32_t pblocks = numCus * kPWgsPerCu;
         const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
@@ -1363,10 +1472,17 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         if (pblocks == 0) pblocks = 1;
         if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
         else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+    } else if (tun.primary_packet) {
+        /* a tile's camera rays walk the tree as one packet (no ray is ever left to the tail kernel: it is not launched); not the default */
+        packet = true;
+        if (stats) hipLaunchKernelGGL((k_primary_packet<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, blocks);
+        else hipLaunchKernelGGL((k_primary_packet<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, blocks);
     } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
     else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
-    if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
-    else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+    if (!packet) {
+        if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+        else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+    }
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
     const uint32_t kBatchEnv = tun.trace_batch;        /* 0 (default): by the length of the queue */

@@ -211,17 +211,26 @@ def test_sponza_1080p_properties_and_sampled_oracle(gpu_ctx, oracle, scene_cache
     W, H = 1920, 1080
     s = scenes.sponza_class(W, H)
     scene = api.Scene(gpu_ctx, s.desc)
-    _, fw = _gpu_render(gpu_ctx, s, api.make_params(W, H, collect_stats=1, pipeline=2), scene=scene)
+    gpu_ctx.set_tunable("primary_packet", 1)            # camera rays as 8x8 packets (k_primary_packet): one stack per tile, no ray is ever abandoned
+    try:
+        _, fw = _gpu_render(gpu_ctx, s, api.make_params(W, H, collect_stats=1, pipeline=2), scene=scene)
+    finally:
+        gpu_ctx.set_tunable("primary_packet", 0)
     wave = fw.download()
+    stp = fw.stats()
+    assert stp.primaryTailRays == 0
+    _, fw = _gpu_render(gpu_ctx, s, api.make_params(W, H, collect_stats=1, pipeline=2), scene=scene, frame=fw)       # ... and one ray per lane (the default): the same frame
+    _assert_same(fw.download(), wave, "camera rays one per lane vs as packets at 1080p")
     stw = fw.stats()
     _, fm = _gpu_render(gpu_ctx, s, api.make_params(W, H, collect_stats=1, pipeline=1), scene=scene)
     _assert_same(fm.download(), wave, "megakernel vs wavefront at 1080p")
     stm = fm.stats()
-    # camera rays walk the BVH2 in both pipelines (the staged one with a 16-entry stack + redo: the redone rays' visits are counted
-    # twice); shadow rays walk the wide view in the staged pipeline only
-    assert stw.numPrimaryRays == W * H and stw.numRays == stm.numRays
+    # one ray per lane, camera rays walk the BVH2 in both pipelines (the staged one with a 16-entry stack + redo: the redone rays'
+    # visits are counted twice); shadow rays walk the wide view in the staged pipeline only
+    assert stw.numPrimaryRays == W * H and stw.numRays == stm.numRays == stp.numRays
     pw, pm = stw.numNodeVisits - stw.numShadowNodeVisits, stm.numNodeVisits - stm.numShadowNodeVisits
     assert pw >= pm and (pw == pm) == (stw.primaryTailRays == 0)
+    assert stp.numShadowNodeVisits == stw.numShadowNodeVisits and stp.numHits == stw.numHits          # the walk of the camera rays changes their work only
     api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H, pipeline=2), fw)
     _assert_same(fw.download(), wave, "idempotence")
     rows = api.shard_rows(H, 8, 8)
@@ -557,18 +566,25 @@ def test_deep_stack_rays_take_the_tail_kernel(gpu_ctx, oracle):
     cam2 = host.Camera(0.004, (-30.0, -0.995, 0.0), (0.8 * end, -1.0, 0.0), (0.0, 1.0, 0.0), W, H).getGPUData()    # inside the boxes' padding all the way
     info2 = host.scene_info(1, 1, (-30.0, -0.995, 0.0))
     out = {}
-    for collect in (0, 1):
-        p = api.make_params(W, H, spp=2, collect_stats=collect, pipeline=2)
-        f2 = api.Frame(gpu_ctx, W, H)
-        api.render(scene2, cam2, info2, p, f2)
-        out[collect] = f2.download()
-        if collect:
-            ref2 = oracle.render(d2, cam2, info2, p, bvh=bvh2, threads=16)
-            _assert_same(out[1], ref2.images[A.IMAGE_SHADOWED], "skimming primary rays, counting kernels")
-            g2 = f2.stats()
-            assert (g2.numNodeVisits, g2.numTriTests, g2.numHits) == (ref2.stats.numNodeVisits, ref2.stats.numTriTests, ref2.stats.numHits)
-            assert (g2.numNodeVisits - g2.numShadowNodeVisits) / g2.numPrimaryRays > 1000, "primary rays must walk a long stretch of the row"
-    _assert_same(out[0], out[1], "production k_primary (16 LDS entries + redo tail) vs counting kernel")
+    for packets in (1, 0):              # as 8x8 packets (one stack per tile, as deep as the tree: > 16 entries here), and one ray per lane (16 LDS entries + redo tail)
+        gpu_ctx.set_tunable("primary_packet", packets)
+        try:
+            for collect in (0, 1):
+                p = api.make_params(W, H, spp=2, collect_stats=collect, pipeline=2)
+                f2 = api.Frame(gpu_ctx, W, H)
+                api.render(scene2, cam2, info2, p, f2)
+                out[packets, collect] = f2.download()
+                if collect:
+                    ref2 = oracle.render(d2, cam2, info2, p, bvh=bvh2, threads=16, primary_packets=bool(packets))
+                    _assert_same(out[packets, 1], ref2.images[A.IMAGE_SHADOWED], "skimming primary rays, counting kernels")
+                    g2 = f2.stats()
+                    assert (g2.numNodeVisits, g2.numTriTests, g2.numHits, g2.primaryTailRays) == (ref2.stats.numNodeVisits, ref2.stats.numTriTests, ref2.stats.numHits, ref2.stats.primaryTailRays), packets
+                    assert (g2.numNodeVisits - g2.numShadowNodeVisits) / g2.numPrimaryRays > 1000, "primary rays must walk a long stretch of the row"
+                    assert (g2.primaryTailRays > 0) == (packets == 0)
+        finally:
+            gpu_ctx.set_tunable("primary_packet", 0)
+        _assert_same(out[packets, 0], out[packets, 1], "timed camera-ray kernel vs its counting form")
+    _assert_same(out[0, 0], out[1, 0], "camera rays one per lane (16 LDS entries + redo tail) vs as packets")
 
 
 def test_context_may_be_destroyed_before_its_children(gpu_ctx, scene_cache):
@@ -1036,7 +1052,7 @@ def test_tunables_belong_to_the_context_and_change_no_pixel(gpu_ctx, scene_cache
     assert c.get_tunable("trace_refill") == 33 and gpu_ctx.get_tunable("trace_refill") == 20
     fr = api.Frame(c, W, H)
     for name, value in (("trace_binned", 1), ("trace_batch", 64), ("trace_wgs_per_cu", 3), ("trace_inner_min", 5), ("trace_octant_forms", 0),
-                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
+                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("primary_packet", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
         c.set_tunable(name, value)
         assert c.get_tunable(name) == value
         api.render(scene, s.camera, s.scene_info(0), p, fr)

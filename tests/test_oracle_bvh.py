@@ -293,3 +293,24 @@ def test_sponza_mixed_size_mix_alpha_layer_and_the_tree_it_gets(oracle, scene_ca
     b = oracle.render(s.desc, s.camera, s.scene_info(2), p, bvh=None, threads=8)
     assert np.array_equal(a.images[1], b.images[1]) and a.stats.numRays == b.stats.numRays
     assert isinstance(st, A.rtr_scene_stats) and ctypes.sizeof(st) > 0
+
+
+def test_oracle_packet_walk_of_the_camera_rays_finds_the_same_hits(oracle, scene_cache):
+    """trace_packet (the restatement of k_primary_packet: the 64 camera rays of an 8x8 tile walking the BVH2 as one packet, a stack of
+    {child, lane mask} per tile) changes the WORK of the camera rays, never what they hit: same image as one ray per lane and as brute
+    force, same ray / hit counts, same shadow-ray work — sharded (padding rows, partial tiles) and at several samples per pixel."""
+    for name, W, H, spp in (("cornell_box", 100, 60, 2), ("bunny_class", 117, 70, 1)):
+        s = getattr(scenes, name)(W, H)
+        bvh = api.host_build_bvh_wide(s.desc)
+        for shard in ((0, 1), (1, 3)):
+            p = _params(W, H, spp=spp)
+            p.collectStats, p.pipeline, p.shardIndex, p.shardCount = 1, 2, shard[0], shard[1]
+            a = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=bvh, threads=8, primary_packets=True)
+            b = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=bvh, threads=8, primary_packets=False)
+            assert np.array_equal(a.images[1], b.images[1]), (name, shard)
+            for f in ("numRays", "numPrimaryRays", "numHits", "numShadowNodeVisits", "numShadowTriTests"):
+                assert getattr(a.stats, f) == getattr(b.stats, f), f
+            assert a.stats.primaryTailRays == 0 and a.stats.numNodeVisits > a.stats.numShadowNodeVisits
+            if shard == (0, 1) and name == "cornell_box":
+                c = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=None, threads=8)
+                assert np.array_equal(a.images[1], c.images[1])
