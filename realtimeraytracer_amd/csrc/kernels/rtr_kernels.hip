@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
     const bool live = frame < fb.n && pixel_of(ra, q, px, lrow, py);
     LocalStats st;
     Accum acc = zero_accum();
-    const bool single = ra.spp == 1u;
+    const bool single = ra.spp == 1u;                 /* (fetching the surface again in the emit phase instead of keeping it across the reservation: 74 VGPRs instead of 88, and slower — profiles/r04/ab_gen_refetch.log) */
     Surface sf0;
     bool surf0 = false;
     CountOctPolicy cp{0ull, 0ull};
