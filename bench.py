@@ -313,6 +313,9 @@ def run_inproc(args, K, plan):
             return best
         c = pick_frames_per_launch(args.max_latency_ms, cap, probe)
         B, groups = c, max(nbuf // c, 1)
+        for _ in range(groups):                         # the slots that lead launches of this size grow their scratch now, not in the timed region
+            run_steps(0, B)
+        drain()
     run_steps(0, args.warmup)
     drain()
     kern.update({k: 0.0 for k in kern}); kern["n"] = 0
@@ -766,6 +769,9 @@ def main():
         B, groups = c, max(nbuf // c, 1)
         if not dist_on:                                 # one launch at a time on one GPU: the frame objects of one launch
             nbuf, groups = B, 1
+        for _ in range(groups):                         # the frames that lead launches of this size grow their scratch now, not in the timed region
+            run_steps(0, B)
+        drain()
     run_steps(0, args.warmup)
     drain()
     kern.update({"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0})

@@ -11,3 +11,12 @@ for l in sys.stdin:
         j=json.loads(l); print('ranks', j['n_gpus'], 'ms/frame', j['ms_per_step'], j['value'], j['unit'], 'slots', j.get('frames_in_flight'), 'per launch', j.get('frames_per_launch'), (j.get('rccl') or {}).get('version'), 'host enqueue ms/frame', (j.get('rccl') or {}).get('host_enqueue_ms_per_frame'), 'inside rccl calls', (j.get('rccl') or {}).get('of_which_inside_rccl_calls'), j.get('verify'), (j.get('rehearsal') or '')[:40])
 "
 done
+# the same with sixteen shards per launch given explicitly (round 3's launches): what ONE exchange per launch does to the ranks' host time
+for n in 4 8; do
+  LD_PRELOAD=$PWD/tests/fake_rccl/libfake_rccl.so RTR_MGPU_TEST_SHARED_DEVICE=1 python3 bench.py --gpus $n --steps 96 --warmup 32 --batch 16 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); print('ranks', j['n_gpus'], '--batch 16: ms/frame', j['ms_per_step'], 'slots', j.get('frames_in_flight'), 'per launch', j.get('frames_per_launch'), 'host enqueue ms/frame', (j.get('rccl') or {}).get('host_enqueue_ms_per_frame'), 'inside rccl calls', (j.get('rccl') or {}).get('of_which_inside_rccl_calls'), j.get('verify'))
+"
+done
