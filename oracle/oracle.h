@@ -38,7 +38,9 @@ typedef struct oracle_scene {
     /* How the staged pipeline (params.pipeline != 1) walks its CAMERA rays over `nodes` — it decides the work counters, never the hits:
      * 0 (what the product does by default): one ray per lane with 16 stack entries, deeper rays re-traced from scratch (k_primary +
      * k_primary_tail);  1 (tunable primary_packet = 1): the 64 rays of an 8x8 tile as one packet (k_primary_packet: a node is visited
-     * when any lane's ray hits it, one stack of {child, lane mask} per tile; counters count every lane of a visited mask). */
+     * when any lane's ray hits it, one stack of {child, lane mask} per tile; counters count every lane of a visited mask);
+     * 2 (tunable primary_wide = 1; needs `wide`): one ray per lane over the 4-wide view, closest hit, 16 stack entries + redo over the
+     * BVH2 (k_primary4). */
     uint32_t primaryPackets;
 } oracle_scene;
 

@@ -66,13 +66,13 @@ def lib():
     return _lib
 
 
-def make_scene(desc, bvh=None, primary_packets=False):
+def make_scene(desc, bvh=None, primary_packets=False, primary_wide=False):
     """bvh = (nodes, tris, grid) from api.Scene.export_bvh() (ctypes arrays + the RtrBvhGrid of rtr_scene_stats), or None
     for brute force.  primary_packets: the staged pipeline's camera rays are walked one ray per lane (the product's default, k_primary) or
     tile by tile (tunable primary_packet = 1, k_primary_packet) — it decides work counters only."""
     s = oracle_scene()
     s.desc = desc
-    s.primaryPackets = 1 if primary_packets else 0
+    s.primaryPackets = 2 if primary_wide else (1 if primary_packets else 0)      # how the staged pipeline walks its camera rays: 0 one ray per lane over the BVH2, 1 8x8 packets, 2 one ray per lane over the 4-wide view
     if bvh is not None:
         nodes, tris, grid = bvh
         wide = getattr(bvh, "wide", None)
@@ -92,12 +92,12 @@ class Result:
     pass
 
 
-def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False):
+def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False):
     """Returns a Result with numpy uint32 images (rows x width) keyed like rtr_image, .hdr and .stats."""
     L = lib()
     rows = _shard_rows(params.height, params.bandRows or 8, params.shardCount or 1)
     W = params.width
-    sc = make_scene(desc, bvh, primary_packets)
+    sc = make_scene(desc, bvh, primary_packets, primary_wide)
     out = oracle_out()
     r = Result()
     r.images = {}

@@ -46,6 +46,7 @@ struct Scene {
     bool useWide = false;                   /* shadow rays over the wide view (oracle_scene::wide) */
     int primaryStackLimit = 0;              /* 16 in the staged pipeline (k_primary_persist / k_primary + k_primary_tail), 0 = unbounded (megakernel) */
     bool primaryPackets = false;            /* camera rays walked tile by tile (trace_packet, k_primary_packet) */
+    bool primaryWide = false;               /* camera rays one per lane over the 4-wide view (trace_wide_closest, k_primary4) */
 };
 
 struct Hit { bool hit; float t, u, v; uint32_t custom, prim; };
@@ -341,11 +342,72 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
     }
 }
 
+/* Closest-hit walk of the 4-wide view, restating k_primary4: trace_wide's rule (nearest hit child first — strict <, ties to the lower
+ * slot — the others stacked in slot order) with the slab tests against the best t so far and ALL triangles of a leaf tested; 16 stack
+ * entries, beyond which the ray is abandoned and walked again from scratch over the BVH2 (k_primary_tail; both parts counted). */
+Hit trace_wide_closest(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Counters& c) {
+    const RtrWideNode* nodes = sc.s->wide;
+    const RtrBvhTri* tris = sc.s->tris;
+    Hit best{}; best.hit = false; best.t = tmax; best.custom = best.prim = 0xffffffffu;
+    rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+    rtr_v3 ga, gb;
+    rtr_ray_grid_centre(o, idir, sc.s->grid.origin, sc.s->grid.scale, sc.s->grid.wideCentreXY, sc.s->grid.wideCentreZ, &ga, &gb);
+    int32_t stack[RTR_WIDE_STACK];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const RtrWideNode& n = nodes[cur];
+            c.nodes++;
+            int hit[4]; float te[4];
+            const float lim = best.t;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t wmin = n.plane[k][0], wmax = n.plane[k][1], wz = n.plane[k][2];
+                const float x0 = rtr_fma(half_bits_to_float(wmin & 0xffffu), ga.x, gb.x), x1 = rtr_fma(half_bits_to_float(wmax & 0xffffu), ga.x, gb.x);
+                const float y0 = rtr_fma(half_bits_to_float(wmin >> 16), ga.y, gb.y), y1 = rtr_fma(half_bits_to_float(wmax >> 16), ga.y, gb.y);
+                const float z0 = rtr_fma(half_bits_to_float(wz & 0xffffu), ga.z, gb.z), z1 = rtr_fma(half_bits_to_float(wz >> 16), ga.z, gb.z);
+                const float lo = rtr_hwmax(rtr_hwmax(rtr_hwmin(x0, x1), rtr_hwmin(y0, y1)), rtr_hwmax(rtr_hwmin(z0, z1), tmin));
+                const float hi = rtr_hwmin(rtr_hwmin(rtr_hwmax(x0, x1), rtr_hwmax(y0, y1)), rtr_hwmin(rtr_hwmax(z0, z1), lim));
+                te[k] = lo;
+                hit[k] = lo <= hi * RTR_BOX_WIDEN;
+                if (k >= 2 && n.child[k] == RTR_WIDE_EMPTY) hit[k] = 0;
+            }
+            int nextSlot = -1;
+            float tn = 3.0e38f;
+            if (hit[0]) { tn = te[0]; nextSlot = 0; }
+            for (int k = 1; k < 4; ++k) if (hit[k] && te[k] < tn) { tn = te[k]; nextSlot = k; }
+            bool overflow = false;
+            for (int k = 0; k < 4; ++k) if (hit[k] && k != nextSlot) { if (sp < RTR_WIDE_STACK) stack[sp++] = n.child[k]; else overflow = true; }
+            if (overflow) { c.primaryOverflow++; return trace_bvh(sc, o, d, tmin, tmax, false, c, 0); }
+            if (nextSlot >= 0) { cur = n.child[nextSlot]; continue; }
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const RtrBvhTri& tr = tris[first + i];
+                float t, u, v;
+                c.tris++;
+                if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
+                    if (!(t < tmax)) continue;
+                    if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
+                    if (t < best.t || (t == best.t && id_less(tr.customIndex, tr.primitiveId, best.custom, best.prim))) {
+                        best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = tr.customIndex; best.prim = tr.primitiveId;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
+
 inline Hit trace(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
     c.rays++;
     if (anyHit) c.shadow++; else c.primary++;
     if (!(tmax > tmin)) { Hit h{}; h.hit = false; return h; }
     if (anyHit && sc.useWide) return trace_wide(sc, o, d, tmin, tmax, c);
+    if (!anyHit && sc.primaryWide) return trace_wide_closest(sc, o, d, tmin, tmax, c);
     return sc.s->nodes ? trace_bvh(sc, o, d, tmin, tmax, anyHit, c, anyHit ? 0 : sc.primaryStackLimit) : trace_brute(sc, o, d, tmin, tmax, anyHit, c);
 }
 
@@ -749,7 +811,8 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     if (!prepare(s, sc)) return -1;
     sc.useWide = s->wide != nullptr && s->nodes != nullptr && s->numWide > 0 && prm.pipeline != 1;
     sc.primaryStackLimit = (s->nodes != nullptr && prm.pipeline != 1) ? 16 : 0;
-    sc.primaryPackets = s->nodes != nullptr && prm.pipeline != 1 && s->primaryPackets != 0;
+    sc.primaryPackets = s->nodes != nullptr && prm.pipeline != 1 && s->primaryPackets == 1;
+    sc.primaryWide = sc.useWide && s->primaryPackets == 2;
     const uint32_t rows = shard_rows(prm.height, prm.bandRows, prm.shardCount);
     const uint32_t W = prm.width;
     BandMap bm{prm.bandRows, prm.shardIndex, prm.shardCount, prm.height};

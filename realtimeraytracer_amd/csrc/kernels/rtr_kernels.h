@@ -72,6 +72,7 @@ struct Tunables {
     uint32_t primary_packet = 0;                  /* camera rays: 0 = one ray per lane (k_primary + k_primary_tail); 1 = a tile's 64 rays walk the BVH2 as one packet (k_primary_packet:
                                                    * scalar node fetches, one stack per tile, no tail kernel — and no faster: 0.168 / 0.334 ms per frame in a launch / alone against
                                                    * 0.167 / 0.320, profiles/r04/ab_primary_packet.log: a wave walks its nodes strictly one after the other, one fetch in flight) */
+    uint32_t primary_wide = 0;                    /* 1: camera rays one per lane over the 4-wide view (k_primary4: half the dependent visits, twice the instructions per visit) */
     uint32_t primary_persist = 0;                 /* camera rays by k_primary_persist: 0 never, 1 whenever it can, 2 by the size of the launch */
     uint32_t primary_persist_min_rays = 6u << 20;
     uint32_t primary_batch = 64, primary_refill = 24, primary_inner_min = 20, primary_wgs_per_cu = 8;

@@ -769,8 +769,15 @@ __device__ __forceinline__ rtr_f4 load_f4(const __amdgpu_buffer_rsrc_t buf, int3
 
 struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
 
+/* RTR_TRACE_PREFETCH (experiment, 0 = off): the entry a visit leaves on TOP of the stack is what the lane's next pop takes; asking for its
+ * line when it is pushed puts that miss under the visits in between.  gfx950 has no vector prefetch instruction: the request is a
+ * one-dword buffer load whose destination is LDS (`buffer_load_dword ... lds`, a 256-B dump area nobody reads), which needs no
+ * register and no wait.  1: the node pushed last, if it is a four-wide record outside the LDS copy; 2: also a leaf's first triangle. */
+#ifndef RTR_TRACE_PREFETCH
+#define RTR_TRACE_PREFETCH 0
+#endif
 template <int STACK, int OCT, bool STATS>
-__device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
+__device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const __amdgpu_buffer_rsrc_t triBuf, uint32_t* dump, const uint4* ldsTop, const uint32_t topCount,
                                              int32_t* lds, int32_t& cur, int32_t*& sp, uint32_t& res,
                                              const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
                                              WaveStats& ws, LocalStats& st) {
@@ -831,6 +838,16 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
                 if (p1) { sp[kTraceBlock] = c1; sp += kTraceBlock; }
                 if (p2) { sp[kTraceBlock] = c2; sp += kTraceBlock; }
                 if (p3) { sp[kTraceBlock] = c3; sp += kTraceBlock; }
+#if RTR_TRACE_PREFETCH
+                {
+                    const int32_t last = p3 ? c3 : (p2 ? c2 : (p1 ? c1 : c0));
+                    const bool pushed = p0 | p1 | p2 | p3;
+                    if (pushed && last >= (int32_t)topCount) __builtin_amdgcn_raw_ptr_buffer_load_lds(nodeBuf, (__attribute__((address_space(3))) void*)dump, 4, last << 6, 0, 0, 0);
+#if RTR_TRACE_PREFETCH > 1
+                    if (pushed && last < 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(triBuf, (__attribute__((address_space(3))) void*)dump, 4, (int32_t)(((uint32_t)~last >> 3) * 48u), 0, 0, 0);
+#endif
+                }
+#endif
                 if (!any) { next = top; sp -= kTraceBlock; }    /* nothing hit: pop (slot 0 holds kDone) */
             } else {
                 bool over = false;
@@ -862,6 +879,12 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                                                               unsigned long long* __restrict__ clk) {
     __shared__ int32_t s_stack[(STACK + 1) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
+#if RTR_TRACE_PREFETCH
+    __shared__ uint32_t s_dump_area[64];                      /* where the prefetches' dwords land (every wave's: nobody reads them) */
+    uint32_t* const s_dump = s_dump_area;
+#else
+    uint32_t* const s_dump = nullptr;
+#endif
 #if RTR_REFILL_LDS
     /* What only the refill block needs — the queue's three arrays, the visibility array, the grid — waits in LDS, not in scalar registers:
      * the kernel holds more wave-uniform values than a wave has SGPRs for, and the ones the compiler parked in VGPR lanes came back
@@ -1027,15 +1050,15 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                 const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
                 const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
                 switch ((mixed || (octForms & 1u) == 0u) ? 8u : woct) {
-                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
                 }
             }
         }
@@ -1093,6 +1116,91 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
             atomicAdd(&stats->clockCycles, c1 - c0); atomicAdd(&stats->clockRef, r1 - r0);
         }
     }
+    if (STATS) st.flush(stats);
+}
+
+/* ---- wavefront stage 1 over the 4-wide view: one camera ray per lane, closest hit (tunable primary_wide) ---------------------------
+ * The camera-ray kernel is bound by its deepest rays' chains of DEPENDENT fetches (k_primary: 31.8 BVH2 visits per ray on the bench
+ * frame); the 4-wide view the shadow rays walk makes about half as many (round 2 measured 18.3), each twice the vector instructions —
+ * which profiles/microbench/visit_mix.hip shows are cheaper than the counters made them look.  Walk rule = k_shadow_trace4's, with a
+ * closest hit: slab tests against the ray's best t so far, the nearest hit child entered (strict <: ties to the lower slot), the others
+ * stacked in slot order, ALL triangles of a leaf tested (min over (t, customIndex, primitiveID), as trace()), RTR_WIDE_STACK = 16 LDS
+ * entries, beyond which the ray goes to the redo list and k_primary_tail walks it over the BVH2 from scratch (both parts counted). */
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, Counters* stats,
+                                                     uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
+    __shared__ int32_t s_stack[RTR_WIDE_STACK * kBlock];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t plane = blockIdx.x / planeBlocks;
+    const RenderArgs& ra = fb.ra[plane / fb.ra[0].spp];
+    const uint32_t i = plane % fb.ra[0].spp;
+    const uint32_t q = (blockIdx.x - plane * planeBlocks) * kBlock + threadIdx.x;
+    uint32_t px, lrow, py;
+    if (!pixel_of(ra, q, px, lrow, py)) return;
+    LocalStats st;
+    const rtr_v3 o = rtr_ld3(ra.cam.position);
+    const rtr_v3 d = primary_dir(ra, px, py, i);
+    const float tmin = 0.001f, tmax = 10000.0f;
+    if (STATS) { st.rays++; st.primary++; }
+    const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
+    rtr_v3 ga, gb;
+    rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);
+    const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes4, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, 0, 0xffffffff, 0x00020000);
+    HitRec best; best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+    int32_t* const lds = s_stack + threadIdx.x;
+    int sp = 0;                                          /* entries held: lds[0 .. sp-1] at stride kBlock */
+    int32_t cur = 0;
+    bool over = false;
+    for (;;) {
+        if (cur >= 0) {
+            if (STATS) st.nodes++;
+            const int32_t nodeOff = cur << 6;
+            const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, 0);
+            const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, 0), q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, 0);
+            const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
+            const float lim = rtr_hwmin(best.t, best.t);
+            float t0, t1, t2, t3;
+            const bool h0 = slab_wide<8>(q0.x, q0.y, q0.z, ga, gb, tmin, lim, t0);
+            const bool h1 = slab_wide<8>(q0.w, q1.x, q1.y, ga, gb, tmin, lim, t1);
+            const bool h2 = slab_wide<8>(q1.z, q1.w, q2.x, ga, gb, tmin, lim, t2) & (c2 != kDone);
+            const bool h3 = slab_wide<8>(q2.y, q2.z, q2.w, ga, gb, tmin, lim, t3) & (c3 != kDone);
+            float tn = h0 ? t0 : 3.0e38f;
+            const bool e1 = h1 & (t1 < tn); tn = e1 ? t1 : tn;
+            const bool e2 = h2 & (t2 < tn); tn = e2 ? t2 : tn;
+            const bool e3 = h3 & (t3 < tn);
+            int32_t next = e3 ? c3 : (e2 ? c2 : (e1 ? c1 : c0));
+            const bool any = h0 | h1 | h2 | h3;
+            const bool p0 = h0 & (e1 | e2 | e3), p1 = h1 & !(e1 & !e2 & !e3), p2 = h2 & !(e2 & !e3), p3 = h3 & !e3;
+            if (p0) { if (sp < RTR_WIDE_STACK) lds[sp++ * kBlock] = c0; else over = true; }
+            if (p1) { if (sp < RTR_WIDE_STACK) lds[sp++ * kBlock] = c1; else over = true; }
+            if (p2) { if (sp < RTR_WIDE_STACK) lds[sp++ * kBlock] = c2; else over = true; }
+            if (p3) { if (sp < RTR_WIDE_STACK) lds[sp++ * kBlock] = c3; else over = true; }
+            if (over) break;
+            if (any) { cur = next; continue; }
+        } else {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const int32_t off = (int32_t)((first + k) * 48u);
+                const rtr_f4 a0 = load_f4(triBuf, off), a1 = load_f4(triBuf, off + 16), a2 = load_f4(triBuf, off + 32);
+                if (STATS) st.tris++;
+                float t, u, v;
+                if (rtr_mt_intersect(o, d, rtr_mk(a0.x, a0.y, a0.z), rtr_mk(a1.x, a1.y, a1.z), rtr_mk(a2.x, a2.y, a2.z), tmin, &t, &u, &v) && t < tmax) {
+                    const uint32_t cu = __float_as_uint(a0.w), pr = __float_as_uint(a1.w);
+                    if ((__float_as_uint(a2.w) & 1u) && !alpha_pass<STATS>(sc, cu, pr, u, v, st)) continue;
+                    if (t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)))) {
+                        best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = lds[--sp * kBlock];
+    }
+    const size_t k = (size_t)plane * planeBlocks * kBlock + q;
+    if (over) redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k;
+    else { hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[k] = best.custom; }
     if (STATS) st.flush(stats);
 }
 
@@ -1374,7 +1482,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_planes(uint4* __restrict__ vis,
 namespace {
 struct TunableField { const char* name; uint32_t Tunables::* field; uint32_t lo, hi; };
 const TunableField kTunables[] = {
-    {"primary_packet", &Tunables::primary_packet, 0u, 1u}, {"primary_persist", &Tunables::primary_persist, 0u, 2u}, {"primary_persist_min_rays", &Tunables::primary_persist_min_rays, 0u, 0xffffffffu},
+    {"primary_packet", &Tunables::primary_packet, 0u, 1u}, {"primary_wide", &Tunables::primary_wide, 0u, 1u}, {"primary_persist", &Tunables::primary_persist, 0u, 2u}, {"primary_persist_min_rays", &Tunables::primary_persist_min_rays, 0u, 0xffffffffu},
     {"primary_batch", &Tunables::primary_batch, 64u, 1u << 16}, {"primary_refill", &Tunables::primary_refill, 1u, 64u},
     {"primary_inner_min", &Tunables::primary_inner_min, 0u, 63u}, {"primary_wgs_per_cu", &Tunables::primary_wgs_per_cu, 1u, 8u},
     {"trace_bvh4", &Tunables::trace_bvh4, 0u, 1u}, {"trace_batch", &Tunables::trace_batch, 0u, 1u << 20}, {"trace_binned", &Tunables::trace_binned, 0u, 2u},
@@ -1472,6 +1580,10 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         if (pblocks == 0) pblocks = 1;
         if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
         else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+    } else if (tun.primary_wide && sc.nodes4) {
+        /* one camera ray per lane over the 4-wide view (not the default); rays that outgrow its 16 entries go to k_primary_tail like k_primary's */
+        if (stats) hipLaunchKernelGGL((k_primary4<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+        else hipLaunchKernelGGL((k_primary4<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
     } else if (tun.primary_packet) {
         /* a tile's camera rays walk the tree as one packet (no ray is ever left to the tail kernel: it is not launched); not the default */
         packet = true;

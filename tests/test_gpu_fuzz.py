@@ -59,6 +59,12 @@ def _soup(seed, directory):
     return obj, directory + "/", cam, lights
 
 
+def _oracle_render(oracle, *a, **kw):
+    """the oracle walks the camera rays the way the GPU is told to (RTR_PRIMARY_PACKET=1 in a soak: 8x8 packets) — work counters only"""
+    kw.setdefault("primary_packets", os.environ.get("RTR_PRIMARY_PACKET") == "1")
+    return oracle.render(*a, **kw)
+
+
 def _seeds():
     """RTR_FUZZ_SEEDS="100-180" (or "3,9,27") runs a soak over other seeds; the default eight are the committed regression set."""
     spec = os.environ.get("RTR_FUZZ_SEEDS", "")
@@ -85,7 +91,7 @@ def test_random_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             p = api.make_params(W, H, spp=2, collect_stats=1, pipeline=pipeline)
             frame = api.Frame(gpu_ctx, W, H)
             api.render(scene, s.camera, s.scene_info(seed), p, frame)
-            ref = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, threads=8)
+            ref = _oracle_render(oracle, s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, threads=8)
             got = frame.download()
             assert np.array_equal(got, ref.images[A.IMAGE_SHADOWED]), (seed, flags, pipeline, int((got != ref.images[A.IMAGE_SHADOWED]).sum()))
             g = frame.stats()
@@ -97,7 +103,7 @@ def test_random_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             api.render(scene, s.camera, s.scene_info(seed), p0, frame)
             assert np.array_equal(frame.download(), got), (seed, flags, pipeline, "counting vs production kernels")
             if ref_brute is None:
-                ref_brute = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=None, threads=8).images[A.IMAGE_SHADOWED]
+                ref_brute = _oracle_render(oracle, s.desc, s.camera, s.scene_info(seed), p, bvh=None, threads=8).images[A.IMAGE_SHADOWED]
             assert np.array_equal(ref.images[A.IMAGE_SHADOWED], ref_brute), (seed, flags, "oracle BVH vs brute force")
             frame.close()
         scene.close()
@@ -182,7 +188,7 @@ def test_random_textured_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             p = api.make_params(W, H, spp=2, collect_stats=1, pipeline=pipeline)
             frame = api.Frame(gpu_ctx, W, H)
             api.render(scene, s.camera, s.scene_info(seed), p, frame)
-            ref = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, threads=8)
+            ref = _oracle_render(oracle, s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, threads=8)
             got = frame.download()
             assert np.array_equal(got, ref.images[A.IMAGE_SHADOWED]), (seed, flags, pipeline, int((got != ref.images[A.IMAGE_SHADOWED]).sum()))
             g = frame.stats()
@@ -190,7 +196,7 @@ def test_random_textured_soup_parity(gpu_ctx, oracle, tmp_path, seed):
             api.render(scene, s.camera, s.scene_info(seed), api.make_params(W, H, spp=2, pipeline=pipeline), frame)
             assert np.array_equal(frame.download(), got), (seed, flags, pipeline, "counting vs production kernels")
             if brute is None:
-                brute = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=None, threads=8).images[A.IMAGE_SHADOWED]
+                brute = _oracle_render(oracle, s.desc, s.camera, s.scene_info(seed), p, bvh=None, threads=8).images[A.IMAGE_SHADOWED]
             assert np.array_equal(ref.images[A.IMAGE_SHADOWED], brute), (seed, flags, "oracle BVH vs brute force")
             frame.close()
         scene.close()
@@ -202,7 +208,7 @@ def test_random_textured_soup_parity(gpu_ctx, oracle, tmp_path, seed):
     frame = api.Frame(gpu_ctx, W, H, all8 | A.IMG_BIT(A.IMAGE_HDR))
     p = api.make_params(W, H, spp=2, images=images, pipeline=1 + (seed & 1))
     api.render(scene, s.camera, s.scene_info(seed), p, frame)
-    ref = oracle.render(s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, images=images, threads=8)
+    ref = _oracle_render(oracle, s.desc, s.camera, s.scene_info(seed), p, bvh=bvh, images=images, threads=8)
     src = {}
     for which in (0, 1, 2, 6, 7):
         src[which] = frame.download(which)

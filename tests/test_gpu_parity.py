@@ -566,25 +566,31 @@ def test_deep_stack_rays_take_the_tail_kernel(gpu_ctx, oracle):
     cam2 = host.Camera(0.004, (-30.0, -0.995, 0.0), (0.8 * end, -1.0, 0.0), (0.0, 1.0, 0.0), W, H).getGPUData()    # inside the boxes' padding all the way
     info2 = host.scene_info(1, 1, (-30.0, -0.995, 0.0))
     out = {}
-    for packets in (1, 0):              # as 8x8 packets (one stack per tile, as deep as the tree: > 16 entries here), and one ray per lane (16 LDS entries + redo tail)
-        gpu_ctx.set_tunable("primary_packet", packets)
+    # as 8x8 packets (one stack per tile, as deep as the tree: > 16 entries here), one ray per lane over the BVH2 (16 LDS entries + redo
+    # tail) and one ray per lane over the 4-wide view (k_primary4: 16 entries, its abandoned rays walked again over the BVH2)
+    for walk in ("packet", "solo", "wide"):
+        gpu_ctx.set_tunable("primary_packet", int(walk == "packet"))
+        gpu_ctx.set_tunable("primary_wide", int(walk == "wide"))
         try:
             for collect in (0, 1):
                 p = api.make_params(W, H, spp=2, collect_stats=collect, pipeline=2)
                 f2 = api.Frame(gpu_ctx, W, H)
                 api.render(scene2, cam2, info2, p, f2)
-                out[packets, collect] = f2.download()
+                out[walk, collect] = f2.download()
                 if collect:
-                    ref2 = oracle.render(d2, cam2, info2, p, bvh=bvh2, threads=16, primary_packets=bool(packets))
-                    _assert_same(out[packets, 1], ref2.images[A.IMAGE_SHADOWED], "skimming primary rays, counting kernels")
+                    ref2 = oracle.render(d2, cam2, info2, p, bvh=bvh2, threads=16, primary_packets=walk == "packet", primary_wide=walk == "wide")
+                    _assert_same(out[walk, 1], ref2.images[A.IMAGE_SHADOWED], "skimming primary rays, counting kernels")
                     g2 = f2.stats()
-                    assert (g2.numNodeVisits, g2.numTriTests, g2.numHits, g2.primaryTailRays) == (ref2.stats.numNodeVisits, ref2.stats.numTriTests, ref2.stats.numHits, ref2.stats.primaryTailRays), packets
-                    assert (g2.numNodeVisits - g2.numShadowNodeVisits) / g2.numPrimaryRays > 1000, "primary rays must walk a long stretch of the row"
-                    assert (g2.primaryTailRays > 0) == (packets == 0)
+                    assert (g2.numNodeVisits, g2.numTriTests, g2.numHits, g2.primaryTailRays) == (ref2.stats.numNodeVisits, ref2.stats.numTriTests, ref2.stats.numHits, ref2.stats.primaryTailRays), walk
+                    assert (g2.numNodeVisits - g2.numShadowNodeVisits) / g2.numPrimaryRays > (1000 if walk != "wide" else 300), "primary rays must walk a long stretch of the row"
+                    if walk != "wide":
+                        assert (g2.primaryTailRays > 0) == (walk == "solo")
         finally:
             gpu_ctx.set_tunable("primary_packet", 0)
-        _assert_same(out[packets, 0], out[packets, 1], "timed camera-ray kernel vs its counting form")
-    _assert_same(out[0, 0], out[1, 0], "camera rays one per lane (16 LDS entries + redo tail) vs as packets")
+            gpu_ctx.set_tunable("primary_wide", 0)
+        _assert_same(out[walk, 0], out[walk, 1], "timed camera-ray kernel vs its counting form")
+    _assert_same(out["solo", 0], out["packet", 0], "camera rays one per lane (16 LDS entries + redo tail) vs as packets")
+    _assert_same(out["solo", 0], out["wide", 0], "camera rays over the BVH2 vs over the 4-wide view")
 
 
 def test_context_may_be_destroyed_before_its_children(gpu_ctx, scene_cache):

@@ -314,3 +314,20 @@ def test_oracle_packet_walk_of_the_camera_rays_finds_the_same_hits(oracle, scene
             if shard == (0, 1) and name == "cornell_box":
                 c = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=None, threads=8)
                 assert np.array_equal(a.images[1], c.images[1])
+
+
+def test_oracle_wide_closest_walk_of_the_camera_rays_finds_the_same_hits(oracle, scene_cache):
+    """trace_wide_closest (the restatement of k_primary4: camera rays one per lane over the 4-wide view, closest hit) changes the WORK
+    of the camera rays, never what they hit; and it makes fewer visits than the BVH2 walk (what the kernel is for)."""
+    for name, W, H, spp in (("cornell_box", 100, 60, 2), ("bunny_class", 117, 70, 1)):
+        s = getattr(scenes, name)(W, H)
+        bvh = api.host_build_bvh_wide(s.desc)
+        for shard in ((0, 1), (1, 3)):
+            p = _params(W, H, spp=spp)
+            p.collectStats, p.pipeline, p.shardIndex, p.shardCount = 1, 2, shard[0], shard[1]
+            a = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=bvh, threads=8, primary_wide=True)
+            b = oracle.render(s.desc, s.camera, s.scene_info(3), p, bvh=bvh, threads=8)
+            assert np.array_equal(a.images[1], b.images[1]), (name, shard)
+            for f in ("numRays", "numPrimaryRays", "numHits", "numShadowNodeVisits", "numShadowTriTests"):
+                assert getattr(a.stats, f) == getattr(b.stats, f), f
+            assert a.stats.numNodeVisits < b.stats.numNodeVisits
