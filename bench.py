@@ -921,6 +921,10 @@ def main():
                 # the part of it that can still move: issue slots whose lanes did work (frac x the hardware's lane utilisation over all vector instructions)
                 "frac_useful": round(frac * lane_all, 4) if (frac and lane_all) else None,
                 "issue_cycles_per_inst_measured": mix,
+                # the same instruction count priced at the visit mix's MEASURED issue cost instead of the counter's flat 4 cycles (the node
+                # loop's mix; the triangle test holds more plain fma / mul, which issue at 2: an estimate, a little high)
+                "frac_at_measured_issue_cost": round(per_launch("SQ_INSTS_VALU") * mix["cycles_per_valu_inst_per_simd_8_waves"] / num_simds / launch_cycles, 4)
+                if (pmc and mix and launch_cycles and mix.get("cycles_per_valu_inst_per_simd_8_waves")) else None,
                 "avg_launch_ms": round(trace_ms, 4), "launches": n_launches,
                 "frames_per_launch": round(launch_frames, 2), "avg_ms_per_frame": round(trace_ms / launch_frames, 4),
                 "avg_launch_ms_source": ("HIP events on the launch stream over the TIMED REGION: one launch of every kernel at a time, "
