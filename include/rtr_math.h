@@ -219,13 +219,24 @@ RTR_HD float rtr_acos(float x) {
     return 2.0f * rtr_atan2(rtr_sqrt(1.0f - x), rtr_sqrt(1.0f + x));
 }
 
-/* b / 255.0f for b = 0..255 without the division sequence: q0 = b * fl(1/255) and one Newton step on the remainder.
- * Equal to the correctly rounded IEEE quotient for all 256 inputs (tests/test_math.py checks it exhaustively), so the
- * denoise kernels unpack UNORM8 with 3 vector instructions per channel while the oracle divides. */
+/* b / 255.0f for b = 0..255 without the division sequence: fl(1/255) split into a head and a tail, b * tail folded into ONE fma with
+ * the head — a single rounding of b/255 to within 2^-50.  Equal to the correctly rounded IEEE quotient for all 256 inputs
+ * (tests/test_math.py checks it exhaustively), so the denoise kernels unpack UNORM8 with a conversion + two plain fp32 operations
+ * per channel (2-cycle instructions on gfx950) while the oracle divides. */
 RTR_HD float rtr_unorm8_to_float(uint32_t b) {
-    const float x = (float)b, r = 0.0039215688593685627f;      /* fl(1/255) */
-    const float q0 = x * r;
-    return rtr_fma(rtr_fma(-255.0f, q0, x), r, q0);
+    const float x = (float)b;
+    return rtr_fma(x, 0.0039215688593685627f, x * -2.3191758e-10f);      /* fl(1/255), fl(1/255 - fl(1/255)) */
+}
+/* a / b for a divisor known ahead, r = fl(1 / b): the quotient estimate a * r corrected twice by its exact remainder.  The first
+ * correction makes it faithful, and a faithful quotient corrected once more by its remainder times the correctly rounded reciprocal
+ * is the correctly rounded quotient (Markstein) — for finite a, b with no overflow / underflow in a * r and the remainders, which is
+ * where the denoise pass uses it (|a| <= 4, b = 0.001, 1, 4, 9, 16 ...).  Five plain fp32 operations instead of the IEEE division
+ * sequence (v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup); a zero keeps its value, not always its sign.
+ * tests/test_math.py holds it against the division over every float of the reachable range for the divisors in use. */
+RTR_HD float rtr_div_by(float a, float b, float r) {
+    const float q0 = a * r;
+    const float q1 = rtr_fma(rtr_fma(-b, q0, a), r, q0);
+    return rtr_fma(rtr_fma(-b, q1, a), r, q1);
 }
 
 /* ---- ray / box / triangle ---------------------------------------------------------------- */

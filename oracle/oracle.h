@@ -80,6 +80,7 @@ float    oracle_log2(float x);
 float    oracle_exp2(float x);
 uint32_t oracle_pack_bgra8(float r, float g, float b);
 float    oracle_unorm8_to_float_fast(uint32_t b);   /* rtr_unorm8_to_float: the product's division-free form */
+uint64_t oracle_div_by_mismatches(float b, uint32_t loBits, uint32_t hiBits);   /* rtr_div_by vs a / b over a range of a's bit patterns, both signs */
 int      oracle_mt(const float* o, const float* d, const float* v0, const float* e1, const float* e2,
                    float tmin, float* tuv);
 

@@ -60,6 +60,8 @@ def lib():
         L.oracle_pack_bgra8.argtypes = [A.f32, A.f32, A.f32]
         L.oracle_unorm8_to_float_fast.restype = A.f32
         L.oracle_unorm8_to_float_fast.argtypes = [A.u32]
+        L.oracle_div_by_mismatches.restype = C.c_uint64
+        L.oracle_div_by_mismatches.argtypes = [A.f32, A.u32, A.u32]
         L.oracle_mt.restype = C.c_int
         L.oracle_mt.argtypes = [C.POINTER(A.f32)] * 5 + [A.f32, C.POINTER(A.f32)]
         _lib = L

@@ -947,6 +947,18 @@ float oracle_log2(float x) { return rtr_log2(x); }
 float oracle_exp2(float x) { return rtr_exp2(x); }
 uint32_t oracle_pack_bgra8(float r, float g, float b) { return rtr_pack_bgra8(r, g, b); }
 float oracle_unorm8_to_float_fast(uint32_t b) { return rtr_unorm8_to_float(b); }
+/* rtr_div_by (the product's division by a known divisor) against the IEEE quotient for every float a whose bits lie in
+ * [loBits, hiBits], both signs: the number of a for which the two differ as numbers */
+uint64_t oracle_div_by_mismatches(float b, uint32_t loBits, uint32_t hiBits) {
+    const float r = 1.0f / b;
+    uint64_t bad = 0;
+    for (uint64_t u = loBits; u <= hiBits; ++u)
+        for (uint32_t sign = 0; sign < 2; ++sign) {
+            const float a = rtr_u2f((uint32_t)u | (sign << 31));
+            if (!(rtr_div_by(a, b, r) == a / b)) ++bad;
+        }
+    return bad;
+}
 int oracle_mt(const float* o, const float* d, const float* v0, const float* e1, const float* e2, float tmin, float* tuv) {
     return rtr_mt_intersect(rtr_ld3(o), rtr_ld3(d), rtr_ld3(v0), rtr_ld3(e1), rtr_ld3(e2), tmin, &tuv[0], &tuv[1], &tuv[2]);
 }

@@ -70,12 +70,26 @@ def test_unorm8_pack(oracle):
 
 
 def test_unorm8_unpack_without_division_is_exact(oracle):
-    """The denoise kernels unpack UNORM8 as b*fl(1/255) + one Newton step (rtr_unorm8_to_float); the oracle divides.
-    Both must agree for every byte."""
+    """The denoise kernels unpack UNORM8 as fma(b, head, b * tail) with fl(1/255) split in two (rtr_unorm8_to_float); the oracle
+    divides.  Both must agree for every byte."""
     import numpy as np
     L = oracle.lib()
     for b in range(256):
         assert np.float32(L.oracle_unorm8_to_float_fast(b)) == np.float32(b) / np.float32(255.0), b
+
+
+def test_division_by_a_known_divisor_is_the_ieee_quotient(oracle):
+    """rtr_div_by (a * fl(1/b) corrected twice by its exact remainder: what the denoise kernel issues instead of the division
+    sequence) against a / b for EVERY float a of either sign with 2^-40 <= |a| <= 16 — the squared distances of UNORM8 vectors and
+    their quotients lie inside — for the divisors the pass uses (the phis, step^2 = 1, 4, 9, 16) and a few others; and at zero."""
+    import numpy as np
+    L = oracle.lib()
+
+    def bits(x):
+        return int(np.float32(x).view(np.uint32))
+    for b in (0.001, 1.0, 4.0, 9.0, 16.0, 25.0, 0.37):
+        assert L.oracle_div_by_mismatches(b, bits(2.0 ** -40), bits(16.0)) == 0, b
+        assert L.oracle_div_by_mismatches(b, 0, 0) == 0, b
 
 
 def test_moeller_trumbore_edge_cases(oracle):
