@@ -558,6 +558,9 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
 #ifndef RTR_REFILL_LDS
 #define RTR_REFILL_LDS 1
 #endif
+#ifndef RTR_LIST_SHARE
+#define RTR_LIST_SHARE 1
+#endif
 constexpr int kTailBlocks = 64;            /* grid of the two "redo" kernels; their global stacks are strided by 64 * kBlock lanes */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
 /* queue entries a wave reserves per atomic: 256 for a queue of one frame's length, 512 for the queue of a launch of several frames
@@ -905,6 +908,10 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
     int32_t* lds = s_stack + threadIdx.x;
     lds[0] = kDone;
     for (uint32_t i = threadIdx.x; i < topCount * 4u; i += kTraceBlock) s_top[i] = sc.nodes4[i];
+#if RTR_LIST_SHARE
+    __shared__ unsigned long long s_drained;                  /* bit r: batch list r was seen drained by a wave of this workgroup (cursors only grow) */
+    if (threadIdx.x == 0) s_drained = 0ull;
+#endif
     __syncthreads();
     /* clock of this launch: shader-clock ticks over 100-MHz ticks, lane 0 of the first workgroup of each XCD (bench.py: roofline.clock_mhz) */
     const bool stamp = clk != nullptr && blockIdx.x < kQueueRegions && threadIdx.x == 0;
@@ -974,7 +981,14 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                         if (LISTS) {
                             const uint32_t r = (myRegion + regionTry / kQueueRegions) % kQueueRegions * kQueueRegions + (myXcd + regionTry) % kQueueRegions;
                             const uint32_t len = lens[r];
-                            if (len != 0u) {
+#if RTR_LIST_SHARE
+                            /* a list one wave of this workgroup found drained is not asked again by its other three: at the end of a launch every
+                             * wave walks all the lists, one atomic round trip each on cursors the whole chip is hammering */
+                            const bool known = (*(volatile unsigned long long*)&s_drained >> r) & 1ull;
+#else
+                            const bool known = false;
+#endif
+                            if (len != 0u && !known) {
                                 uint32_t got = 0;
                                 if ((threadIdx.x & 63u) == 0) got = atomicAdd(nextBatch + 16u * r, 1u);
                                 got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
@@ -983,6 +997,9 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                                     batchPos = dsc.x; batchEnd = dsc.x + dsc.y;
                                     break;
                                 }
+#if RTR_LIST_SHARE
+                                if ((threadIdx.x & 63u) == 0) atomicOr(&s_drained, 1ull << r);
+#endif
                             }
                         } else {
                             const uint32_t r = (myRegion + regionTry) % kQueueRegions;
