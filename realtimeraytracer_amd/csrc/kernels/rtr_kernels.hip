@@ -755,15 +755,6 @@ __device__ __forceinline__ bool tri_any(const DeviceScene& sc, const __amdgpu_bu
     return true;
 }
 
-/* tri_any with the record already loaded (RTR_TRI_LOAD2: a leaf's first two records are fetched together, tested one after the other) */
-template <bool STATS>
-__device__ __forceinline__ bool tri_test(const DeviceScene& sc, const rtr_f4 q0, const rtr_f4 q1, const rtr_f4 q2, const rtr_v3 o, const rtr_v3 d,
-                                         const float tmin, const float tmax, LocalStats& st) {
-    float t, u, v;
-    if (!(rtr_mt_intersect(o, d, rtr_mk(q0.x, q0.y, q0.z), rtr_mk(q1.x, q1.y, q1.z), rtr_mk(q2.x, q2.y, q2.z), tmin, &t, &u, &v) && t < tmax)) return false;
-    if (__float_as_uint(q2.w) & 1u) return alpha_pass<STATS>(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st);
-    return true;
-}
 __device__ __forceinline__ rtr_f4 load_f4(const __amdgpu_buffer_rsrc_t buf, int32_t off) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(buf, off, 0, 0);
@@ -772,15 +763,8 @@ __device__ __forceinline__ rtr_f4 load_f4(const __amdgpu_buffer_rsrc_t buf, int3
 
 struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
 
-/* RTR_TRACE_PREFETCH (experiment, 0 = off): the entry a visit leaves on TOP of the stack is what the lane's next pop takes; asking for its
- * line when it is pushed puts that miss under the visits in between.  gfx950 has no vector prefetch instruction: the request is a
- * one-dword buffer load whose destination is LDS (`buffer_load_dword ... lds`, a 256-B dump area nobody reads), which needs no
- * register and no wait.  1: the node pushed last, if it is a four-wide record outside the LDS copy; 2: also a leaf's first triangle. */
-#ifndef RTR_TRACE_PREFETCH
-#define RTR_TRACE_PREFETCH 0
-#endif
 template <int STACK, int OCT, bool STATS>
-__device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const __amdgpu_buffer_rsrc_t triBuf, uint32_t* dump, const uint4* ldsTop, const uint32_t topCount,
+__device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
                                              int32_t* lds, int32_t& cur, int32_t*& sp, uint32_t& res,
                                              const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
                                              WaveStats& ws, LocalStats& st) {
@@ -841,16 +825,6 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
                 if (p1) { sp[kTraceBlock] = c1; sp += kTraceBlock; }
                 if (p2) { sp[kTraceBlock] = c2; sp += kTraceBlock; }
                 if (p3) { sp[kTraceBlock] = c3; sp += kTraceBlock; }
-#if RTR_TRACE_PREFETCH
-                {
-                    const int32_t last = p3 ? c3 : (p2 ? c2 : (p1 ? c1 : c0));
-                    const bool pushed = p0 | p1 | p2 | p3;
-                    if (pushed && last >= (int32_t)topCount) __builtin_amdgcn_raw_ptr_buffer_load_lds(nodeBuf, (__attribute__((address_space(3))) void*)dump, 4, last << 6, 0, 0, 0);
-#if RTR_TRACE_PREFETCH > 1
-                    if (pushed && last < 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(triBuf, (__attribute__((address_space(3))) void*)dump, 4, (int32_t)(((uint32_t)~last >> 3) * 48u), 0, 0, 0);
-#endif
-                }
-#endif
                 if (!any) { next = top; sp -= kTraceBlock; }    /* nothing hit: pop (slot 0 holds kDone) */
             } else {
                 bool over = false;
@@ -882,12 +856,6 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                                                               unsigned long long* __restrict__ clk) {
     __shared__ int32_t s_stack[(STACK + 1) * kTraceBlock];    /* slot 0, below the stack, holds kDone for good */
     __shared__ uint4 s_top[kTopNodes * 4];                    /* the first topCount (<= kTopNodes) four-wide entries */
-#if RTR_TRACE_PREFETCH
-    __shared__ uint32_t s_dump_area[64];                      /* where the prefetches' dwords land (every wave's: nobody reads them) */
-    uint32_t* const s_dump = s_dump_area;
-#else
-    uint32_t* const s_dump = nullptr;
-#endif
 #if RTR_REFILL_LDS
     /* What only the refill block needs — the queue's three arrays, the visibility array, the grid — waits in LDS, not in scalar registers:
      * the kernel holds more wave-uniform values than a wave has SGPRs for, and the ones the compiler parked in VGPR lanes came back
@@ -1067,15 +1035,15 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                 const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
                 const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
                 switch ((mixed || (octForms & 1u) == 0u) ? 8u : woct) {
-                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, triBuf, s_dump, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
                 }
             }
         }
@@ -1100,21 +1068,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             bool hit = false;
-#ifdef RTR_TRI_LOAD2
-            {   /* nine leaves in ten hold a quad's two triangles: both records are asked for at once (six loads in flight instead of three
-                 * and then three more), tested one after the other so that the second test is still skipped when the first decides */
-                const int32_t off = (int32_t)(first * 48u);
-                const bool two = cnt > 1u;
-                const rtr_f4 a0 = load_f4(triBuf, off), a1 = load_f4(triBuf, off + 16), a2 = load_f4(triBuf, off + 32);
-                rtr_f4 b0 = a0, b1 = a1, b2 = a2;
-                if (two) { b0 = load_f4(triBuf, off + 48); b1 = load_f4(triBuf, off + 64); b2 = load_f4(triBuf, off + 80); }
-                hit = tri_test<false>(sc, a0, a1, a2, o, d, tmin, tmax, st);
-                if (!hit && two) hit = tri_test<false>(sc, b0, b1, b2, o, d, tmin, tmax, st);
-                for (uint32_t i = 2; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
-            }
-#else
             for (uint32_t i = 0; i < cnt && !hit; ++i) hit = tri_any<false>(sc, triBuf, first + i, o, d, tmin, tmax, st);
-#endif
             if (hit) { res = 1u; cur = kDone; }
             else { cur = *sp; sp -= kTraceBlock; }                        /* slot 0 holds kDone: an empty stack ends the ray (visible) */
         }

@@ -60,8 +60,9 @@ def _soup(seed, directory):
 
 
 def _oracle_render(oracle, *a, **kw):
-    """the oracle walks the camera rays the way the GPU is told to (RTR_PRIMARY_PACKET=1 in a soak: 8x8 packets) — work counters only"""
+    """the oracle walks the camera rays the way the GPU is told to (in a soak — RTR_PRIMARY_PACKET=1: 8x8 packets; RTR_PRIMARY_WIDE=1: the 4-wide view) — work counters only"""
     kw.setdefault("primary_packets", os.environ.get("RTR_PRIMARY_PACKET") == "1")
+    kw.setdefault("primary_wide", os.environ.get("RTR_PRIMARY_WIDE") == "1")
     return oracle.render(*a, **kw)
 
 
