@@ -563,6 +563,7 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
 #endif
 constexpr int kTailBlocks = 64;            /* grid of the two "redo" kernels; their global stacks are strided by 64 * kBlock lanes */
 constexpr int32_t kDone = (int32_t)0x80000000;   /* not a valid leaf code (first would be 2^28-1) */
+constexpr int32_t kAbandoned = (int32_t)0x80000001;   /* inner_nodes4 -> its caller: this lane's stack was full (nor is this a leaf code: same first) */
 /* queue entries a wave reserves per atomic: 256 for a queue of one frame's length, 512 for the queue of a launch of several frames
  * (kBatchLongQueue: 0.6-1.5 % faster there — fewer cursor atomics, fewer short batches — while a single frame rendered alone ends in
  * a longer tail with it, 2.65 instead of 2.53 ms; profiles/r03/sweep_batch_r03_4.log, bench_*_r03_5.log) */
@@ -765,10 +766,12 @@ struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLan
 
 template <int STACK, int OCT, bool STATS>
 __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
-                                             int32_t* lds, int32_t& cur, int32_t*& sp, uint32_t& res,
+                                             int32_t* lds, int32_t& curRef, int32_t*& spRef,
                                              const rtr_v3 ga, const rtr_v3 gb, const float tmin, const float tmax, const uint32_t kInnerMin,
                                              WaveStats& ws, LocalStats& st) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    int32_t cur = curRef;
+    int32_t* sp = spRef;
     const float tmaxC = rtr_hwmin(tmax, tmax);           /* the far limit as a min's result: the loop's min3 need not quiet it again on every trip */
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
@@ -833,11 +836,12 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
                 if (p2) { if (sp < full) { sp[kTraceBlock] = c2; sp += kTraceBlock; } else over = true; }
                 if (p3) { if (sp < full) { sp[kTraceBlock] = c3; sp += kTraceBlock; } else over = true; }
                 if (!any) { next = top; sp -= kTraceBlock; }
-                if (over) { res = 2u; next = kDone; }           /* needs more than the LDS stack: the tail kernel redoes this ray */
+                if (over) next = kAbandoned;                    /* needs more than the LDS stack: the caller hands the ray to the tail kernel */
             }
             cur = next;
         }
     }
+    curRef = cur; spRef = sp;
 }
 
 /* The same kernel over the 4-wide view of the tree (DeviceScene::nodes4, built by k_wide_nodes): a visit is one 64-B record
@@ -1035,16 +1039,17 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                 const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)innerNow) - 1);
                 const bool mixed = __ballot(cur >= 0 && oct != woct) != 0ull;
                 switch ((mixed || (octForms & 1u) == 0u) ? 8u : woct) {
-                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
-                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, res, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 0: inner_nodes4<STACK, 0, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 1: inner_nodes4<STACK, 1, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 2: inner_nodes4<STACK, 2, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 3: inner_nodes4<STACK, 3, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 4: inner_nodes4<STACK, 4, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 5: inner_nodes4<STACK, 5, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 6: inner_nodes4<STACK, 6, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    case 7: inner_nodes4<STACK, 7, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
+                    default: inner_nodes4<STACK, 8, STATS>(nodeBuf, s_top, topCount, lds, cur, sp, ga, gb, tmin, tmax, kInnerMin, ws, st); break;
                 }
+                if (cur == kAbandoned) { res = 2u; cur = kDone; }
             }
         }
         /* ---- leaves ---- */
