@@ -187,6 +187,13 @@ __device__ __forceinline__ bool slab_oct<8>(uint32_t wmin, uint32_t wmax, uint32
 /* Slab test of one slot of an RtrWideNode: the same three words, but the planes are HALF FLOATS — offsets from the centre of the scene
  * grid in grid steps, rounded outward when the record was made — so t = fma(plane, ga, gbc) is one v_fma_mix_f32 per plane with no
  * conversion (gbc: gb taken about the scene's wide centre, rtr_ray_grid_centre).  OCT as in slab_oct. */
+/* v_min_f32 as the instruction.  The compiler's fmin first quiets an operand it cannot prove canonical (v_max x, x); for the ray's far
+ * limit — a loaded, loop-carried value — it re-materialised that on EVERY visit.  The limit is a finite number the queue build wrote. */
+__device__ __forceinline__ float vmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int OCT>
 __device__ __forceinline__ bool slab_wide(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gbc, float tmin, float tmax, float& t_entry) {
     typedef _Float16 rtr_h2 __attribute__((ext_vector_type(2)));
@@ -205,7 +212,7 @@ __device__ __forceinline__ bool slab_wide(uint32_t wmin, uint32_t wmax, uint32_t
         nz = rtr_hwmin(z0, z1); fz = rtr_hwmax(z0, z1);
     }
     const float lo = rtr_hwmax(rtr_hwmax(nx, ny), rtr_hwmax(nz, tmin));
-    const float hi = rtr_hwmin(rtr_hwmin(fx, fy), rtr_hwmin(fz, tmax));
+    const float hi = rtr_hwmin(rtr_hwmin(fx, fy), vmin_raw(fz, tmax));
     t_entry = lo;
     return lo <= hi * RTR_BOX_WIDEN;
 }

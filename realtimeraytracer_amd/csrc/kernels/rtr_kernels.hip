@@ -772,7 +772,7 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     int32_t cur = curRef;
     int32_t* sp = spRef;
-    const float tmaxC = rtr_hwmin(tmax, tmax);           /* the far limit as a min's result: the loop's min3 need not quiet it again on every trip */
+    const float tmaxC = tmax;
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
         if (innerMask == 0ull) break;
@@ -783,7 +783,8 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
             /* one 64-B four-wide node = the whole visit; the first topCount entries (the top levels: breadth-first order) are in
              * LDS, which takes those visits — 35-40 % of all — off the L1's tag look-ups, the busiest unit of this kernel */
             u32x4 q0, q1, q2, q3;
-            if ((uint32_t)cur < topCount) {
+            const bool inLds = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64((uint32_t)cur < topCount));      /* the mask once: branch and select from one compare */
+            if (inLds) {
                 const uint4* t = ldsTop + cur * 4;
                 const uint4 a0 = t[0], a1 = t[1], a2 = t[2], a3 = t[3];
                 q0 = u32x4{a0.x, a0.y, a0.z, a0.w}; q1 = u32x4{a1.x, a1.y, a1.z, a1.w};
@@ -810,18 +811,24 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
              * (Taking the first hit slot instead of the nearest saves instructions and costs 2 % more time; ordering the others too —
              * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
              * 2.15 / 2.22 ms against 2.05.)  Which slots are stacked is mask arithmetic on the comparison results, not a
-             * comparison of codes. */
+             * comparison of codes — written on wave masks, so that every comparison is issued once and the rest is scalar (from bools
+             * the compiler derived !(t2 < tn) with a second vector compare). */
+            const unsigned long long H0 = __builtin_amdgcn_ballot_w64(h0), H1 = __builtin_amdgcn_ballot_w64(h1), H2 = __builtin_amdgcn_ballot_w64(h2), H3 = __builtin_amdgcn_ballot_w64(h3);
             float tn = h0 ? t0 : 3.0e38f;
-            const bool e1 = h1 & (t1 < tn); tn = e1 ? t1 : tn;
-            const bool e2 = h2 & (t2 < tn); tn = e2 ? t2 : tn;
-            const bool e3 = h3 & (t3 < tn);
+            const unsigned long long E1 = H1 & __builtin_amdgcn_ballot_w64(t1 < tn);
+            const bool e1 = __builtin_amdgcn_inverse_ballot_w64(E1); tn = e1 ? t1 : tn;
+            const unsigned long long E2 = H2 & __builtin_amdgcn_ballot_w64(t2 < tn);
+            const bool e2 = __builtin_amdgcn_inverse_ballot_w64(E2); tn = e2 ? t2 : tn;
+            const unsigned long long E3 = H3 & __builtin_amdgcn_ballot_w64(t3 < tn);
+            const bool e3 = __builtin_amdgcn_inverse_ballot_w64(E3);
             int32_t next = e3 ? c3 : (e2 ? c2 : (e1 ? c1 : c0));
-            const bool any = h0 | h1 | h2 | h3;
+            const bool any = __builtin_amdgcn_inverse_ballot_w64(H0 | H1 | H2 | H3);
             /* the stack pointer is the LDS address of the top entry, so a push is a store and an add.  A visit pushes at most three
              * entries: while every lane of the wave has three free (one comparison and a branch the whole wave takes or skips) the pushes
              * need no bound; otherwise the visit runs its checked form, in which a lane whose stack is full is abandoned to the tail
              * kernel.  All STACK entries are usable, none is a guard. */
-            const bool p0 = h0 & (e1 | e2 | e3), p1 = h1 & !(e1 & !e2 & !e3), p2 = h2 & !(e2 & !e3), p3 = h3 & !e3;
+            const bool p0 = __builtin_amdgcn_inverse_ballot_w64(H0 & (E1 | E2 | E3)), p1 = __builtin_amdgcn_inverse_ballot_w64(H1 & ~(E1 & ~E2 & ~E3));
+            const bool p2 = __builtin_amdgcn_inverse_ballot_w64(H2 & ~(E2 & ~E3)), p3 = __builtin_amdgcn_inverse_ballot_w64(H3 & ~E3);
             int32_t* const full = lds + STACK * kTraceBlock;
             if (__ballot(sp > full - 3 * kTraceBlock) == 0ull) {
                 if (p0) { sp[kTraceBlock] = c0; sp += kTraceBlock; }
