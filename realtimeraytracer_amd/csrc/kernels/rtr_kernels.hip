@@ -963,7 +963,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
 #if RTR_LIST_SHARE
                             /* a list one wave of this workgroup found drained is not asked again by its other three: at the end of a launch every
                              * wave walks all the lists, one atomic round trip each on cursors the whole chip is hammering */
-                            const bool known = (*(volatile unsigned long long*)&s_drained >> r) & 1ull;
+                            const bool known = (*(volatile __attribute__((address_space(3))) unsigned long long*)&s_drained >> r) & 1ull;      /* address space kept: a ds_read, not a flat load */
 #else
                             const bool known = false;
 #endif
