@@ -71,6 +71,35 @@ KERNEL(k_floor, float, I_FLOOR, "memory")
 #define I_CMPCND(i) "v_cmp_le_f32 vcc, %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
 KERNEL(k_cmp_then_cndmask, float, I_CMPCND, "vcc")          /* 16 instructions per block */
 
+#define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %10\n"
+KERNEL(k_mul_lo_u32, float, I_MULLO, "memory")
+#define I_XOR(i) "v_xor_b32 %" #i ", %" #i ", %10\n"
+KERNEL(k_xor, float, I_XOR, "memory")
+#define I_LSHR(i) "v_lshrrev_b32 %" #i ", 3, %" #i "\n"
+KERNEL(k_lshr, float, I_LSHR, "memory")
+#define I_LSHRV(i) "v_lshrrev_b32 %" #i ", %10, %" #i "\n"
+KERNEL(k_lshr_var, float, I_LSHRV, "memory")
+#define I_AND(i) "v_and_b32 %" #i ", %" #i ", %10\n"
+KERNEL(k_and, float, I_AND, "memory")
+#define I_LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 3, %10\n"
+KERNEL(k_lshl_add, float, I_LSHLADD, "memory")
+#define I_SQRT(i) "v_sqrt_f32 %" #i ", %" #i "\n"
+KERNEL(k_sqrt, float, I_SQRT, "memory")
+#define I_DIVFIX(i) "v_div_fixup_f32 %" #i ", %" #i ", %8, %9\n"
+KERNEL(k_div_fixup, float, I_DIVFIX, "memory")
+#define I_DIVFMAS(i) "v_div_fmas_f32 %" #i ", %" #i ", %8, %9\n"
+KERNEL(k_div_fmas, float, I_DIVFMAS, "vcc")
+#define I_DIVSCALE(i) "v_div_scale_f32 %" #i ", vcc, %" #i ", %8, %9\n"
+KERNEL(k_div_scale, float, I_DIVSCALE, "vcc")
+#define I_CVTU(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+KERNEL(k_cvt_f32_u32, float, I_CVTU, "memory")
+#define I_LSHL64(i) "v_lshlrev_b64 %" #i ", 3, %" #i "\n"
+KERNEL(k_lshl_b64, f2, I_LSHL64, "memory")
+#define I_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %" #i ", 2, %8\n"
+KERNEL(k_lshl_add_u64, f2, I_LSHLADD64, "memory")
+#define I_MOVDPP(i) "v_mov_b32_dpp %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+KERNEL(k_mov_dpp, float, I_MOVDPP, "memory")
+
 template <class K> static void run(const char* name, K k, int perBlock, int cus, float* d, Stamp* ds) {
     int fit = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k, 256, 0);
     if (fit < 8) { fprintf(stderr, "%s: only %d workgroups fit a CU\n", name, fit); exit(1); }
@@ -117,6 +146,20 @@ int main() {
     run("v_floor_f32", k_floor, 8, cus, d, ds);
     run("v_exp_f32", k_exp, 8, cus, d, ds);
     run("v_rcp_f32", k_rcp, 8, cus, d, ds);
+    run("v_mul_lo_u32", k_mul_lo_u32, 8, cus, d, ds);
+    run("v_xor_b32", k_xor, 8, cus, d, ds);
+    run("v_lshrrev_b32 (constant)", k_lshr, 8, cus, d, ds);
+    run("v_lshrrev_b32 (register)", k_lshr_var, 8, cus, d, ds);
+    run("v_and_b32", k_and, 8, cus, d, ds);
+    run("v_lshl_add_u32", k_lshl_add, 8, cus, d, ds);
+    run("v_cvt_f32_u32", k_cvt_f32_u32, 8, cus, d, ds);
+    run("v_sqrt_f32", k_sqrt, 8, cus, d, ds);
+    run("v_div_scale_f32", k_div_scale, 8, cus, d, ds);
+    run("v_div_fmas_f32", k_div_fmas, 8, cus, d, ds);
+    run("v_div_fixup_f32", k_div_fixup, 8, cus, d, ds);
+    run("v_lshlrev_b64", k_lshl_b64, 8, cus, d, ds);
+    run("v_lshl_add_u64", k_lshl_add_u64, 8, cus, d, ds);
+    run("v_mov_b32 dpp quad_perm", k_mov_dpp, 8, cus, d, ds);
     printf("  {}]}\n");
     return 0;
 }
