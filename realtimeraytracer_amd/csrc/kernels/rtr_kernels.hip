@@ -1454,8 +1454,14 @@ __global__ __launch_bounds__(64) void k_light_tris(const RtrAreaLightInfo* __res
     for (uint32_t ti = 0; ti < L->numTriangles; ++ti) light_tri_record(L, vertices, indices, ti, out + (size_t)(first[l] + ti) * kLightTriRecord);
 }
 
-/* Pre-fill of the visibility array: the first planeVec 16-B words of each plane (blockIdx.y), pitchVec words apart. */
-__global__ __launch_bounds__(kBlock) void k_fill_planes(uint4* __restrict__ vis, uint32_t word, uint32_t planeVec, uint32_t pitchVec) {
+/* Pre-fill of the visibility array: the first planeVec 16-B words of each plane (blockIdx.y), pitchVec words apart — and the launch's
+ * control block and overflow count zeroed by the first workgroup (two memset launches less in front of every launch of the pipeline). */
+__global__ __launch_bounds__(kBlock) void k_fill_planes(uint4* __restrict__ vis, uint32_t word, uint32_t planeVec, uint32_t pitchVec,
+                                                        uint32_t* __restrict__ ctrl, uint32_t ctrlWords, uint32_t* __restrict__ overflowCount) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (uint32_t i = threadIdx.x; i < ctrlWords; i += kBlock) ctrl[i] = 0u;
+        if (threadIdx.x == 0) overflowCount[0] = 0u;
+    }
     const uint4 v = make_uint4(word, word, word, word);
     uint4* plane = vis + (size_t)blockIdx.y * pitchVec;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < planeVec; i += gridDim.x * kBlock) plane[i] = v;
@@ -1528,9 +1534,7 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     const RenderArgs& ra = fb.ra[0];                   /* extent, spp, sharding: the same for every frame of the batch */
     const uint32_t nb = fb.n;
     const uint32_t blocks = (padded_pixels(ra) + kBlock - 1) / kBlock;      /* per frame and sample plane */
-    hipError_t e;
-    if ((e = hipMemsetAsync(ws.queueCount, 0, kQueueCtrlWords * sizeof(uint32_t), s)) != hipSuccess) return e;   /* [0] queue length, [1] / [16 + 16 r] batch cursors */
-    if ((e = hipMemsetAsync(ws.overflow, 0, sizeof(uint32_t), s)) != hipSuccess) return e;           /* [0] number of abandoned rays */
+    /* the control block (queue length, batch cursors, list lengths ...) and the count of abandoned rays are zeroed by k_fill_planes */
     /* the visibility array starts as "every ray had the commoner outcome" (the frame object's last launch says which: three shadow
      * rays in four of the bench frame are occluded); the any-hit kernel stores only the other outcome — whole-line fill traffic
      * instead of most of its scattered byte stores (WRITE_SIZE of the launch 136 -> 34 MB + 27 MB of fill) */
@@ -1539,7 +1543,8 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         const uint32_t planeVec = (uint32_t)(ws.visPlaneBytes / 16u), pitchVec = ws.rayQueue.slotStride / 16u;
         uint32_t fblocks = std::min<uint32_t>((planeVec + kBlock - 1) / kBlock, std::max<uint32_t>(4096u / std::max<uint32_t>(ws.visPlanes, 1u), 64u));
         if (fblocks == 0) fblocks = 1;
-        hipLaunchKernelGGL(k_fill_planes, dim3(fblocks, ws.visPlanes ? ws.visPlanes : 1u), dim3(kBlock), 0, s, reinterpret_cast<uint4*>(ws.vis), ws.visFill * 0x01010101u, planeVec, pitchVec);
+        hipLaunchKernelGGL(k_fill_planes, dim3(fblocks, ws.visPlanes ? ws.visPlanes : 1u), dim3(kBlock), 0, s, reinterpret_cast<uint4*>(ws.vis), ws.visFill * 0x01010101u, planeVec, pitchVec,
+                           ws.queueCount, kQueueCtrlWords, ws.overflow);
     }
     if (ev) hipEventRecord(ev[0], s);
     /* the storage of ws.overflow is used twice per frame: first as k_primary's redo list (count in queueCount[2], consumed by
