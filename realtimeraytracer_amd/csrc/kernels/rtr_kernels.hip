@@ -188,10 +188,17 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
 /* One camera ray per lane (the comparison form, RTR_PRIMARY_PERSIST=0; k_primary_persist is the production kernel).  16-entry LDS
  * stack (16 KiB per workgroup): ordered traversal seldom holds more, and the rare ray that needs more is listed in `redo` and
  * re-traced by k_primary_tail with a full-depth stack in global memory — the same rule in the timed and the counting form. */
+#ifndef RTR_PRIMARY_BLOCK
+#define RTR_PRIMARY_BLOCK 64
+#endif
+/* Lanes per workgroup of k_primary (a multiple of 64 dividing kBlock).  One wave: a workgroup lives as long as its slowest ray, and with
+ * four waves the three that finish first keep their wave slots and LDS idle until the fourth does — 0.144 -> 0.134 ms per frame in
+ * launches, 0.304 -> 0.286 alone (profiles/r04/ab_primary_block.log). */
+constexpr int kPrimBlock = RTR_PRIMARY_BLOCK;
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
+__global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
                                                     Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
-    __shared__ int32_t s_stack[16 * kBlock];
+    __shared__ int32_t s_stack[16 * kPrimBlock];
     int32_t* stack = s_stack + threadIdx.x;
     /* the grid is spp planes of planeBlocks workgroups: one lane = one (sample, pixel slot), so at spp > 1 the samples of a pixel are
      * walked side by side by different waves instead of one after the other by one lane (the kernel is bound by the chain of dependent
@@ -199,32 +206,32 @@ __global__ __launch_bounds__(kBlock) void k_primary(DeviceScene sc, FrameBatch f
     const uint32_t plane = blockIdx.x / planeBlocks;                 /* frame of the batch * spp + sample */
     const RenderArgs& ra = fb.ra[plane / fb.ra[0].spp];
     const uint32_t i = plane % fb.ra[0].spp;
-    const uint32_t q = (blockIdx.x - plane * planeBlocks) * kBlock + threadIdx.x;
+    const uint32_t q = (blockIdx.x - plane * planeBlocks) * kPrimBlock + threadIdx.x;
     uint32_t px, lrow, py;
     if (!pixel_of(ra, q, px, lrow, py)) return;
     LocalStats st;
     const rtr_v3 camPos = rtr_ld3(ra.cam.position);
     const rtr_v3 dir = primary_dir(ra, px, py, i);
     HitRec h;
-    if (STATS) trace<false, true, kBlock, 16, 8>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
+    if (STATS) trace<false, true, kPrimBlock, 16, 8>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st);
     else {
         /* camera rays of one 8x8 tile nearly always share their direction signs: run the traversal compiled for that octant */
         const uint32_t oct = ray_octant(sc, camPos, dir);
         const uint32_t woct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
         switch (__ballot(oct != woct) != 0ull ? 8u : woct) {
-            case 0: trace<false, false, kBlock, 16, 0>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 1: trace<false, false, kBlock, 16, 1>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 2: trace<false, false, kBlock, 16, 2>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 3: trace<false, false, kBlock, 16, 3>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 4: trace<false, false, kBlock, 16, 4>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 5: trace<false, false, kBlock, 16, 5>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 6: trace<false, false, kBlock, 16, 6>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            case 7: trace<false, false, kBlock, 16, 7>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
-            default: trace<false, false, kBlock, 16, 8>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 0: trace<false, false, kPrimBlock, 16, 0>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 1: trace<false, false, kPrimBlock, 16, 1>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 2: trace<false, false, kPrimBlock, 16, 2>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 3: trace<false, false, kPrimBlock, 16, 3>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 4: trace<false, false, kPrimBlock, 16, 4>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 5: trace<false, false, kPrimBlock, 16, 5>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 6: trace<false, false, kPrimBlock, 16, 6>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            case 7: trace<false, false, kPrimBlock, 16, 7>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
+            default: trace<false, false, kPrimBlock, 16, 8>(sc, stack, camPos, dir, 0.001f, 10000.0f, h, st); break;
         }
     }
     /* sample-major planes keep each store of a wave contiguous */
-    const size_t k = (size_t)plane * planeBlocks * kBlock + q;
+    const size_t k = (size_t)plane * planeBlocks * kPrimBlock + q;
     if (h.custom == RTR_STACK_OVERFLOW) redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k;
     else {
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -1577,8 +1584,8 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         packet = true;
         if (stats) hipLaunchKernelGGL((k_primary_packet<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, blocks);
         else hipLaunchKernelGGL((k_primary_packet<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, blocks);
-    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
     if (!packet) {
         if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
         else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
