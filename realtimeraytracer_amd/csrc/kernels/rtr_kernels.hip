@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
                                                               RayQueue queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
                                                               uint32_t listStride, uint32_t kBatch, uint32_t nt) {
     constexpr uint32_t kWaves = kGenOctBlock / 64;
-    __shared__ uint32_t s_tot[kWaves][8], s_run[kWaves][8], s_first[8], s_len[8];
+    __shared__ uint32_t s_tot[kWaves][8], s_run[kWaves][8];
     uint32_t q;
     const uint32_t frame = batch_frame(blockIdx.x * kGenOctBlock + threadIdx.x, planeStride, q);
     const RenderArgs& ra = fb.ra[frame < fb.n ? frame : 0u];
@@ -506,31 +506,39 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
         if ((threadIdx.x & 63u) == 0) s_tot[wave][o] = t;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                       /* ONE reservation per workgroup (see k_shadow_gen), then the runs inside it */
-        uint32_t total = 0;
-        for (uint32_t o = 0; o < 8; ++o) { uint32_t t = 0; for (uint32_t w = 0; w < kWaves; ++w) t += s_tot[w][o]; s_len[o] = t; total += t; }
-        uint32_t at = total ? atomicAdd(ctrl, total) : 0u;
-        for (uint32_t o = 0; o < 8; ++o) { s_first[o] = at; at += s_len[o]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < kQueueLists) {              /* one lane per (octant, list): the waves' write cursors; the run's batches */
+    if (threadIdx.x < kQueueLists) {
+        /* The first wave, one lane per (octant, list), makes BOTH reservations at once — the workgroup's chunk of the queue (lane 0: ONE
+         * atomic per workgroup, see k_shadow_gen) and the places of its batches in the 64 lists (how many batches a run is cut into
+         * depends on its length only) — so the workgroup waits for one device-scope round trip, not for two with a barrier between; then
+         * it lays the runs inside the chunk: the waves' write cursors, the batch descriptors.  Every lane sums the per-wave counts
+         * itself (64 broadcast LDS reads) instead of waiting for one lane to do it. */
         const uint32_t o = threadIdx.x / kQueueRegions, x = threadIdx.x % kQueueRegions;
-        if (x == 0) {
-            uint32_t at = s_first[o];
-            for (uint32_t w = 0; w < kWaves; ++w) { s_run[w][o] = at; at += s_tot[w][o]; }
+        uint32_t before = 0, len = 0, total = 0;                 /* rays of the octants before o, of o, of all */
+#pragma unroll
+        for (uint32_t oo = 0; oo < 8; ++oo) {
+            uint32_t t = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kWaves; ++w) t += s_tot[w][oo];
+            before += oo < o ? t : 0u;
+            len = oo == o ? t : len;
+            total += t;
         }
-        const uint32_t len = s_len[o];
         /* the run's batches are dealt round-robin to the eight lists of this octant (one per consumer XCD); every lane makes its
-         * own reservation, so the workgroup waits for one atomic's round trip, not eight in a row */
+         * own reservation */
         const uint32_t nb = (len + kBatch - 1) / kBatch;
         const uint32_t b0 = (x + kQueueRegions - blockIdx.x % kQueueRegions) % kQueueRegions;     /* first batch that goes to list x */
-        if (b0 < nb) {
-            const uint32_t cnt = (nb - b0 + kQueueRegions - 1) / kQueueRegions;
-            const uint32_t pos = atomicAdd(ctrl + kQueueListLens + threadIdx.x, cnt);
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const uint32_t f = (b0 + j * kQueueRegions) * kBatch;
-                lists[(size_t)threadIdx.x * listStride + pos + j] = make_uint2(s_first[o] + f, len - f < kBatch ? len - f : kBatch);
-            }
+        const uint32_t cnt = b0 < nb ? (nb - b0 + kQueueRegions - 1) / kQueueRegions : 0u;
+        uint32_t at = 0, pos = 0;
+        if (threadIdx.x == 0 && total) at = atomicAdd(ctrl, total);
+        if (cnt) pos = atomicAdd(ctrl + kQueueListLens + threadIdx.x, cnt);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + before;      /* of this lane's octant's run */
+        if (x == 0) {
+            uint32_t c = first;
+            for (uint32_t w = 0; w < kWaves; ++w) { s_run[w][o] = c; c += s_tot[w][o]; }
+        }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t f = (b0 + j * kQueueRegions) * kBatch;
+            lists[(size_t)threadIdx.x * listStride + pos + j] = make_uint2(first + f, len - f < kBatch ? len - f : kBatch);
         }
     }
     __syncthreads();
