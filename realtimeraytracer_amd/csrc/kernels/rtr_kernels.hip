@@ -380,6 +380,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+/* The sum over the 64 lanes as a wave-uniform value, through the DPP cross-lane modes of gfx9 (quad permutes, row mirrors, row
+ * broadcasts: vector instructions) instead of six trips through the LDS crossbar (ds_bpermute): the queue build sums eight counters
+ * per wave before it can reserve anything.  All 64 lanes must be active. */
+__device__ __forceinline__ uint32_t wave_total(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);       /* quad_perm:[1,0,3,2] */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);       /* quad_perm:[2,3,0,1] */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);      /* row_half_mirror */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);      /* row_mirror: every lane holds its row's sum */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      /* row_bcast:15 into rows 1 and 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      /* row_bcast:31 into rows 2 and 3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 /* 1024-thread workgroups (16 waves): the queue is reserved once per workgroup, see below; planeStride = the sample-plane stride
  * of the hit records k_primary wrote (its grid x 256). */
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
     for (uint32_t o = 0; o < 8; ++o) {
         const uint32_t c = (uint32_t)(((o < 4 ? cp.lo : cp.hi) >> ((o & 3u) * 16u)) & 0xffffull);
         mine += c;
-        const uint32_t t = wave_sum(c);
+        const uint32_t t = wave_total(c);
         if ((threadIdx.x & 63u) == 0) s_tot[wave][o] = t;
     }
     __syncthreads();
