@@ -537,7 +537,12 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
         }
         /* the run's batches are dealt round-robin to the eight lists of this octant (one per consumer XCD); every lane makes its
          * own reservation */
-        const uint32_t nb = (len + kBatch - 1) / kBatch;
+        /* Long queues (batches of >= 512 rays): the last eighth of the workgroups — whose batches land at the ends of the lists, which the
+         * any-hit kernel's waves drain last — cut their runs into half batches, so the kernel ends on shorter ones (-0.5 % of the any-hit
+         * kernel in 8-frame launches; a single frame's 256-ray batches are left alone: finer ones cost it more than the shorter tail
+         * saves — profiles/r04/ab_gen_tail_batches*.log) */
+        const uint32_t kB = (kBatch >= 512u && blockIdx.x * 8u >= gridDim.x * 7u) ? kBatch / 2u : kBatch;
+        const uint32_t nb = (len + kB - 1) / kB;
         const uint32_t b0 = (x + kQueueRegions - blockIdx.x % kQueueRegions) % kQueueRegions;     /* first batch that goes to list x */
         const uint32_t cnt = b0 < nb ? (nb - b0 + kQueueRegions - 1) / kQueueRegions : 0u;
         uint32_t at = 0, pos = 0;
@@ -549,8 +554,8 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
             for (uint32_t w = 0; w < kWaves; ++w) { s_run[w][o] = c; c += s_tot[w][o]; }
         }
         for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t f = (b0 + j * kQueueRegions) * kBatch;
-            lists[(size_t)threadIdx.x * listStride + pos + j] = make_uint2(first + f, len - f < kBatch ? len - f : kBatch);
+            const uint32_t f = (b0 + j * kQueueRegions) * kB;
+            lists[(size_t)threadIdx.x * listStride + pos + j] = make_uint2(first + f, len - f < kB ? len - f : kB);
         }
     }
     __syncthreads();
