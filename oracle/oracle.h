@@ -42,7 +42,22 @@ typedef struct oracle_scene {
      * 2 (tunable primary_wide = 1; needs `wide`): one ray per lane over the 4-wide view, closest hit, 16 stack entries + redo over the
      * BVH2 (k_primary4). */
     uint32_t primaryPackets;
+    /* The order a shadow ray tries the children of a wide record in — it decides the work counters, never the answer (any-hit is a
+     * pure function of ray and triangles): 0 = the nearest hit child first (strict <, ties to the lower slot), the others stacked in
+     * slot order; 1 = the any-hit order: the first hit slot in SLOT order, the others stacked so that they pop in slot order (the
+     * builder arranged the slots by where an occluder is expected soonest; no distance is compared). */
+    uint32_t shadowWalk;
+    /* Experiments only (profiles/experiments/anyhit_order_lab.py), normally NULL: numWide * 4 * 3 counters the shadow walk adds to —
+     * per (record, slot) {times the walk went into the slot, record visits + triangle tests it then spent below it, occluders it found
+     * below it} — from which an order "by found occluders per unit of work" is made. */
+    uint64_t* walkProfile;
 } oracle_scene;
+
+/* shadow rays walked over the wide view, split by their answer (what an any-hit order is judged by) */
+typedef struct oracle_walk_stats {
+    uint64_t occludedRays, occludedVisits, occludedTests;
+    uint64_t visibleRays, visibleVisits, visibleTests;
+} oracle_walk_stats;
 
 typedef struct oracle_out {
     /* any pointer may be NULL; sizes are localRows*width elements */
@@ -53,6 +68,7 @@ typedef struct oracle_out {
     uint32_t* position;
     float*    hdr;           /* float4 per pixel: pre-tonemap shadowed radiance (accumulated if params.accumulate) */
     rtr_frame_stats stats;   /* counters filled when params.collectStats */
+    oracle_walk_stats walk;
 } oracle_out;
 
 /* Renders with the same semantics as rtr_render (same params struct, same band sharding).

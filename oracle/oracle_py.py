@@ -1,6 +1,6 @@
 """ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE.  Importable only from tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg; nothing under realtimeraytracer_amd/ may
-import this module (tests/test_layout.py enforces it)."""
+import this module (tests/test_abi.py::test_product_never_touches_the_oracle enforces it)."""
 import ctypes as C
 import os
 import subprocess
@@ -16,13 +16,17 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 class oracle_scene(C.Structure):
     _fields_ = [("desc", A.rtr_scene_desc), ("nodes", C.POINTER(A.RtrBvhNode)), ("numNodes", A.u32),
                 ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid),
-                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("primaryPackets", A.u32)]
+                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("primaryPackets", A.u32), ("shadowWalk", A.u32), ("walkProfile", C.POINTER(C.c_uint64))]
+
+
+class oracle_walk_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("occludedRays", "occludedVisits", "occludedTests", "visibleRays", "visibleVisits", "visibleTests")]
 
 
 class oracle_out(C.Structure):
     _fields_ = [("analytic", C.POINTER(A.u32)), ("shadowed", C.POINTER(A.u32)), ("unshadowed", C.POINTER(A.u32)),
                 ("normal", C.POINTER(A.u32)), ("position", C.POINTER(A.u32)), ("hdr", C.POINTER(A.f32)),
-                ("stats", A.rtr_frame_stats)]
+                ("stats", A.rtr_frame_stats), ("walk", oracle_walk_stats)]
 
 
 _lib = None
@@ -68,12 +72,15 @@ def lib():
     return _lib
 
 
-def make_scene(desc, bvh=None, primary_packets=False, primary_wide=False):
+def make_scene(desc, bvh=None, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None):
     """bvh = (nodes, tris, grid) from api.Scene.export_bvh() (ctypes arrays + the RtrBvhGrid of rtr_scene_stats), or None
     for brute force.  primary_packets: the staged pipeline's camera rays are walked one ray per lane (the product's default, k_primary) or
     tile by tile (tunable primary_packet = 1, k_primary_packet) — it decides work counters only."""
     s = oracle_scene()
     s.desc = desc
+    s.shadowWalk = int(shadow_walk)
+    if walk_profile is not None:      # numpy uint64 (numWide, 4, 3): experiments only
+        s.walkProfile = walk_profile.ctypes.data_as(C.POINTER(C.c_uint64))
     s.primaryPackets = 2 if primary_wide else (1 if primary_packets else 0)      # how the staged pipeline walks its camera rays: 0 one ray per lane over the BVH2, 1 8x8 packets, 2 one ray per lane over the 4-wide view
     if bvh is not None:
         nodes, tris, grid = bvh
@@ -94,12 +101,12 @@ class Result:
     pass
 
 
-def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False):
+def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None):
     """Returns a Result with numpy uint32 images (rows x width) keyed like rtr_image, .hdr and .stats."""
     L = lib()
     rows = _shard_rows(params.height, params.bandRows or 8, params.shardCount or 1)
     W = params.width
-    sc = make_scene(desc, bvh, primary_packets, primary_wide)
+    sc = make_scene(desc, bvh, primary_packets, primary_wide, shadow_walk, walk_profile)
     out = oracle_out()
     r = Result()
     r.images = {}
@@ -119,6 +126,7 @@ def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFF
     if rc != 0:
         raise RuntimeError(f"oracle_render failed: {rc}")
     r.stats = out.stats
+    r.walk = out.walk
     return r
 
 

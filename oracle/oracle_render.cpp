@@ -28,7 +28,9 @@ namespace {
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
     uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0, primaryOverflow = 0;
+    uint64_t walk[6] = {0, 0, 0, 0, 0, 0};   /* oracle_walk_stats: shadow rays over the wide view, split by their answer */
     void add(const Counters& o) {
+        for (int k = 0; k < 6; ++k) walk[k] += o.walk[k];
         shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests; primaryOverflow += o.primaryOverflow;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
@@ -44,6 +46,8 @@ struct Scene {
     std::vector<const RtrInstance*> byCustom;
     rtr_v3 skyLinear;
     bool useWide = false;                   /* shadow rays over the wide view (oracle_scene::wide) */
+    uint32_t shadowWalk = 0;                /* oracle_scene::shadowWalk */
+    std::vector<uint32_t> wideParent;       /* only with oracle_scene::walkProfile: record -> parent record * 4 + slot */
     int primaryStackLimit = 0;              /* 16 in the staged pipeline (k_primary_persist / k_primary + k_primary_tail), 0 = unbounded (megakernel) */
     bool primaryPackets = false;            /* camera rays walked tile by tile (trace_packet, k_primary_packet) */
     bool primaryWide = false;               /* camera rays one per lane over the 4-wide view (trace_wide_closest, k_primary4) */
@@ -290,10 +294,24 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
     rtr_ray_grid_centre(o, idir, sc.s->grid.origin, sc.s->grid.scale, sc.s->grid.wideCentreXY, sc.s->grid.wideCentreZ, &ga, &gb);
     std::vector<int32_t> stack;
     int32_t cur = 0;
+    const bool slotOrder = sc.shadowWalk == 1u;
+    uint64_t visits = 0, tests = 0;            /* of this ray, for the split by its answer (oracle_walk_stats) */
+    auto done = [&](bool occluded) { c.walk[occluded ? 0 : 3]++; c.walk[occluded ? 1 : 4] += visits; c.walk[occluded ? 2 : 5] += tests; };
+    /* walk profile (experiments only, oracle.h): per (record, slot) {entries, work done below it, occluders found below it} */
+    uint64_t* const prof = sc.s->walkProfile;
+    auto credit = [&](uint32_t rec, uint32_t slot, int what, uint64_t n) {       /* (rec, slot) and every slot above it */
+        for (;;) {
+            __atomic_fetch_add(&prof[((size_t)rec * 4u + slot) * 3u + (size_t)what], n, __ATOMIC_RELAXED);
+            if (rec == 0u) break;
+            const uint32_t up = sc.wideParent[rec]; rec = up >> 2; slot = up & 3u;
+        }
+    };
+    std::vector<uint32_t> from;                                                   /* parallel to `stack` */
+    uint32_t curFrom = 0;
     for (;;) {
         if (cur >= 0) {
             const RtrWideNode& n = nodes[cur];
-            c.nodes++; c.shadowNodes++;
+            c.nodes++; c.shadowNodes++; visits++;
             int hit[4]; float te[4];
             for (int k = 0; k < 4; ++k) {
                 const uint32_t wmin = n.plane[k][0], wmax = n.plane[k][1], wz = n.plane[k][2];
@@ -306,21 +324,37 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
                 hit[k] = lo <= hi * RTR_BOX_WIDEN;
                 if (k >= 2 && n.child[k] == RTR_WIDE_EMPTY) hit[k] = 0;
             }
-            int32_t next = RTR_WIDE_EMPTY;
-            float tn = 3.0e38f;
-            if (hit[0]) { tn = te[0]; next = n.child[0]; }
-            for (int k = 1; k < 4; ++k) if (hit[k] && te[k] < tn) { tn = te[k]; next = n.child[k]; }
-            bool overflow = false;
-            for (int k = 0; k < 4; ++k) if (hit[k] && n.child[k] != next) { stack.push_back(n.child[k]); }
+            int nextSlot = -1;
+            if (slotOrder) {
+                /* the any-hit order: the record's slots were put in the order they should be tried when it was made (the builder's
+                 * estimate of where an occluder is met soonest); the first hit slot is entered, the others are stacked so that they
+                 * pop in slot order — no distances are compared */
+                for (int k = 0; k < 4; ++k) if (hit[k]) { nextSlot = k; break; }
+                for (int k = 3; k >= 0; --k) if (hit[k] && k != nextSlot) { stack.push_back(n.child[k]); if (prof) from.push_back((uint32_t)cur * 4u + (uint32_t)k); }
+            } else {
+                float tn = 3.0e38f;
+                if (hit[0]) { tn = te[0]; nextSlot = 0; }
+                for (int k = 1; k < 4; ++k) if (hit[k] && te[k] < tn) { tn = te[k]; nextSlot = k; }
+                for (int k = 0; k < 4; ++k) if (hit[k] && k != nextSlot) { stack.push_back(n.child[k]); if (prof) from.push_back((uint32_t)cur * 4u + (uint32_t)k); }
+            }
+            if (prof && cur != 0) credit(curFrom >> 2, curFrom & 3u, 1, 1);       /* this visit is work below the slot that led here */
             /* the kernel keeps RTR_WIDE_STACK stack entries in LDS; a ray that would hold more
              * after a visit is abandoned there and re-traced from scratch over the BVH2 by k_shadow_tail (counting form: both parts
              * are counted) */
-            overflow = stack.size() > RTR_WIDE_STACK;
-            if (overflow) return trace_bvh(sc, o, d, tmin, tmax, true, c);
-            if (next == RTR_WIDE_EMPTY) {
-                if (stack.empty()) return best;
-                next = stack.back(); stack.pop_back();
+            if (stack.size() > RTR_WIDE_STACK) {
+                const uint64_t n0 = c.shadowNodes, t0 = c.shadowTris;
+                const Hit h = trace_bvh(sc, o, d, tmin, tmax, true, c);
+                visits += c.shadowNodes - n0; tests += c.shadowTris - t0;
+                done(h.hit);
+                return h;
             }
+            int32_t next;
+            if (nextSlot < 0) {
+                if (stack.empty()) { done(false); return best; }
+                next = stack.back(); stack.pop_back();
+                if (prof) { curFrom = from.back(); from.pop_back(); }
+            } else { next = n.child[nextSlot]; curFrom = (uint32_t)cur * 4u + (uint32_t)nextSlot; }
+            if (prof) __atomic_fetch_add(&prof[(size_t)curFrom * 3u], 1ull, __ATOMIC_RELAXED);      /* an entry of that slot */
             cur = next;
         } else {
             const uint32_t code = (uint32_t)~cur;
@@ -328,16 +362,20 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
             for (uint32_t i = 0; i < count; ++i) {
                 const RtrBvhTri& tr = tris[first + i];
                 float t, u, v;
-                c.tris++; c.shadowTris++;
+                c.tris++; c.shadowTris++; tests++;
+                if (prof) credit(curFrom >> 2, curFrom & 3u, 1, 1);
                 if (rtr_mt_intersect(o, d, rtr_ld3(tr.v0), rtr_ld3(tr.e1), rtr_ld3(tr.e2), tmin, &t, &u, &v)) {
                     if (!(t < tmax)) continue;
                     if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
                     best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = tr.customIndex; best.prim = tr.primitiveId;
+                    if (prof) credit(curFrom >> 2, curFrom & 3u, 2, 1);
+                    done(true);
                     return best;
                 }
             }
-            if (stack.empty()) return best;
+            if (stack.empty()) { done(false); return best; }
             cur = stack.back(); stack.pop_back();
+            if (prof) { curFrom = from.back(); from.pop_back(); __atomic_fetch_add(&prof[(size_t)curFrom * 3u], 1ull, __ATOMIC_RELAXED); }
         }
     }
 }
@@ -810,6 +848,12 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     Scene sc;
     if (!prepare(s, sc)) return -1;
     sc.useWide = s->wide != nullptr && s->nodes != nullptr && s->numWide > 0 && prm.pipeline != 1;
+    sc.shadowWalk = s->shadowWalk;
+    if (sc.useWide && s->walkProfile) {
+        sc.wideParent.assign(s->numWide, 0u);
+        for (uint32_t i = 0; i < s->numWide; ++i)
+            for (uint32_t k = 0; k < 4; ++k) if (s->wide[i].child[k] >= 0 && (uint32_t)s->wide[i].child[k] < s->numWide) sc.wideParent[(size_t)s->wide[i].child[k]] = i * 4u + k;
+    }
     sc.primaryStackLimit = (s->nodes != nullptr && prm.pipeline != 1) ? 16 : 0;
     sc.primaryPackets = s->nodes != nullptr && prm.pipeline != 1 && s->primaryPackets == 1;
     sc.primaryWide = sc.useWide && s->primaryPackets == 2;
@@ -899,6 +943,8 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     const uint64_t shadowNodeBytes = sc.useWide ? RTR_WIDE_NODE_BYTES : RTR_BVH_NODE_BYTES;
     st.shadowTraceBytes = shadowNodeBytes * tot.shadowNodes + 48 * tot.shadowTris + 37 * tot.shadow;   /* per ray: 20-B queue record + 16-B origin of its pixel-sample + visibility byte */
     st.primaryTailRays = tot.primaryOverflow;
+    out->walk.occludedRays = tot.walk[0]; out->walk.occludedVisits = tot.walk[1]; out->walk.occludedTests = tot.walk[2];
+    out->walk.visibleRays = tot.walk[3]; out->walk.visibleVisits = tot.walk[4]; out->walk.visibleTests = tot.walk[5];
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;
