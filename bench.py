@@ -75,6 +75,25 @@ def launch_sizes(count, batch):
     return [base + 1] * extra + [base] * (nl - extra)
 
 
+def launches_in_flight(n_gpus, groups):
+    """Launches a rank keeps enqueued under a latency bound.  A frame's camera is fixed when its launch is enqueued, so a frame is
+    (launches in flight) x (launch duration) old when its launch ends.  One GPU: one launch at a time (the next is enqueued when the last has
+    been joined).  N > 1: two — while launch k runs, launch k + 1 is already enqueued, so that rank 0's exchange and de-interleave of k
+    overlap the render of k + 1 — and the bound is applied to BOTH launches' duration."""
+    return 1 if n_gpus <= 1 else max(1, min(2, groups))
+
+
+def latency_fields(B, groups, steps, ms_per_step, latency):
+    """frames_per_launch / frame_latency_ms of the JSON line, from the launches the timed region made (not from the probe):
+    the longest timed launch x ms_per_step x the launches in flight"""
+    timed = launch_sizes(steps, B)
+    longest = max(timed) if timed else B
+    latency = dict(latency, launches_in_flight=groups, frames_per_launch_limit=B,
+                   frame_latency_is="launches_in_flight x the longest timed launch's frames x ms_per_step: the age of a launch's first frame when the launch ends "
+                                    "(its camera was fixed when the launch was enqueued)")
+    return {"frames_per_launch": longest, "frame_latency_ms": round(groups * longest * ms_per_step, 4), "latency": latency, "timed_launches": timed}
+
+
 # sponza_mixed: the atrium with the triangle-size mix of a real asset (large walls / column slivers beside fine cloth, an alpha-tested layer);
 # a second line for profiles/, never the headline (BASELINE config 4 is sponza_class)
 WORKLOADS = {"sponza_class": "sponza_class", "cornell": "cornell_box", "bunny_class": "bunny_class", "sponza_mixed": "sponza_mixed"}
@@ -312,8 +331,9 @@ def run_inproc(args, K, plan):
                     best = dt if best is None else min(best, dt)
             latency["probes"].append({"frames": c, "launch_ms": round(best, 4)})
             return best
-        c = pick_frames_per_launch(args.max_latency_ms * PROBE_MARGIN, cap, probe)
-        B, groups = c, max(nbuf // c, 1)
+        lif = launches_in_flight(N, max(nbuf // 2, 1))      # N > 1: two launches enqueued, so a single launch may take half the bound
+        c = pick_frames_per_launch(args.max_latency_ms * PROBE_MARGIN / lif, max(1, min(cap, nbuf // lif)), probe)
+        B, groups = c, launches_in_flight(N, max(nbuf // c, 1))
         for _ in range(groups):                         # the slots that lead launches of this size grow their scratch now, not in the timed region
             run_steps(0, B)
         drain()
@@ -345,7 +365,7 @@ def run_inproc(args, K, plan):
         "metric": "Mrays/sec at 1920x1080 1spp (all rays: primary + shadow)" if (W, H, S, K) == (1920, 1080, 1, 1) else f"Mrays/sec at {W}x{H} {S}spp" + (f" x{K} frames accumulated in HDR" if K > 1 else ""),
         "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / K, 4), "higher_is_better": True,
-        "frames_per_launch": B, "frame_latency_ms": round(B * ms_per_step, 4), "latency": latency,
+        **latency_fields(B, groups, args.steps, ms_per_step, latency),
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("file " + args.obj) if args.obj else "synthetic",
         "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
                                f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{N}",
@@ -355,7 +375,6 @@ def run_inproc(args, K, plan):
                    "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries), "build_ms": round(float(sstats.buildMs), 1)}},
         "primary_mrays_per_s": round(primary_total / elapsed / 1e6, 2),
         "frames_in_flight": nbuf,
-        "timed_launches": launch_sizes(args.steps, B),
         "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
         "kernels_scope": "rank 0's shard, per frame (a launch covers frames_per_launch frames); HIP-event brackets",
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
@@ -766,10 +785,10 @@ def main():
                     best = dt if best is None else min(best, dt)
             latency["probes"].append({"frames": c, "launch_ms": round(best, 4)})
             return best
-        c = pick_frames_per_launch(args.max_latency_ms * PROBE_MARGIN, cap, probe)
-        B, groups = c, max(nbuf // c, 1)
-        if not dist_on:                                 # one launch at a time on one GPU: the frame objects of one launch
-            nbuf, groups = B, 1
+        lif = launches_in_flight(world if dist_on else 1, max(nbuf // 2, 1))      # N > 1: two launches enqueued, so a single launch may take half the bound
+        c = pick_frames_per_launch(args.max_latency_ms * PROBE_MARGIN / lif, max(1, min(cap, nbuf // lif)), probe)
+        B, groups = c, launches_in_flight(world if dist_on else 1, max(nbuf // c, 1))
+        nbuf = B * groups                               # the frame objects of the launches in flight (one GPU: one launch at a time)
         for _ in range(groups):                         # the frames that lead launches of this size grow their scratch now, not in the timed region
             run_steps(0, B)
         drain()
@@ -1006,7 +1025,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / K, 4), "higher_is_better": True,
             # a launch renders frames_per_launch frames and they are ready together when it ends: the age of the first of them, and how
             # far ahead the cameras had to be known (one_frame_at_a_time below: the same frames with one frame per launch)
-            "frames_per_launch": B, "frame_latency_ms": round(B * ms_per_step, 4), "latency": latency,
+            **latency_fields(B, groups, args.steps, ms_per_step, latency),
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("file " + args.obj) if args.obj else "synthetic",
             "config": {"workload": f"{args.workload} {W}x{H} {S}spp{' x%d accumulated frames per step' % K if K > 1 else ''}, {sstats.numTriangles} triangles, {setup.num_lights} area lights, "
                                    f"{args.shadow_rays} shadow rays/light-triangle, band-sharded x{world}",
@@ -1017,7 +1036,6 @@ def main():
                                "build_ms": round(float(sstats.buildMs), 1)}},
             "primary_mrays_per_s": round(primary_total / elapsed / 1e6, 2),
             "frames_in_flight": nbuf,
-            "timed_launches": launch_sizes(args.steps, B),
             "kernels_ms": {k: round(v, 4) for k, v in kern_iso.items()} if kern_iso else {k: round(v / n, 4) for k, v in kern.items() if k != "n"},
             "kernels_ms_in_flight_event_brackets": {k: round(v / n, 4) for k, v in kern.items() if k != "n"} if kern_iso else None,
             "one_frame_at_a_time": {"ms_per_step": round(iso_ms_per_frame, 4), "mrays_per_s": round(iso_rays / args.isolated_frames * K / iso_ms_per_frame / 1e3, 2),

@@ -53,6 +53,9 @@ int  rtr_mgpu_scene_create(rtr_mgpu* m, const rtr_scene_desc* desc);
  * exchange — the frames of a sum before its last.  Returns when everything is enqueued; rtr_mgpu_wait joins.  Calls on one slot
  * are ordered; a slot's previous exchange is waited for (on the GPU, by an event) before its buffers are overwritten. */
 #define RTR_MGPU_NO_EXCHANGE 1
+/* the launch's transfers as one RCCL group PER SLOT instead of one group for the launch (the fallback; also set for every launch of a
+ * handle made while RTR_MGPU_GROUP_PER_SLOT=1 is in the environment) */
+#define RTR_MGPU_GROUP_PER_SLOT 2
 int  rtr_mgpu_render_async(rtr_mgpu* m, int slot, const RtrCameraData* camera, const RtrSceneInfo* sceneInfo, const rtr_render_params* params, int flags);
 /* n frames into n distinct slots with ONE launch of the pipeline per rank (rtr_render_batch_async: a 1/N shard of a 1-spp frame is
  * too little work per launch — one rank of eight renders a frame in 0.39 ms one launch per frame and in 0.35 ms four per launch) and
@@ -142,7 +145,7 @@ int  rtr_mgpu_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32
  * RENDER (slot 0 leads), one render -> communication edge, ONE group holding every slot's transfers in slot order — on rank 0 the
  * (nranks - 1) receives of slot 0, then of slot 1 ...; on the others one send per slot — then a DEINTERLEAVE and a RECORD per slot.
  * At most RTR_MGPU_BATCH_PLAN_MAX_OPS operations. */
-#define RTR_MGPU_BATCH_PLAN_MAX_OPS (6 + RTR_MAX_BATCH * (3 + RTR_MGPU_MAX_RANKS))
+#define RTR_MGPU_BATCH_PLAN_MAX_OPS (6 + RTR_MAX_BATCH * (5 + RTR_MGPU_MAX_RANKS))
 int  rtr_mgpu_plan_batch(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, int nslots,
                          rtr_mgpu_op* ops, int maxOps, int* numOps);
 

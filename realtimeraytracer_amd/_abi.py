@@ -228,7 +228,7 @@ MGPU_BUF_NONE, MGPU_BUF_LOCAL, MGPU_BUF_GATHER, MGPU_BUF_SELF_SRC, MGPU_BUF_FULL
 MGPU_EV_NONE, MGPU_EV_RENDER_DONE, MGPU_EV_COMM_DONE = range(3)
 MGPU_PLAN_MAX_OPS = 32
 MGPU_MAX_RANKS = 16
-MGPU_BATCH_PLAN_MAX_OPS = 6 + 32 * (3 + MGPU_MAX_RANKS)
+MGPU_BATCH_PLAN_MAX_OPS = 6 + 32 * (5 + MGPU_MAX_RANKS)
 
 
 MAX_BATCH = 32
@@ -236,6 +236,7 @@ MAX_SPLIT = 16
 MGPU_ID_BYTES = 128
 MGPU_MAX_SLOTS = 64
 MGPU_NO_EXCHANGE = 1
+MGPU_GROUP_PER_SLOT = 2
 
 # every entry point include/rtr_mgpu.h declares
 MGPU_SYMBOLS = {

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DeviceScene sc, RenderArg
  * four waves the three that finish first keep their wave slots and LDS idle until the fourth does — 0.144 -> 0.134 ms per frame in
  * launches, 0.304 -> 0.286 alone (profiles/r04/ab_primary_block.log). */
 constexpr int kPrimBlock = RTR_PRIMARY_BLOCK;
+static_assert(kPrimBlock % 64 == 0 && kPrimBlock >= 64 && kPrimBlock <= kBlock && kBlock % kPrimBlock == 0,
+              "RTR_PRIMARY_BLOCK: a multiple of 64 that divides the 256-lane tile group (the launcher's grid is blocks * (kBlock / kPrimBlock))");
 template <int STACK, bool STATS>
 __global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
                                                     Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
@@ -1531,7 +1533,9 @@ Tunables tunables_from_env() {
         env[n] = 0;
         const char* v = getenv(env);
         if (!v || !*v) continue;
-        const unsigned long x = strtoul(v, nullptr, 10);
+        char* end = nullptr;
+        const unsigned long x = strtoul(v, &end, 10);
+        if (end == v) continue;                               /* not a number: the default stays (RTR_TRACE_BINNED=foo is not "never binned") */
         t.*(f.field) = x < f.lo ? f.lo : (x > f.hi ? f.hi : (uint32_t)x);
     }
     return t;

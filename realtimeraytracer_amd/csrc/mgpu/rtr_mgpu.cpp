@@ -111,6 +111,7 @@ struct rtr_mgpu {
     bool selfExchange = false;
     std::atomic<bool> aborted{false};               /* the communicators were aborted: the handle only waits for / frees things now; workers issue no further RCCL call */
     uint32_t timeoutMs = 120000;
+    int planFlags = 0;                /* OR-ed into every launch's flags (RTR_MGPU_GROUP_PER_SLOT=1 in the environment at creation) */
     std::vector<std::unique_ptr<Rank>> ranks;       /* the local ones */
 };
 
@@ -203,8 +204,12 @@ int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t ba
      * of a rank's transfers together — a send and a receive that depend on each other and sit one behind the other on a stream
      * never complete */
     if (nranks > 1 || self) {
-        op(RTR_MGPU_OP_GROUP_START, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
+        /* RTR_MGPU_GROUP_PER_SLOT: the fallback — one group per slot (nslots RCCL launches instead of one), should a communicator ever
+         * mis-order the (N - 1) x nslots receives of one group */
+        const bool perSlot = (flags & RTR_MGPU_GROUP_PER_SLOT) != 0;
+        if (!perSlot) op(RTR_MGPU_OP_GROUP_START, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
         for (int j = 0; j < nslots; ++j) {
+            if (perSlot) op(RTR_MGPU_OP_GROUP_START, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
             if (self) {
                 op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, j, 0, RTR_MGPU_BUF_SELF_SRC, RTR_MGPU_EV_NONE, 0, shardBytes);
                 op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, j, 0, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, 0, shardBytes);
@@ -213,8 +218,9 @@ int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t ba
             } else {
                 op(RTR_MGPU_OP_SEND, RTR_MGPU_STREAM_COMM, j, 0, RTR_MGPU_BUF_LOCAL, RTR_MGPU_EV_NONE, 0, shardBytes);
             }
+            if (perSlot) op(RTR_MGPU_OP_GROUP_END, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
         }
-        op(RTR_MGPU_OP_GROUP_END, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
+        if (!perSlot) op(RTR_MGPU_OP_GROUP_END, RTR_MGPU_STREAM_COMM, 0, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_NONE, 0, 0);
     }
     if (rank == 0) for (int j = 0; j < nslots; ++j) op(RTR_MGPU_OP_DEINTERLEAVE, RTR_MGPU_STREAM_COMM, j, -1, RTR_MGPU_BUF_FULL, RTR_MGPU_EV_NONE, 0, (uint64_t)width * height * 4u);     /* one rank: a plain copy */
     for (int j = 0; j < nslots; ++j) op(RTR_MGPU_OP_RECORD, RTR_MGPU_STREAM_COMM, j, -1, RTR_MGPU_BUF_NONE, RTR_MGPU_EV_COMM_DONE, 0, 0);
@@ -378,6 +384,7 @@ void read_env(rtr_mgpu* m) {
     m->selfExchange = se && se[0] == '1';
 #endif
     if (const char* t = getenv("RTR_MGPU_TIMEOUT_MS")) m->timeoutMs = (uint32_t)strtoul(t, nullptr, 10);
+    if (const char* g = getenv("RTR_MGPU_GROUP_PER_SLOT")) if (g[0] == '1') m->planFlags |= RTR_MGPU_GROUP_PER_SLOT;
 }
 
 /* Gives the communicators up: peers blocked in a send / receive that will never be matched are released.  Cooperative with the
@@ -620,7 +627,7 @@ int rtr_mgpu_render_batch_async(rtr_mgpu* m, const int* slots, int n, const RtrC
     }
     /* Phase 2 — the plan, rank by rank, each on its own thread */
     BatchJob job;
-    job.n = n; job.p = *p; job.flags = flags;
+    job.n = n; job.p = *p; job.flags = flags | m->planFlags;
     for (int j = 0; j < n; ++j) { job.slots[j] = slots[j]; job.cams[j] = cams[j]; job.infos[j] = infos[j]; }
     for (auto& rp : m->ranks) {
         Rank* r = rp.get();

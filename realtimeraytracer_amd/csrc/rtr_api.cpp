@@ -1167,8 +1167,15 @@ int rtr_render_split_async(rtr_scene* s, const RtrCameraData* cam, const RtrScen
     if (f->batchStream && f->batchStream != st) HIP_TRY(hipStreamWaitEvent(st, f->evDone, 0));
     f->batchStream = nullptr;
     HIP_TRY(hipEventRecord(f->evSplit[0], st));          /* the fork */
+    /* A failure inside the loop must not leave the frame's stream un-joined from parts that were already enqueued (a download, clear
+     * or denoise that follows would race them, and rtr_frame_wait would never collect them): the error is kept, every part that WAS
+     * enqueued is joined, the frame is marked pending for exactly those, and then the error is returned. */
     int rc = RTR_OK;
     uint32_t started = 0;
+    auto hip_keep = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == RTR_OK) rc = fail(RTR_ERR_HIP, "rtr_render_split_async: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
     for (uint32_t k = 0; k < parts && rc == RTR_OK; ++k) {
         rtr_frame* pf = f->parts[k];
         pf->ctx->tun = f->ctx->tun;
@@ -1176,15 +1183,15 @@ int rtr_render_split_async(rtr_scene* s, const RtrCameraData* cam, const RtrScen
         for (int i = 0; i < 8; ++i) pf->ext[i] = f->image_ptr(i);
         pf->extHdr = f->hdr.p;
         hipStream_t ps = pf->ctx->stream;
-        HIP_TRY(hipStreamWaitEvent(ps, f->evSplit[0], 0));
+        if (!hip_keep(hipStreamWaitEvent(ps, f->evSplit[0], 0), "hipStreamWaitEvent (fork)")) break;
         p.shardIndex = k; p.shardCount = parts;
-        rc = enqueue_render(s, cam, info, &p, &pf, 1, true);
-        if (rc != RTR_OK) break;
-        HIP_TRY(hipEventRecord(f->evPart[k], ps));
-        HIP_TRY(hipStreamWaitEvent(st, f->evPart[k], 0));      /* the join: whatever follows on the frame's stream sees the whole frame */
-        ++started;
+        const int prc = enqueue_render(s, cam, info, &p, &pf, 1, true);
+        if (prc != RTR_OK) { rc = prc; break; }
+        ++started;                                              /* from here on part k has work on its stream: it must be joined */
+        if (hip_keep(hipEventRecord(f->evPart[k], ps), "hipEventRecord (part)")) hip_keep(hipStreamWaitEvent(st, f->evPart[k], 0), "hipStreamWaitEvent (join)");
+        else hip_keep(hipStreamSynchronize(ps), "hipStreamSynchronize (join of last resort)");      /* no event to order behind: drain the part here */
     }
-    HIP_TRY(hipEventRecord(f->evSplit[1], st));
+    hip_keep(hipEventRecord(f->evSplit[1], st), "hipEventRecord (join)");
     f->ownPending = true; f->viaBatch = false;
     f->pendingSplit = started; f->pendingStats = started != 0;
     return rc;

@@ -86,8 +86,22 @@ struct World {
 /* an operation keeps what it needs of its communicator BY VALUE (rank, world) and a reference on the world: the communicator may be
  * aborted — and deleted — by the watchdog's thread while the rank's own thread is still inside ncclGroupEnd */
 struct Op { bool send; void* buf; size_t bytes; int peer; int rank; World* w; hipStream_t stream; };
+/* gives the operations' references on their worlds back; the last one out frees a world every communicator of which is gone */
+void release(std::vector<Op>& ops) {
+    for (Op& o : ops) {
+        World* w = o.w;
+        bool last;
+        { std::lock_guard<std::mutex> g(w->mu); last = --w->users == 0 && w->alive == 0; }
+        if (last) delete w;
+    }
+    ops.clear();
+}
+/* the operations queued inside an open ncclGroupStart.  A rank's thread that is told to stop between ncclGroupStart and ncclGroupEnd
+ * (librtr_mgpu's cooperative abort makes no further RCCL call) never runs the group: the queue gives its references back when the
+ * thread ends, so an aborted world is still freed */
+struct Pending { std::vector<Op> ops; ~Pending() { release(ops); } };
 thread_local int g_depth = 0;
-thread_local std::vector<Op> g_ops;
+thread_local Pending g_pending;
 
 }  // namespace
 
@@ -97,7 +111,7 @@ namespace {
 
 int run_group(std::vector<Op>& ops) {
     Hip& h = hip();
-    if (!h.ok) return 1;
+    if (!h.ok) { release(ops); return 1; }
     std::vector<std::pair<Op*, Msg*>> sent;
     int rc = 0;
     for (Op& o : ops) if (o.send) {                      /* 1: post every send of the group */
@@ -147,12 +161,7 @@ int run_group(std::vector<Op>& ops) {
          * double that sends a few hundred messages — it keeps them */
         delete m;
     }
-    for (Op& o : ops) {                                    /* give the references back; the last one out frees a world every communicator of which is gone */
-        World* w = o.w;
-        bool last;
-        { std::lock_guard<std::mutex> g(w->mu); last = --w->users == 0 && w->alive == 0; }
-        if (last) delete w;
-    }
+    release(ops);
     return rc;
 }
 
@@ -195,14 +204,14 @@ ncclResult_t ncclGroupStart(void) { ++g_depth; return 0; }
 ncclResult_t ncclGroupEnd(void) {
     if (g_depth <= 0) return 5;
     if (--g_depth > 0) return 0;
-    std::vector<Op> ops; ops.swap(g_ops);
+    std::vector<Op> ops; ops.swap(g_pending.ops);
     return run_group(ops);
 }
 static ncclResult_t add(bool send, void* buf, size_t count, int type, int peer, ncclComm_t c, hipStream_t s) {
     if (!buf || !c || type != 1 /* ncclUint8 */ || peer < 0 || peer >= c->nranks) return 4;
     Op o{send, buf, count, peer, c->rank, c->w, s};
     { std::lock_guard<std::mutex> g(c->w->mu); ++c->w->users; }
-    if (g_depth > 0) { g_ops.push_back(o); return 0; }
+    if (g_depth > 0) { g_pending.ops.push_back(o); return 0; }
     std::vector<Op> one{o};
     return run_group(one);
 }

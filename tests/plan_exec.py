@@ -38,7 +38,7 @@ def plan_batch(rank, nranks, width, height, nslots, band_rows=8, flags=0, self_e
     return [dict(kind=o.kind, stream=o.stream, peer=o.peer, buffer=o.buffer, event=o.event, slot=o.slot, offset=int(o.offset), bytes=int(o.bytes)) for o in ops[:n.value]]
 
 
-def check_batch_plans(plans, width, height, nslots, band_rows=8):
+def check_batch_plans(plans, width, height, nslots, band_rows=8, group_per_slot=False):
     """plans[r] = rank r's plan of one launch of nslots frames.  ONE exchange per launch: a single group holding every slot's
     transfers; between a pair of ranks the sends and the receives name the slots in the same order (RCCL matches in posting order);
     every slot's shards land once at shardBytes * src of THAT slot's gather buffer; one render, led by slot 0; a de-interleave and an
@@ -58,7 +58,17 @@ def check_batch_plans(plans, width, height, nslots, band_rows=8):
         i_wait = next(i for i, o in enumerate(ops) if o["kind"] == A.MGPU_OP_WAIT and o["event"] == A.MGPU_EV_RENDER_DONE)
         assert ops[i_rec]["stream"] == A.MGPU_STREAM_RENDER and ops[i_wait]["stream"] == A.MGPU_STREAM_COMM and i_ren < i_rec < i_wait and ops[i_rec]["slot"] == ops[i_wait]["slot"], (r, "render -> comm edge")
         xfer = [i for i, o in enumerate(ops) if o["kind"] in (A.MGPU_OP_SEND, A.MGPU_OP_RECV)]
-        if n > 1:
+        if n > 1 and group_per_slot:
+            # the fallback (RTR_MGPU_GROUP_PER_SLOT): nslots groups one behind the other, group j holding exactly slot j's transfers
+            starts = [i for i, k in enumerate(kinds) if k == A.MGPU_OP_GROUP_START]
+            ends = [i for i, k in enumerate(kinds) if k == A.MGPU_OP_GROUP_END]
+            assert len(starts) == len(ends) == nslots and i_wait < starts[0], (r, "a group per slot, after the wait")
+            for j, (gs, ge) in enumerate(zip(starts, ends)):
+                inside = ops[gs + 1:ge]
+                assert gs < ge and (j == 0 or ends[j - 1] < gs), (r, j, "groups do not nest or overlap")
+                assert inside and all(o["kind"] in (A.MGPU_OP_SEND, A.MGPU_OP_RECV) and o["slot"] == j for o in inside), (r, j, "group j holds slot j's transfers only")
+            assert sum(e - s_ - 1 for s_, e in zip(starts, ends)) == len(xfer), (r, "no transfer outside a group")
+        elif n > 1:
             assert kinds.count(A.MGPU_OP_GROUP_START) == 1 and kinds.count(A.MGPU_OP_GROUP_END) == 1, (r, "ONE group per launch")
             gs, ge = kinds.index(A.MGPU_OP_GROUP_START), kinds.index(A.MGPU_OP_GROUP_END)
             assert i_wait < gs < min(xfer) and max(xfer) < ge, (r, "every transfer of every slot inside the one group, after the wait")
@@ -73,7 +83,7 @@ def check_batch_plans(plans, width, height, nslots, band_rows=8):
             else:
                 assert r == 0 and o["buffer"] == A.MGPU_BUF_GATHER and o["offset"] == shard * o["peer"], (r, "recv offset = shardBytes * src")
                 recvs.setdefault((o["peer"], 0), []).append(o["slot"])
-        tail = ops[(kinds.index(A.MGPU_OP_GROUP_END) + 1) if n > 1 else (i_wait + 1):]
+        tail = ops[(len(kinds) - kinds[::-1].index(A.MGPU_OP_GROUP_END)) if n > 1 else (i_wait + 1):]
         de = [o for o in tail if o["kind"] == A.MGPU_OP_DEINTERLEAVE]
         done = [o for o in tail if o["kind"] == A.MGPU_OP_RECORD and o["event"] == A.MGPU_EV_COMM_DONE]
         assert len(de) + len(done) == len(tail), (r, "behind the group: de-interleaves and exchange-done records only")

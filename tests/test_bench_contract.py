@@ -37,14 +37,16 @@ def test_bench_line_keeps_the_contract(scene_cache):
         assert k in r, k
     assert r["bound"] == "valu_issue" and r["avg_launch_ms"] > 0 and 1500 < r["clock_mhz"] < 2600
     # up to thirty-two frames per launch of every kernel by default, a run cut into equal launches; the roofline is that of the launches of the timed region
-    assert d["frames_per_launch"] == 32 and d["frames_in_flight"] == 32 and d["timed_launches"] == [12] and r["frames_per_launch"] == 12, (d["frames_per_launch"], d["latency"])
+    # the line describes the launches it TIMED: twelve steps are one launch of twelve frames, though thirty-two would have fitted the bound
+    assert d["frames_per_launch"] == 12 and d["latency"]["frames_per_launch_limit"] == 32 and d["frames_in_flight"] == 32 and d["timed_launches"] == [12] and r["frames_per_launch"] == 12, (d["frames_per_launch"], d["latency"])
+    assert d["latency"]["launches_in_flight"] == 1
     assert abs(r["avg_ms_per_frame"] * 12 - r["avg_launch_ms"]) < 1e-3 and r["one_frame_launch_ms"] > 0
     # a frame time beside the rate: the launch's duration is the age of its first frame; the launch size was chosen under the latency bound
     # (a 640x360 frame: thirty-two of them fit one 60-Hz refresh), every frame of the timed region a new view along the scripted walk
     # (both figures are rounded to four decimals in the line: the product of the rounded factor may be off by frames x 0.00005)
     assert abs(d["frame_latency_ms"] - d["frames_per_launch"] * d["ms_per_step"]) < d["frames_per_launch"] * 6e-5 + 1e-4
     assert d["latency"]["limit_ms"] == 16.7 and d["latency"]["chosen_by"] == "probe"
-    assert all(p_["launch_ms"] > 0 for p_ in d["latency"]["probes"]) and d["latency"]["probes"][-1]["frames"] == d["frames_per_launch"]
+    assert all(p_["launch_ms"] > 0 for p_ in d["latency"]["probes"]) and d["latency"]["probes"][-1]["frames"] == d["latency"]["frames_per_launch_limit"]
     assert d["latency"]["probes"][-1]["launch_ms"] <= 16.7 and "scripted walk" in d["config"]["camera"]
     assert d["one_frame_at_a_time"]["frame_latency_ms"] == d["one_frame_at_a_time"]["ms_per_step"] > 0
     assert "frac_useful" in r and "issue_cycles_per_inst_measured" in r
@@ -109,6 +111,9 @@ def test_bench_gpus_4_started_plainly_with_the_ranks_sharing_one_gpu(scene_cache
     assert r["nranks"] == 4 and r["nlocal"] == 4 and r["version"] == 99999 and "rtr_mgpu_create" in r["launch"]
     assert 0 < r["host_enqueue_ms_per_frame"] < 5 and 0 <= r["of_which_inside_rccl_calls"] <= r["host_enqueue_ms_per_frame"]
     assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0
-    assert d["frames_in_flight"] == 32 and d["frames_per_launch"] == 16 and d["timed_launches"] == [12, 12]
+    # N > 1 under the latency bound: two launches in flight, each allowed half the bound; a frame is two launches old when it lands
+    assert d["frames_in_flight"] == 32 and d["latency"]["frames_per_launch_limit"] == 16 and d["frames_per_launch"] == 12 and d["timed_launches"] == [12, 12]
+    assert d["latency"]["launches_in_flight"] == 2 and abs(d["frame_latency_ms"] - 2 * 12 * d["ms_per_step"]) < 2e-3
+    assert all(p_["launch_ms"] <= 16.7 / 2 for p_ in d["latency"]["probes"][-1:])
     assert "band-sharded x4" in d["config"]["workload"]
 

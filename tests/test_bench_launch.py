@@ -96,3 +96,16 @@ def test_frames_per_launch_under_a_latency_bound():
     moving, still = bench.CameraSource(S(), "path"), bench.CameraSource(S(), "static")
     assert moving.mode == "path" and moving.camera(5) == "view5" and moving.camera(bench.PATH_PERIOD + 5) == "view5" and moving.info(7) == (7, (7.0, 0.0, 0.0))
     assert moving.info(7, 3) == (3, (7.0, 0.0, 0.0)) and still.mode == "static" and still.camera(9) == "still" and still.info(9) == (9, None) and still.index(9) == 0
+
+
+def test_latency_is_reported_for_the_launches_that_were_timed():
+    """ADVICE r04 / VERDICT r04 weak-4: a frame's camera is fixed when its launch is enqueued, so it is (launches in flight) x (launch
+    duration) old when the launch ends.  One GPU keeps one launch enqueued; N > 1 keeps two and lets a single launch take half the bound.
+    The line's frames_per_launch / frame_latency_ms come from the launches the timed region made, not from the probe."""
+    import bench
+    assert bench.launches_in_flight(1, 8) == 1 and bench.launches_in_flight(8, 16) == 2 and bench.launches_in_flight(4, 1) == 1 and bench.launches_in_flight(2, 0) == 1
+    f = bench.latency_fields(8, 1, 20, 1.9, {"limit_ms": 16.7, "probes": [{"frames": 8, "launch_ms": 15.5}]})
+    assert f["timed_launches"] == [7, 7, 6] and f["frames_per_launch"] == 7 and abs(f["frame_latency_ms"] - 7 * 1.9) < 1e-9
+    assert f["latency"]["frames_per_launch_limit"] == 8 and f["latency"]["launches_in_flight"] == 1 and f["latency"]["limit_ms"] == 16.7 and f["latency"]["probes"]
+    g = bench.latency_fields(16, 2, 24, 0.3, {"limit_ms": 16.7})
+    assert g["timed_launches"] == [12, 12] and g["frames_per_launch"] == 12 and abs(g["frame_latency_ms"] - 2 * 12 * 0.3) < 1e-9 and g["latency"]["launches_in_flight"] == 2

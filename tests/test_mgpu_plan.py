@@ -123,6 +123,24 @@ def test_batch_plan_is_one_exchange_per_launch(n, nslots):
     PE.check_plans([PE.plan_batch(r, n, W, H, 1, band) for r in range(n)], W, H, band)
 
 
+@pytest.mark.parametrize("n", [2, 3, 8, 16])
+@pytest.mark.parametrize("nslots", [1, 3, 32])
+def test_group_per_slot_fallback_plan(n, nslots):
+    """RTR_MGPU_GROUP_PER_SLOT (flag, or RTR_MGPU_GROUP_PER_SLOT=1 at creation): the same launch with one RCCL group per slot — the
+    round-3 form, kept reachable should one group of (N - 1) x nslots receives ever be mis-ordered by a communicator.  Same transfers,
+    same offsets, same slot order per pair of ranks; only the group boundaries differ."""
+    W, H, band = 96, 52, 8
+    plans = [PE.plan_batch(r, n, W, H, nslots, band, flags=A.MGPU_GROUP_PER_SLOT) for r in range(n)]
+    PE.check_batch_plans(plans, W, H, nslots, band, group_per_slot=True)
+    one = [PE.plan_batch(r, n, W, H, nslots, band) for r in range(n)]
+    strip = lambda p: [o for o in p if o["kind"] not in (A.MGPU_OP_GROUP_START, A.MGPU_OP_GROUP_END)]
+    assert [strip(p) for p in plans] == [strip(p) for p in one]
+    assert max(len(p) for p in plans) <= A.MGPU_BATCH_PLAN_MAX_OPS
+    if nslots > 1:
+        with pytest.raises(AssertionError):
+            PE.check_batch_plans(plans, W, H, nslots, band)          # and the one-group checker does tell the two apart
+
+
 def test_batch_checker_catches_a_receive_outside_the_group_and_a_slot_order_mismatch():
     W, H, band, n, nslots = 96, 52, 8, 4, 3
     good = [PE.plan_batch(r, n, W, H, nslots, band) for r in range(n)]
