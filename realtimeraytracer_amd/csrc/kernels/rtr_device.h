@@ -44,6 +44,7 @@ struct DeviceScene {
     const float* ltc2;
     float skyLinear[3];
     uint32_t numLights;
+    uint32_t numLightTris;           /* light triangles of all the lights (records in lightTris) */
     const DeviceTexture* textures;   /* texSamplers[]: indexed by ObjectInfo.*Index (slots 0,1 unused: LTC) */
     DeviceTexture hdri;              /* pixels == null -> constant sky */
 };
@@ -551,6 +552,62 @@ __device__ __forceinline__ bool fetch_surface(const DeviceScene& sc, const Rende
     return true;
 }
 
+/* One area-light sample's BRDF * L / pdf (raygen.rgen:244-267) and the directional light's BRDF * L (raygen.rgen:316-336): the
+ * arithmetic of the light loops, as functions of what a sample needs of its surface point — so that the per-pixel loops (light_loops)
+ * and the compacted form of k_resolve_compact (one lane per VISIBLE sample, whichever pixel it belongs to) run the same operations in
+ * the same order.  currDiffuse = (om * color) / pi per channel, formed once per surface point. */
+__device__ __forceinline__ rtr_v3 surface_diffuse(float om, rtr_v3 color) {
+    return rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
+}
+__device__ __forceinline__ rtr_v3 area_sample_contrib(rtr_v3 hitNormal, rtr_v3 viewDir, float roughness, rtr_v3 mSpecular, rtr_v3 currDiffuse,
+                                                      rtr_v3 lcol, float lintensity, float pdf, rtr_v3 sampledLightDir, float lightDistance) {
+    const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir));
+    const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
+    const float Dg = GGX_Distribution(hitNormal, halfVector, roughness);
+    const float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
+                    GGX_PartialGeometryTerm(sampledLightDir, hitNormal, halfVector, roughness);
+    const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
+    const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 0.1f);
+    const float NdotL = rtr_max(rtr_dot(hitNormal, sampledLightDir), 0.1f);
+    /* the products in the order GLSL evaluates them, left to right (raygen.rgen:259-267): (D * F * G) / (4 NdotV NdotL),
+     * color * intensity * NdotL * attenuation * 10, BRDF * L / pdf */
+    const float den = 4.0f * NdotV * NdotL;
+    const rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
+    const float attenuation = 1.0f / (lightDistance * lightDistance);
+    const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
+    const rtr_v3 Lr = rtr_mk((((lcol.x * lintensity) * NdotL) * attenuation) * 10.0f, (((lcol.y * lintensity) * NdotL) * attenuation) * 10.0f,
+                             (((lcol.z * lintensity) * NdotL) * attenuation) * 10.0f);
+    return rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf);
+}
+__device__ __forceinline__ rtr_v3 directional_light_dir() { return rtr_normalize(rtr_mk(-1.0f, 1.0f, -0.5f)); }      /* raygen.rgen:289 */
+__device__ __forceinline__ rtr_v3 directional_contrib(rtr_v3 hitNormal, rtr_v3 viewDir, float roughness, rtr_v3 mSpecular, rtr_v3 currDiffuse) {
+    const rtr_v3 directLightDir = directional_light_dir();
+    const rtr_v3 directLightColor = rtr_mk(1.0f, 1.0f, 0.5f);
+    const float directLightIntensity = 0.2f;
+    const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, directLightDir));
+    const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
+    const float Dg = GGX_Distribution(hitNormal, halfVector, roughness);
+    const float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
+                    GGX_PartialGeometryTerm(directLightDir, hitNormal, halfVector, roughness);
+    const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
+    const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 5.0f);
+    const float NdotL = rtr_max(rtr_dot(hitNormal, directLightDir), 0.0001f);
+    const float den = 4.0f * NdotV * NdotL;
+    const rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
+    const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
+    /* directLightColor * directLightIntensity * NdotL * 20, left to right (raygen.rgen:334) */
+    const rtr_v3 Lr = rtr_mk(((directLightColor.x * directLightIntensity) * NdotL) * 20.0f, ((directLightColor.y * directLightIntensity) * NdotL) * 20.0f,
+                             ((directLightColor.z * directLightIntensity) * NdotL) * 20.0f);
+    return rtr_mul(BRDF, Lr);
+}
+/* the point on light triangle P the sample s of pixel (px, py) of frame `frame` aims at (raygen.rgen:206-215) */
+__device__ __forceinline__ rtr_v3 light_sample_pos(const rtr_v3* P, uint32_t s, uint32_t px, uint32_t py, uint32_t frame) {
+    const uint32_t seed = s + px * 733u + py * 1933u + frame;
+    float r1 = rtr_random(seed), r2 = rtr_random(seed + 100u);
+    if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }
+    return rtr_madd(rtr_madd(P[0], rtr_sub(P[1], P[0]), r1), rtr_sub(P[2], P[0]), r2);
+}
+
 /* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax, rawDir) (rawDir: dir before normalisation, only its signs are meaningful) answers the
  * shadow query; Policy::kShade == false (counting / emitting the queries) skips the BRDF arithmetic but keeps the exact
  * sequence of queries. */
@@ -567,6 +624,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
     const float roughness = sf.roughness, om = sf.om;
     const float4 t1 = sf.t1, t2 = sf.t2;
     const rtr_v3 shadowOrigin = rtr_madd(hitPoint, hitNormal, 0.01f);
+    const rtr_v3 currDiffuse = surface_diffuse(om, color);
 
     for (uint32_t li = 0; li < ra.info.numAreaLights; ++li) {                             /* :165 */
         const RtrAreaLightInfo* L = sc.lights + li;
@@ -590,34 +648,14 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
             }
             rtr_v3 shadowedSample = rtr_mk(0, 0, 0), unshadowedSample = rtr_mk(0, 0, 0);
             for (uint32_t s = 0; s < ra.numShadowRays; ++s) {                             /* :206 */
-                const uint32_t seed = s + px * 733u + py * 1933u + ra.info.frame;
-                float r1 = rtr_random(seed), r2 = rtr_random(seed + 100u);
-                if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }
-                const rtr_v3 lightSamplePos = rtr_madd(rtr_madd(P[0], rtr_sub(P[1], P[0]), r1), rtr_sub(P[2], P[0]), r2);
+                const rtr_v3 lightSamplePos = light_sample_pos(P, s, px, py, ra.info.frame);
                 const rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
                 const rtr_v3 sampledLightDir = rtr_normalize(lightVec);
                 const float lightDistance = rtr_length(lightVec);
                 const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f, lightVec);
                 if (Policy::kShade && (wantUnshadowed || !occ)) {
                     const float currShadow = occ ? 0.0f : 1.0f;
-                    const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, sampledLightDir));
-                    const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
-                    const float Dg = GGX_Distribution(hitNormal, halfVector, roughness);
-                    const float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
-                                    GGX_PartialGeometryTerm(sampledLightDir, hitNormal, halfVector, roughness);
-                    const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
-                    const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 0.1f);
-                    const float NdotL = rtr_max(rtr_dot(hitNormal, sampledLightDir), 0.1f);
-                    /* the products in the order GLSL evaluates them, left to right (raygen.rgen:259-267): (D * F * G) / (4 NdotV NdotL),
-                     * color * intensity * NdotL * attenuation * 10, BRDF * L / pdf */
-                    const float den = 4.0f * NdotV * NdotL;
-                    const rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
-                    const rtr_v3 currDiffuse = rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
-                    const float attenuation = 1.0f / (lightDistance * lightDistance);
-                    const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
-                    const rtr_v3 Lr = rtr_mk((((lcol.x * lintensity) * NdotL) * attenuation) * 10.0f, (((lcol.y * lintensity) * NdotL) * attenuation) * 10.0f,
-                                             (((lcol.z * lintensity) * NdotL) * attenuation) * 10.0f);
-                    const rtr_v3 contrib = rtr_mk((BRDF.x * Lr.x) / pdf, (BRDF.y * Lr.y) / pdf, (BRDF.z * Lr.z) / pdf);
+                    const rtr_v3 contrib = area_sample_contrib(hitNormal, viewDir, roughness, mSpecular, currDiffuse, lcol, lintensity, pdf, sampledLightDir, lightDistance);
                     shadowedSample = rtr_madd(shadowedSample, contrib, currShadow);
                     unshadowedSample = rtr_add(unshadowedSample, contrib);
                 }
@@ -643,29 +681,12 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
         }
     }
     /* directional light, raygen.rgen:289-338 */
-    const rtr_v3 directLightDir = rtr_normalize(rtr_mk(-1.0f, 1.0f, -0.5f));
+    const rtr_v3 directLightDir = directional_light_dir();
     if (rtr_dot(hitNormal, directLightDir) <= 0.0f) return;
     const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f, directLightDir);
     if (Policy::kShade && (wantUnshadowed || wantAnalytic || !occ)) {
-        const rtr_v3 directLightColor = rtr_mk(1.0f, 1.0f, 0.5f);
-        const float directLightIntensity = 0.2f;
         const float currShadow = occ ? 0.0f : 1.0f;
-        const rtr_v3 halfVector = rtr_normalize(rtr_add(viewDir, directLightDir));
-        const float cosTheta = rtr_clamp(rtr_dot(viewDir, halfVector), 0.0f, 1.0f);
-        const float Dg = GGX_Distribution(hitNormal, halfVector, roughness);
-        const float G = GGX_PartialGeometryTerm(viewDir, hitNormal, halfVector, roughness) *
-                        GGX_PartialGeometryTerm(directLightDir, hitNormal, halfVector, roughness);
-        const rtr_v3 F = Fresnel_Schlick(cosTheta, mSpecular);
-        const float NdotV = rtr_max(rtr_dot(hitNormal, viewDir), 5.0f);
-        const float NdotL = rtr_max(rtr_dot(hitNormal, directLightDir), 0.0001f);
-        const float den = 4.0f * NdotV * NdotL;
-        const rtr_v3 currSpecular = rtr_mk(((Dg * F.x) * G) / den, ((Dg * F.y) * G) / den, ((Dg * F.z) * G) / den);
-        const rtr_v3 currDiffuse = rtr_mk((om * color.x) / RTR_PI_F, (om * color.y) / RTR_PI_F, (om * color.z) / RTR_PI_F);
-        const rtr_v3 BRDF = rtr_add(currSpecular, currDiffuse);
-        /* directLightColor * directLightIntensity * NdotL * 20, left to right (raygen.rgen:334) */
-        const rtr_v3 Lr = rtr_mk(((directLightColor.x * directLightIntensity) * NdotL) * 20.0f, ((directLightColor.y * directLightIntensity) * NdotL) * 20.0f,
-                                 ((directLightColor.z * directLightIntensity) * NdotL) * 20.0f);
-        const rtr_v3 contrib = rtr_mul(BRDF, Lr);
+        const rtr_v3 contrib = directional_contrib(hitNormal, viewDir, roughness, mSpecular, currDiffuse);
         o.shadowed = rtr_madd(o.shadowed, contrib, currShadow);
         o.unshadowed = rtr_add(o.unshadowed, contrib);
         o.analytic = rtr_add(o.analytic, contrib);

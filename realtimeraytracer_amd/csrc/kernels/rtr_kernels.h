@@ -85,6 +85,7 @@ struct Tunables {
     uint32_t trace_octant_forms = 1;
     uint32_t trace_top_nodes = 0xffffffffu;       /* 4-wide records kept in LDS (at most the kernel's kTopNodes) */
     uint32_t resolve_row_waves = 0;
+    uint32_t resolve_compact = 1;                 /* framebuffer-only launches: 1 = k_resolve_compact (the BRDF of the VISIBLE samples of a tile, compacted over the wave's lanes), 0 = k_resolve (one lane per pixel walks its samples) */
     uint32_t split_priorities = 0;                /* rtr_render_split: part k's stream gets the k-th highest stream priority (0, the default: all parts default priority — priorities bought nothing, profiles/r04/sweep_split_priorities.log) */
 };
 Tunables tunables_from_env();

@@ -107,10 +107,31 @@ struct EmitPolicy {
     }
 };
 
+/* The visibility bytes of a pixel-sample's first 32 queries as one mask, fetched TOGETHER (bit j = query j is occluded): read one
+ * by one where the light loops ask for them, every byte is a dependent load the wave waits out before it can branch — thirteen
+ * memory latencies in a row on the bench frame.  Slots a pixel-sample does not use hold the pre-fill; nobody asks for them. */
+__device__ __forceinline__ uint32_t vis_mask32(const uint8_t* __restrict__ vis, uint32_t slot, uint32_t slotStride, uint32_t queries) {
+    uint32_t m = 0;
+    const uint32_t n = queries < 32u ? queries : 32u;
+    for (uint32_t j0 = 0; j0 < n; j0 += 8u) {
+        uint32_t b[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) { const uint32_t jj = j0 + j < n ? j0 + j : n - 1u; b[j] = vis[slot + jj * slotStride]; }      /* eight loads in flight */
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) m |= (b[j] != 0u && j0 + j < n ? 1u : 0u) << (j0 + j);
+    }
+    return m;
+}
+
 struct LookupPolicy {
     static constexpr bool kShade = true;
     const uint8_t* vis; uint32_t slot, slotStride;
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { const bool occ = vis[slot] != 0; slot += slotStride; return occ; }
+    uint32_t mask, j;                        /* vis_mask32 of this pixel-sample; queries answered so far */
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) {
+        const bool occ = j < 32u ? ((mask >> j) & 1u) != 0u : vis[slot] != 0;
+        slot += slotStride; ++j;
+        return occ;
+    }
 };
 
 /* The same two phases with the queue binned by direction octant (k_shadow_gen_oct): a workgroup's chunk of the queue is laid
@@ -1457,12 +1478,198 @@ __global__ __launch_bounds__(kBlock) RTR_RESOLVE_ATTR void k_resolve(DeviceScene
         const float4 r = hitTuvp[k];
         HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
         const rtr_v3 dir = primary_dir(ra, px, py, i);
-        LookupPolicy pol{vis, (uint32_t)k, slotStride};
+        LookupPolicy pol{vis, (uint32_t)k, slotStride, vis_mask32(vis, (uint32_t)k, slotStride, ra.maxRaysPerSample), 0u};
         shade_sample<LookupPolicy, STATS>(sc, ra, px, py, h, dir, want, acc, pol, st);
     }
     if (FULL) write_pixel(ra, fo, out_index(ra, px, lrow, py), acc);
     else write_pixel_framebuffer(ra, fo, out_index(ra, px, lrow, py), acc.shadowed);
     if (STATS) st.flush(stats);
+}
+
+/* ---- wavefront stage 4, compacted form: the BRDF only for the VISIBLE samples, dealt out densely over the wave's lanes ------------
+ * k_resolve walks, lane = pixel, the light loops of raygen.rgen:165-338 and evaluates a sample's BRDF when its shadow ray was not
+ * occluded.  Three shadow rays in four ARE occluded, and which ones differs from pixel to pixel (every pixel aims at its own random
+ * points of the light): at nearly every step SOME lane of the wave has a visible sample, so the wave issues the ~200-instruction BRDF
+ * at nearly every step for a fifth of its lanes (measured lane use 0.53, a quarter of it IEEE divisions).  Here a wave (one 8x8 tile)
+ *   1. fetches its 64 surfaces as before and parks what a sample needs of them in LDS (16 floats per pixel);
+ *   2. BUILD: walks the light loops without any arithmetic but the back-face test, reads each query's visibility byte and appends
+ *      every VISIBLE query as one work item {pixel lane, light, light triangle, sample} to a list in LDS — ballot + mbcnt, the same
+ *      wavefront-ballot compaction the ray queue is made with;
+ *   3. EVALUATE: the list is dealt out 64 items at a time: a lane takes ANY pixel's sample — the surface from LDS, the light
+ *      triangle from its record, the sample point from the PCG seed of that pixel — and leaves BRDF * L / pdf in LDS;
+ *   4. CONSUME: each pixel's lane walks the same steps again and adds its samples' contributions in the reference's order
+ *      (samples of a light triangle in order, / numShadowRays, then the triangle's sum onto the pixel's: raygen.rgen:268-285).
+ * The arithmetic of a sample is the same function of the same operands (area_sample_contrib / directional_contrib,
+ * light_sample_pos) and the sums are formed in the same order, so the image is the one k_resolve writes, bit for bit (tests: both
+ * forms against the oracle).  A round holds at most CAP items and 32 steps; longer light lists take more rounds.  Only the
+ * framebuffer-only launch has this form: with the unshadowed image asked for every sample's BRDF is an output and nothing is sparse. */
+#ifndef RTR_RESOLVE_CAP
+#define RTR_RESOLVE_CAP 192
+#endif
+#ifndef RTR_RESOLVE_COMPACT_WAVES
+#define RTR_RESOLVE_COMPACT_WAVES 5
+#endif
+constexpr uint32_t kResolveCap = RTR_RESOLVE_CAP;        /* work items a wave collects before it evaluates them: a multiple of 64, at least 128 */
+static_assert(kResolveCap % 64 == 0 && kResolveCap >= 128 && kResolveCap <= 1024, "RTR_RESOLVE_CAP");
+constexpr uint32_t kResolveMaxLights = 255u, kResolveMaxLightTris = 4094u, kResolveMaxSamples = 63u;      /* what a 32-bit work item can name */
+constexpr uint32_t kItemDirectional = 0xfffu;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    /* LDS traffic of ONE wave: its ds instructions execute in order, so a lane sees what another lane of the wave wrote by an earlier
+     * instruction; all that is needed is that the compiler keeps the order */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTR_RESOLVE_COMPACT_WAVES, 8)))
+void k_resolve_compact(DeviceScene sc, FrameBatch fb, uint32_t planeStride, const float4* __restrict__ hitTuvp, const uint32_t* __restrict__ hitCustom,
+                       const uint8_t* __restrict__ vis, uint32_t slotStride) {
+    constexpr uint32_t kWaves = kBlock / 64;
+    __shared__ float4 s_surf[kWaves][4][64];             /* per pixel of the tile: {hitPoint, roughness} {hitNormal, cd.x} {viewDir, cd.y} {mSpecular, cd.z} */
+    __shared__ uint32_t s_item[kWaves][kResolveCap];     /* lane | sample << 6 | light triangle << 12 | light << 24 */
+    __shared__ float s_con[kWaves][3][kResolveCap];      /* an item's BRDF * L / pdf */
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t frame = batch_frame(q, planeStride, q);
+    if (frame >= fb.n) return;                           /* wave-uniform */
+    const RenderArgs& ra = fb.ra[frame];
+    const FrameOut& fo = fb.fo[frame];
+    uint32_t px, lrow, py;
+    const bool valid = pixel_of(ra, q, px, lrow, py);
+    if (__ballot(valid) == 0ull) return;                 /* a tile of padding */
+    /* a wave is one 8x8 tile and bandRows is a multiple of 8: the pixel of lane l is (pxBase + (l & 7), pyBase + (l >> 3)) */
+    const uint32_t pxBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(px - (lane & 7u))), pyBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(py - (lane >> 3)));
+    const uint32_t ns = ra.numShadowRays;
+    const float nsf = (float)ns;
+    const rtr_v3 directLightDir = directional_light_dir();
+    LocalStats st;
+    Accum acc = zero_accum();
+    for (uint32_t i = 0; i < ra.spp; ++i) {
+        const size_t k = ((size_t)frame * ra.spp + i) * planeStride + q;
+        bool has = false;
+        Surface sf;
+        sf.hitPoint = sf.hitNormal = rtr_mk(0, 0, 0);
+        if (valid) {
+            const float4 r = hitTuvp[k];
+            HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
+            has = fetch_surface<true, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);      /* a miss / a light adds its colour to acc.shadowed, as in k_resolve */
+        }
+        wave_lds_sync();                                 /* the last sample's evaluation has read the surfaces */
+        if (has) {
+            const rtr_v3 cd = surface_diffuse(sf.om, sf.color);
+            s_surf[wave][0][lane] = make_float4(sf.hitPoint.x, sf.hitPoint.y, sf.hitPoint.z, sf.roughness);
+            s_surf[wave][1][lane] = make_float4(sf.hitNormal.x, sf.hitNormal.y, sf.hitNormal.z, cd.x);
+            s_surf[wave][2][lane] = make_float4(sf.viewDir.x, sf.viewDir.y, sf.viewDir.z, cd.y);
+            s_surf[wave][3][lane] = make_float4(sf.mSpecular.x, sf.mSpecular.y, sf.mSpecular.z, cd.z);
+        }
+        const rtr_v3 hitPoint = sf.hitPoint, hitNormal = sf.hitNormal;
+        uint32_t qdone = 0;                              /* queries this pixel-sample has issued so far: its next visibility byte is plane qdone (LookupPolicy) */
+        rtr_v3 shadowedSample = rtr_mk(0, 0, 0);         /* of the light triangle being summed; lives across rounds */
+        uint32_t e0 = 0, total = 0;                      /* steps [0, e0) are done; total: steps of a pixel-sample (set by the first walk) */
+        do {
+            /* ---- build: steps [e0, e1) ---- */
+            uint32_t count = 0, e = 0, e1 = e0;          /* wave-uniform */
+            uint32_t vmask = 0, imask = 0;               /* per lane: bit (step - e0) = the query is visible / was issued */
+            bool full = false;
+            /* a round takes at most 32 steps, so a lane issues at most 32 queries in it: their visibility bytes, fetched together */
+            const uint32_t occ = has ? vis_mask32(vis, (uint32_t)k + qdone * slotStride, slotStride, ra.maxRaysPerSample - qdone) : 0xffffffffu;
+            uint32_t nq = 0;                             /* queries this lane issued in this round */
+            for (uint32_t li = 0; li < ra.info.numAreaLights; ++li) {
+                const RtrAreaLightInfo* L = sc.lights + li;
+                const uint32_t lnt = L->numTriangles, first = sc.lightTriFirst[li];
+                const bool twoSided = L->isTwoSided != 0u;
+                for (uint32_t ti = 0; ti < lnt; ++ti) {
+                    if (full || e + ns <= e0) { e += ns; continue; }
+                    const float4* rec = sc.lightTris + (size_t)(first + ti) * kLightTriRecord;
+                    const float4 r0 = rec[0], r3 = rec[3];
+                    const bool culled = !twoSided && rtr_dot(rtr_mk(r3.x, r3.y, r3.z), rtr_sub(hitPoint, rtr_mk(r0.x, r0.y, r0.z))) < 0.0f;
+                    const bool issued = has && !culled;
+                    for (uint32_t s = 0; s < ns; ++s, ++e) {
+                        if (e < e0 || full) continue;
+                        bool v = false;
+                        if (issued) { v = ((occ >> nq) & 1u) == 0u; ++nq; }
+                        const unsigned long long m = __ballot(v);
+                        if (v) s_item[wave][count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = lane | (s << 6) | ((first + ti) << 12) | (li << 24);
+                        const uint32_t bit = e - e0;
+                        vmask |= (v ? 1u : 0u) << bit; imask |= (issued ? 1u : 0u) << bit;
+                        count += (uint32_t)__popcll(m);
+                        e1 = e + 1u;
+                        full = count + 64u > kResolveCap || e1 - e0 == 32u;
+                    }
+                }
+            }
+            if (!full && e >= e0) {                      /* the directional light: the last step */
+                const bool issued = has && rtr_dot(hitNormal, directLightDir) > 0.0f;
+                bool v = false;
+                if (issued) { v = ((occ >> nq) & 1u) == 0u; ++nq; }
+                const unsigned long long m = __ballot(v);
+                if (v) s_item[wave][count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = lane | (kItemDirectional << 12);
+                const uint32_t bit = e - e0;
+                vmask |= (v ? 1u : 0u) << bit; imask |= (issued ? 1u : 0u) << bit;
+                count += (uint32_t)__popcll(m);
+                e1 = e + 1u;
+            }
+            total = e + 1u;
+            qdone += nq;
+            wave_lds_sync();
+            /* ---- evaluate: any lane, any pixel's sample ---- */
+            for (uint32_t c = lane; c < count; c += 64u) {
+                const uint32_t item = s_item[wave][c];
+                const uint32_t src = item & 63u, s = (item >> 6) & 63u, tri = (item >> 12) & 0xfffu, li = item >> 24;
+                const float4 a0 = s_surf[wave][0][src], a1 = s_surf[wave][1][src], a2 = s_surf[wave][2][src], a3 = s_surf[wave][3][src];
+                const rtr_v3 hp = rtr_mk(a0.x, a0.y, a0.z), hn = rtr_mk(a1.x, a1.y, a1.z), vd = rtr_mk(a2.x, a2.y, a2.z), ms = rtr_mk(a3.x, a3.y, a3.z), cd = rtr_mk(a1.w, a2.w, a3.w);
+                rtr_v3 con;
+                if (tri == kItemDirectional) con = directional_contrib(hn, vd, a0.w, ms, cd);
+                else {
+                    const float4* rec = sc.lightTris + (size_t)tri * kLightTriRecord;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    rtr_v3 P[3];
+                    P[0] = rtr_mk(r0.x, r0.y, r0.z); P[1] = rtr_mk(r1.x, r1.y, r1.z); P[2] = rtr_mk(r2.x, r2.y, r2.z);
+                    const RtrAreaLightInfo* L = sc.lights + li;
+                    const rtr_v3 lightVec = rtr_sub(light_sample_pos(P, s, pxBase + (src & 7u), pyBase + (src >> 3), ra.info.frame), hp);
+                    con = area_sample_contrib(hn, vd, a0.w, ms, cd, rtr_ld3(L->color), L->intensity, r1.w, rtr_normalize(lightVec), rtr_length(lightVec));
+                }
+                s_con[wave][0][c] = con.x; s_con[wave][1][c] = con.y; s_con[wave][2][c] = con.z;
+            }
+            wave_lds_sync();
+            /* ---- consume: each pixel's lane adds its samples in the reference's order ---- */
+            uint32_t base = 0;
+            e = 0;
+            for (uint32_t li = 0; li < ra.info.numAreaLights; ++li) {
+                const uint32_t lnt = sc.lights[li].numTriangles;
+                for (uint32_t ti = 0; ti < lnt; ++ti) {
+                    if (e >= e1 || e + ns <= e0) { e += ns; continue; }
+                    for (uint32_t s = 0; s < ns; ++s, ++e) {
+                        if (e < e0 || e >= e1) continue;
+                        const uint32_t bit = e - e0;
+                        const bool v = ((vmask >> bit) & 1u) != 0u;
+                        const unsigned long long m = __ballot(v);
+                        if (v) {
+                            const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            shadowedSample = rtr_madd(shadowedSample, rtr_mk(s_con[wave][0][at], s_con[wave][1][at], s_con[wave][2][at]), 1.0f);
+                        }
+                        base += (uint32_t)__popcll(m);
+                        if (s + 1u == ns) {              /* raygen.rgen:268-285: the triangle's sum / numShadowRays onto the pixel's */
+                            if ((imask >> bit) & 1u) acc.shadowed = rtr_add(acc.shadowed, rtr_mk(shadowedSample.x / nsf, shadowedSample.y / nsf, shadowedSample.z / nsf));
+                            shadowedSample = rtr_mk(0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (e >= e0 && e < e1) {
+                const uint32_t bit = e - e0;
+                const bool v = ((vmask >> bit) & 1u) != 0u;
+                const unsigned long long m = __ballot(v);
+                if (v) {
+                    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    acc.shadowed = rtr_madd(acc.shadowed, rtr_mk(s_con[wave][0][at], s_con[wave][1][at], s_con[wave][2][at]), 1.0f);
+                }
+            }
+            e0 = e1;
+        } while (e0 < total);
+    }
+    if (valid) write_pixel_framebuffer(ra, fo, out_index(ra, px, lrow, py), acc.shadowed);
 }
 
 /* ---- rank-0 de-interleave after the RCCL gather ------------------------------------------------ */
@@ -1511,7 +1718,7 @@ const TunableField kTunables[] = {
     {"trace_bvh4", &Tunables::trace_bvh4, 0u, 1u}, {"trace_batch", &Tunables::trace_batch, 0u, 1u << 20}, {"trace_binned", &Tunables::trace_binned, 0u, 2u},
     {"queue_nt", &Tunables::queue_nt, 0u, 3u}, {"trace_wgs_per_cu", &Tunables::trace_wgs_per_cu, 0u, 8u}, {"trace_refill", &Tunables::trace_refill, 1u, 64u},
     {"trace_inner_min", &Tunables::trace_inner_min, 0u, 63u}, {"trace_octant_forms", &Tunables::trace_octant_forms, 0u, 1u},
-    {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u}, {"split_priorities", &Tunables::split_priorities, 0u, 1u},
+    {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u}, {"resolve_compact", &Tunables::resolve_compact, 0u, 1u}, {"split_priorities", &Tunables::split_priorities, 0u, 1u},
 };
 }  // namespace
 
@@ -1679,7 +1886,12 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     const uint32_t rowWaves = (kRowWaves && ra.tilesPerRow % 8u == 0u && blocks % 2u == 0u) ? 1u : 0u;
     /* every frame of a launch has the same image set (params.images): framebuffer-only launches take the trimmed form */
     const bool full = (ra.images & ~((1u << 1) | (1u << 16))) != 0u;          /* anything beside RTR_IMAGE_SHADOWED (1) and RTR_IMAGE_HDR (16) */
-    if (stats) {
+    /* framebuffer only, timed form: the BRDF of the visible samples compacted over the wave (k_resolve_compact); the counting form stays
+     * the per-pixel walk (its counters are the light loops') */
+    const bool compact = !stats && !full && tun.resolve_compact && !rowWaves && ra.numShadowRays >= 1u && ra.numShadowRays <= kResolveMaxSamples &&
+                         sc.numLights <= kResolveMaxLights && sc.numLightTris <= kResolveMaxLightTris;
+    if (compact) hipLaunchKernelGGL(k_resolve_compact, dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride);
+    else if (stats) {
         if (full) hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
         else hipLaunchKernelGGL((k_resolve<true, false>), dim3(blocks * nb), dim3(kBlock), 0, s, sc, fb, blocks * kBlock, ws.hitTuvp, ws.hitCustom, ws.vis, ws.rayQueue.slotStride, stats, rowWaves);
     } else {

@@ -675,6 +675,8 @@ static int scene_create_impl(rtr_ctx* ctx, const rtr_scene_desc* d, const rtr_sc
     dv.ltc1 = s->hasLtc ? s->ltc1.p : nullptr; dv.ltc2 = s->hasLtc ? s->ltc2.p : nullptr;
     for (int k = 0; k < 3; ++k) dv.skyLinear[k] = rtr_to_linear(d->skyColor[k]);
     dv.numLights = d->numLights;
+    dv.numLightTris = 0;
+    for (uint32_t l = 0; l < d->numLights; ++l) dv.numLightTris += d->lights[l].numTriangles;
     dv.textures = s->texTable.p;
     dv.hdri = hdri;
     *out = s;

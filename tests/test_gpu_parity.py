@@ -1039,6 +1039,39 @@ def test_split_render_1080p_against_the_unsplit_frame(gpu_ctx, scene_cache):
         o.close()
 
 
+@pytest.mark.parametrize("case", ["cornell_s1", "cornell_s3_spp3", "cornell_s20", "cornell_s40", "sponza_class", "sponza_mixed", "textured_room"])
+def test_resolve_compact_and_per_pixel_forms_match_the_oracle(gpu_ctx, oracle, scene_cache, case):
+    """k_resolve_compact (the framebuffer-only launch's default: the BRDF of a tile's VISIBLE samples dealt out densely over the wave's
+    lanes, sums in the reference's order) and k_resolve (one lane per pixel walks its samples) against the oracle, framebuffer bytes and
+    HDR bits, over two accumulated frames: 1 / 3 shadow rays per light triangle, several samples per pixel, light lists longer than a
+    round's 32 steps (20 rays x 2 triangles + 1) and than its item list (40 rays: 81 steps), textures / alpha / HDRI sky."""
+    W, H = 200, 120
+    setup, spp, ns = {"cornell_s1": (scenes.cornell_box, 1, 1), "cornell_s3_spp3": (scenes.cornell_box, 3, 3), "cornell_s20": (scenes.cornell_box, 1, 20),
+                      "cornell_s40": (scenes.cornell_box, 2, 40), "sponza_class": (scenes.sponza_class, 1, 3), "sponza_mixed": (scenes.sponza_mixed, 1, 3),
+                      "textured_room": (scenes.textured_room, 2, 3)}[case]
+    s = setup(W, H)
+    imgs = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_HDR)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    c = api.Context(0)
+    try:
+        for compact in (1, 0):
+            c.set_tunable("resolve_compact", compact)
+            frame = api.Frame(c, W, H, imgs)
+            hdr = np.zeros((H, W, 4), np.float32)
+            ref = None
+            for f in range(2):
+                p = api.make_params(W, H, spp=spp, shadow_rays=ns, images=imgs, accumulate=1, accumulated_frames=f, pipeline=2)
+                api.render(scene, s.camera, s.scene_info(f), p, frame)
+                ref = oracle.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, images=imgs, hdr=hdr, threads=8)
+            assert np.array_equal(frame.download(A.IMAGE_HDR).view(np.uint32), hdr.view(np.uint32)), f"{case}: HDR bits, resolve_compact={compact}"
+            _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"{case}: framebuffer, resolve_compact={compact}")
+            frame.close()
+    finally:
+        c.close()
+        scene.close()
+
+
 @pytest.mark.gpu
 def test_tunables_belong_to_the_context_and_change_no_pixel(gpu_ctx, scene_cache):
     """rtr_ctx_set_tunable / rtr_ctx_get_tunable: scheduling knobs of the staged pipeline are read from the environment when a
@@ -1058,7 +1091,7 @@ def test_tunables_belong_to_the_context_and_change_no_pixel(gpu_ctx, scene_cache
     assert c.get_tunable("trace_refill") == 33 and gpu_ctx.get_tunable("trace_refill") == 20
     fr = api.Frame(c, W, H)
     for name, value in (("trace_binned", 1), ("trace_batch", 64), ("trace_wgs_per_cu", 3), ("trace_inner_min", 5), ("trace_octant_forms", 0),
-                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("primary_packet", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
+                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("resolve_compact", 0), ("primary_packet", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
         c.set_tunable(name, value)
         assert c.get_tunable(name) == value
         api.render(scene, s.camera, s.scene_info(0), p, fr)
