@@ -208,6 +208,42 @@ def build_setup(args, scenes, np):
     return getattr(scenes, WORKLOADS[args.workload])(W, H)
 
 
+FIRST_EXCHANGE_TIMEOUT_MS = 60000        # watchdog of the verified first exchange (RTR_MGPU_TIMEOUT_MS, if set, wins)
+
+
+def start_line(what, **kw):
+    """One line on stderr about how an N > 1 run starts (stdout carries the ONE JSON line): the first contact with real RCCL must not
+    be a silent hang or an anonymous traceback in the driver's log."""
+    print("bench.py: N>1 start: " + what + " | " + " ".join(f"{k}={v}" for k, v in kw.items()), file=sys.stderr, flush=True)
+
+
+def start_failure(args, stage, why, rccl=None, code=3):
+    """The run cannot start: the diagnostic on stderr AND as the JSON line on stdout (value null), then a non-zero exit."""
+    start_line(f"FAILED at {stage}", why=why)
+    print(json.dumps({"metric": "Mrays/sec", "value": None, "unit": "Mrays/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                      "error": {"stage": stage, "why": str(why)}, "rccl": rccl}), flush=True)
+    raise SystemExit(code)
+
+
+def first_exchange(mg, A, render_whole, camera, info, p_shards, n_frames_acc=1):
+    """The FIRST launch of an N > 1 run is a verified one: one frame through every rank's render, the grouped exchange and the
+    de-interleave, joined under a watchdog, and compared with rank 0's unsharded render of the same camera.  Returns
+    (pixels differing, milliseconds) — raises RuntimeError when the library reports a failure or the watchdog fires."""
+    import ctypes as C
+    if "RTR_MGPU_TIMEOUT_MS" not in os.environ:
+        A.mgpu_lib().rtr_mgpu_set_timeout_ms(mg.h, FIRST_EXCHANGE_TIMEOUT_MS)
+    t = time.perf_counter()
+    for j, p in enumerate(p_shards):
+        mg.render_async(0, camera, info(j), p, exchange=(j == len(p_shards) - 1))
+    mg.wait(0)
+    ms = (time.perf_counter() - t) * 1e3
+    if "RTR_MGPU_TIMEOUT_MS" not in os.environ:
+        A.mgpu_lib().rtr_mgpu_set_timeout_ms(mg.h, 120000)
+    want = render_whole()
+    got = mg.download(0) if want is not None else None
+    return (int((got != want).sum()) if want is not None else None), ms
+
+
 def run_inproc(args, K, plan):
     """N > 1 from ONE process: what a C++ application would do with include/rtr_mgpu.h.  rtr_mgpu_create makes the communicator
     (ncclCommInitAll) and a host thread per rank; every step enqueues the frame's N shards, the grouped send / recv to rank 0 on the
@@ -223,13 +259,20 @@ def run_inproc(args, K, plan):
     os.environ.setdefault("RTR_SCENE_CACHE", os.path.join("/tmp", "rtr_scene_cache_rank0"))
     nbuf = plan["frames_in_flight"]
     # the library says what is wrong when the devices are not there ("8 devices requested, 1 present"): no check of our own before it
+    start_line("one process drives the ranks (rtr_mgpu_create: ncclCommInitAll, a host thread per rank)", asked=N, devices_present=torch.cuda.device_count(),
+               devices=plan["devices"], shared_device=bool(plan.get("shared_device")))
     try:
         mg = mgpu.MultiGpu(devices=plan["devices"], frames_in_flight=nbuf)
     except RuntimeError as e:
-        raise SystemExit(f"bench.py: {e}")
+        start_failure(args, "rtr_mgpu_create (ncclCommInitAll)", e)
+    rccl0 = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion)}
+    start_line("communicator up", rccl_version=rccl0["version"], nranks=rccl0["nranks"], nlocal=rccl0["nlocal"], group_per_slot=os.environ.get("RTR_MGPU_GROUP_PER_SLOT", "0"))
     setup = build_setup(args, scenes, np)
     cams = CameraSource(setup, args.camera)
-    mg.scene_create(setup.desc)
+    try:
+        mg.scene_create(setup.desc)
+    except RuntimeError as e:
+        start_failure(args, "rtr_mgpu_scene_create", e, rccl0)
     images = A.IMAGES_FRAMEBUFFER | (A.IMG_BIT(A.IMAGE_HDR) if K > 1 else 0)
 
     def params(collect=0, shard_index=0, shard_count=1, j=0):
@@ -254,6 +297,20 @@ def run_inproc(args, K, plan):
     p_run = [params(0, j=j) for j in range(K)]
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
     inflight = [False] * nbuf
+
+    # the first launch: verified — before anything is timed, probed or warmed up
+    def whole_of_first():
+        for j in range(K):
+            api.render(scene, cams.camera(0), cams.info(0, j if K > 1 else None), params(0, j=j), whole)
+        return whole.download()
+    try:
+        first_bad, first_ms = first_exchange(mg, A, whole_of_first, cams.camera(0), lambda j: cams.info(0, j if K > 1 else None), p_run)
+    except RuntimeError as e:
+        start_failure(args, "first grouped exchange (ncclGroupStart ... ncclGroupEnd, k_deinterleave)", e, rccl0)
+    rccl0.update(first_exchange_verified=(first_bad == 0), first_exchange_pixels_differing=first_bad, first_exchange_ms=round(first_ms, 2))
+    start_line("first exchange " + ("verified" if first_bad == 0 else "WRONG"), pixels_differing=first_bad, ms=round(first_ms, 1))
+    if first_bad != 0:
+        start_failure(args, "first exchange verification", f"the assembled frame differs from rank 0's unsharded render in {first_bad} pixels", rccl0, code=4)
 
     def collect(b):
         if not inflight[b]:
@@ -379,6 +436,7 @@ def run_inproc(args, K, plan):
         "kernels_scope": "rank 0's shard, per frame (a launch covers frames_per_launch frames); HIP-event brackets",
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
         "rccl": {"nranks": int(info.nranks), "nlocal": int(info.nlocal), "version": int(info.rcclVersion), "launch": "one process, rtr_mgpu_create (ncclCommInitAll, a host thread per rank)",
+                 "first_exchange_verified": rccl0["first_exchange_verified"], "first_exchange_ms": rccl0["first_exchange_ms"],
                  "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
                  "env": plan["env_defaults"],
                  # host time of the slowest rank's thread per frame it enqueued (stream waits, the launch, RCCL calls, event records): the
@@ -632,8 +690,55 @@ def main():
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(mgpu.MultiGpu.unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
-        mg = mgpu.MultiGpu.rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), frames_in_flight=nbuf)
-        mg.scene_create(setup.desc)
+        if rank == 0:
+            start_line("one process per GPU (torch.distributed.run; rtr_mgpu_create_rank: ncclCommInitRank, the id broadcast through torch.distributed)",
+                       asked=world, devices_present=torch.cuda.device_count(), local_rank=local_rank)
+
+        def all_ranks_ok(ok):
+            """every rank learns whether ALL ranks got through a stage (a rank that failed must not leave the others in a collective)"""
+            t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            return bool(t_.item())
+        why, rccl0 = None, None
+        try:
+            mg = mgpu.MultiGpu.rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), frames_in_flight=nbuf)
+            rccl0 = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion)}
+            mg.scene_create(setup.desc)
+        except RuntimeError as e:
+            why = e
+        if not all_ranks_ok(why is None):
+            if rank == 0:
+                start_failure(args, "rtr_mgpu_create_rank (ncclCommInitRank) / rtr_mgpu_scene_create", why or "another rank failed (its stderr says why)", rccl0)
+            raise SystemExit(3)
+        if rank == 0:
+            start_line("communicator up", rccl_version=rccl0["version"], nranks=rccl0["nranks"], nlocal=rccl0["nlocal"], group_per_slot=os.environ.get("RTR_MGPU_GROUP_PER_SLOT", "0"))
+        # the first launch: verified (VERDICT r04 item 6) — every rank renders its shard of frame 0 and takes part in the grouped exchange
+        # under the watchdog; rank 0 compares the assembled frame with its own unsharded render of the same camera
+        first_whole = api.Frame(ctx, W, H, images) if rank == 0 else None
+
+        def whole_of_first():
+            if rank != 0:
+                return None
+            render_step(first_whole, 0, [params(0, 0, 1, j=j) for j in range(K)], False)
+            return first_whole.download()
+        first_bad, first_ms = None, 0.0
+        try:
+            first_bad, first_ms = first_exchange(mg, A, whole_of_first, cams.camera(0), lambda j: cams.info(0, j if K > 1 else None), [params(0, j=j) for j in range(K)])
+        except RuntimeError as e:
+            why = e
+        if not all_ranks_ok(why is None):
+            if rank == 0:
+                start_failure(args, "first grouped exchange (ncclGroupStart ... ncclGroupEnd, k_deinterleave)", why or "another rank failed (its stderr says why)", rccl0)
+            raise SystemExit(3)
+        verified = all_ranks_ok(rank != 0 or first_bad == 0)
+        if rank == 0:
+            rccl0.update(first_exchange_verified=(first_bad == 0), first_exchange_pixels_differing=first_bad, first_exchange_ms=round(first_ms, 2))
+            start_line("first exchange " + ("verified" if first_bad == 0 else "WRONG"), pixels_differing=first_bad, ms=round(first_ms, 1))
+            first_whole.close()
+        if not verified:
+            if rank == 0:
+                start_failure(args, "first exchange verification", f"the assembled frame differs from rank 0's unsharded render in {first_bad} pixels", rccl0, code=4)
+            raise SystemExit(4)
 
     def collect(buf):
         """host-side join of the frame that used `buf` (the other frames stay in flight) + its per-launch HIP-event times"""
@@ -1098,6 +1203,7 @@ def main():
                          "gather": "librtr_mgpu.so: grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave" if use_lib else "torch.distributed gather (rehearsal backend)"}
         if use_lib:
             out["rccl"] = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion),
+                           "first_exchange_verified": rccl0["first_exchange_verified"], "first_exchange_ms": rccl0["first_exchange_ms"],
                            "launch": "one process per GPU under torch.distributed.run, rtr_mgpu_create_rank (ncclCommInitRank; the id travels through a broadcast)",
                            "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
                            "env": plan["env_defaults"]}

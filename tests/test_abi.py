@@ -141,13 +141,13 @@ def test_shipped_libraries_hold_no_test_hooks():
     """environment switches that let ranks share a device, make a one-rank communicator exchange with itself, shrink the
     overflow list or force the visibility pre-fill must not be reachable in the shipped libraries.  They are compiled only into
     librtr_hip_test.so / librtr_mgpu_test.so (-DRTR_TEST_HOOKS, same sources), which export the same ABI."""
-    hooks = (b"RTR_MGPU_TEST_SHARED_DEVICE", b"RTR_MGPU_SELF_EXCHANGE", b"RTR_TRACE_OVERFLOW_CAP", b"RTR_TRACE_VIS_FILL")
+    hooks = (b"RTR_MGPU_TEST_SHARED_DEVICE", b"RTR_MGPU_SELF_EXCHANGE", b"RTR_TRACE_OVERFLOW_CAP", b"RTR_TRACE_VIS_FILL", b"RTR_MGPU_TEST_WRONG_PLACE")
     for path in (A.LIB_HIP_PATH, A.LIB_MGPU_PATH, A.LIB_HOST_PATH):
         blob = open(path, "rb").read()
         for h in hooks:
             assert h not in blob, f"{os.path.basename(path)} contains {h.decode()}"
-    assert all(h in open(A.LIB_HIP_HOOKS_PATH, "rb").read() for h in hooks[2:])
-    assert all(h in open(A.LIB_MGPU_HOOKS_PATH, "rb").read() for h in hooks[:2])
+    assert all(h in open(A.LIB_HIP_HOOKS_PATH, "rb").read() for h in hooks[2:4])
+    assert all(h in open(A.LIB_MGPU_HOOKS_PATH, "rb").read() for h in hooks[:2] + hooks[4:])
     # the test builds export every entry point the headers declare (loading them needs no GPU)
     A.hip_lib_with_hooks()
     for name in A.MGPU_SYMBOLS:

@@ -112,8 +112,36 @@ def test_bench_gpus_4_started_plainly_with_the_ranks_sharing_one_gpu(scene_cache
     assert 0 < r["host_enqueue_ms_per_frame"] < 5 and 0 <= r["of_which_inside_rccl_calls"] <= r["host_enqueue_ms_per_frame"]
     assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0
     # N > 1 under the latency bound: two launches in flight, each allowed half the bound; a frame is two launches old when it lands
+    # the first launch was a verified one (assembled frame against rank 0's unsharded render of the same camera), before anything was timed
+    assert r["first_exchange_verified"] is True and r["first_exchange_ms"] > 0
     assert d["frames_in_flight"] == 32 and d["latency"]["frames_per_launch_limit"] == 16 and d["frames_per_launch"] == 12 and d["timed_launches"] == [12, 12]
     assert d["latency"]["launches_in_flight"] == 2 and abs(d["frame_latency_ms"] - 2 * 12 * d["ms_per_step"]) < 2e-3
     assert all(p_["launch_ms"] <= 16.7 / 2 for p_ in d["latency"]["probes"][-1:])
     assert "band-sharded x4" in d["config"]["workload"]
 
+
+
+def test_bench_gpus_n_start_is_verified_and_a_wrong_exchange_stops_the_run(scene_cache):
+    """first contact with RCCL at N > 1 must not be a silent failure.  Before any render bench.py --gpus N says
+    (stderr) how many devices there are, which RCCL answered and how large the communicator is; its first launch is a VERIFIED one.
+    The mutation: the test build's RTR_MGPU_TEST_WRONG_PLACE=1 makes rank 0 receive every shard into its neighbour's place — the
+    exchange completes, the frame is wrong — and the run must stop there: rc != 0, the reason on stderr and in the JSON line, no rate."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_SCENE_CACHE=str(scene_cache), LD_PRELOAD=fake, RTR_MGPU_TEST_SHARED_DEVICE="1")
+    base.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2", "--width", "320", "--height", "200"]
+    good = subprocess.run(cmd, cwd=ROOT, env=base, capture_output=True, text=True, timeout=600)
+    assert good.returncode == 0, good.stderr[-3000:]
+    assert "N>1 start: one process drives the ranks" in good.stderr and "devices_present=" in good.stderr
+    assert "communicator up | rccl_version=99999 nranks=3" in good.stderr and "first exchange verified | pixels_differing=0" in good.stderr
+    d = json.loads([ln for ln in good.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["rccl"]["first_exchange_verified"] is True and d["value"] > 0
+    bad = subprocess.run(cmd, cwd=ROOT, env=dict(base, RTR_MGPU_TEST_WRONG_PLACE="1"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 4, (bad.returncode, bad.stderr[-2000:])
+    assert "first exchange WRONG" in bad.stderr and "FAILED at first exchange verification" in bad.stderr
+    e = json.loads([ln for ln in bad.stdout.splitlines() if ln.startswith("{")][-1])
+    assert e["value"] is None and e["error"]["stage"] == "first exchange verification" and e["rccl"]["first_exchange_verified"] is False and e["rccl"]["nranks"] == 3
+    # the per-slot grouping of the exchange stays reachable (the fallback should one group per launch ever misbehave on a node)
+    per_slot = subprocess.run(cmd, cwd=ROOT, env=dict(base, RTR_MGPU_GROUP_PER_SLOT="1"), capture_output=True, text=True, timeout=600)
+    assert per_slot.returncode == 0 and "group_per_slot=1" in per_slot.stderr, per_slot.stderr[-2000:]
+    assert json.loads([ln for ln in per_slot.stdout.splitlines() if ln.startswith("{")][-1])["verify"]["assembled_vs_unsharded_pixels_differing"] == 0

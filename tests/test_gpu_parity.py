@@ -270,8 +270,9 @@ def test_bunny_1080p_4spp_properties_and_sampled_oracle(gpu_ctx, oracle, scene_c
 
 
 def test_4k_accumulated_sample(gpu_ctx, oracle, scene_cache):
-    """BASELINE config 5 shape (3840x2160, frames accumulated in float HDR), checked on shard 0 of 32 against the oracle."""
-    W, H, N, SH = 3840, 2160, 3, 32
+    """BASELINE config 5 as written — Sponza-class, 3840x2160, 16 frames accumulated in the float HDR buffer, 8 band-shards — on ONE of the
+    eight shards (272 rows, 1.04 M pixels, 16 x 14 M rays) against the oracle: HDR bits and framebuffer bytes after the sixteenth frame."""
+    W, H, N, SH = 3840, 2160, 16, 8
     s = scenes.sponza_class(W, H)
     imgs = A.IMAGES_FRAMEBUFFER | A.IMG_BIT(A.IMAGE_HDR)
     scene = api.Scene(gpu_ctx, s.desc)
@@ -285,7 +286,8 @@ def test_4k_accumulated_sample(gpu_ctx, oracle, scene_cache):
         ref = oracle.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, images=imgs, hdr=hdr, threads=16)
     assert np.array_equal(frame.download(A.IMAGE_HDR).view(np.uint32), hdr.view(np.uint32))
     _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], "4K accumulated shard")
-    # the whole 4K frame renders and every live pixel is opaque
+    assert np.all(frame.download(A.IMAGE_HDR)[api.shard_rows(H, 8, SH) - 8 - 1, :, 3] == N)       # sixteen frames in every live pixel's sum
+    # the whole 4K frame renders and every live pixel is opaque; its rows of shard 0 are the shard's first frame
     full = api.Frame(gpu_ctx, W, H, A.IMAGES_FRAMEBUFFER)
     api.render(scene, s.camera, s.scene_info(0), api.make_params(W, H), full)
     img = full.download()
