@@ -991,13 +991,13 @@ def main():
             rev = A.hip_lib().rtr_kernel_revision().decode()
             pmc, pmc_note, pmc_key, pmc_file = None, None, None, None
             # The counter totals are NOT measured by this process (rocprofv3 has to wrap it): they are committed passes of this command
-            # (profiles/pmc_r04.sh -> profiles/r04/pmc_roofline.json).  Used when workload, kernel revision and triangle count match this
+            # (profiles/pmc_r05.sh -> profiles/r05/pmc_roofline.json).  Used when workload, kernel revision and triangle count match this
             # run; among those, the passes whose launches are closest in length (same camera mode first), and the totals are SCALED by
             # rays traced (`pmc_scaled_by`: 1.0 = the committed passes are of exactly these launches) — counter totals of this kernel are
             # proportional to the rays it walks to within a per cent across launch lengths (profiles/r03/pmc_roofline.json: 33.9 - 34.4
             # vector instructions per ray from 1 to 32 frames per launch).
             base_key = f"{args.workload}_{W}x{H}_spp{S}_gpus{world}"
-            for tpath in (os.path.join(ROOT, "profiles", "r04", "pmc_roofline.json"), os.path.join(ROOT, "profiles", "r03", "pmc_roofline.json")):
+            for tpath in (os.path.join(ROOT, "profiles", "r05", "pmc_roofline.json"), os.path.join(ROOT, "profiles", "r04", "pmc_roofline.json")):
                 try:
                     table = json.load(open(tpath))
                 except Exception as e:      # noqa: BLE001

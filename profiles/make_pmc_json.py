@@ -41,7 +41,9 @@ def hbm(entry, stream_read_bytes):
 queue_bytes, hit_bytes = rays * 20, nps * 20          # the queue's streamed part: 16-B (direction, tmax) + 4-B slot per ray; the 16-B origins are gathered through the caches
 kernels = {}
 for short, needles, stream in (("k_primary", ("k_primary<", "false"), 0), ("k_shadow_gen_oct", ("k_shadow_gen_oct",), hit_bytes),
-                               ("k_shadow_trace4", (name,), queue_bytes), ("k_resolve", ("k_resolve<false>",), hit_bytes)):
+                               ("k_shadow_trace4", (name,), queue_bytes), ("k_resolve", ("k_resolve_compact",), hit_bytes), ("k_resolve", ("k_resolve<false",), hit_bytes)):
+    if short in kernels:
+        continue
     try:
         kn, e = pick(*needles)
     except SystemExit:
