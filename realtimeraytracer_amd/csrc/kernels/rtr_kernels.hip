@@ -1509,8 +1509,8 @@ __global__ __launch_bounds__(kBlock) RTR_RESOLVE_ATTR void k_resolve(DeviceScene
 #ifndef RTR_RESOLVE_COMPACT_WAVES
 #define RTR_RESOLVE_COMPACT_WAVES 5
 #endif
-constexpr uint32_t kResolveCap = RTR_RESOLVE_CAP;        /* work items a wave collects before it evaluates them: a multiple of 64, at least 128 */
-static_assert(kResolveCap % 64 == 0 && kResolveCap >= 128 && kResolveCap <= 1024, "RTR_RESOLVE_CAP");
+constexpr uint32_t kResolveCap = RTR_RESOLVE_CAP;        /* work items a wave collects before it evaluates them (a round closes once fewer than 64 places are left): a multiple of 32, at least 128 */
+static_assert(kResolveCap % 32 == 0 && kResolveCap >= 128 && kResolveCap <= 1024, "RTR_RESOLVE_CAP");
 constexpr uint32_t kResolveMaxLights = 255u, kResolveMaxLightTris = 4094u, kResolveMaxSamples = 63u;      /* what a 32-bit work item can name */
 constexpr uint32_t kItemDirectional = 0xfffu;
 
