@@ -225,23 +225,93 @@ def start_failure(args, stage, why, rccl=None, code=3):
     raise SystemExit(code)
 
 
-def first_exchange(mg, A, render_whole, camera, info, p_shards, n_frames_acc=1):
-    """The FIRST launch of an N > 1 run is a verified one: one frame through every rank's render, the grouped exchange and the
-    de-interleave, joined under a watchdog, and compared with rank 0's unsharded render of the same camera.  Returns
-    (pixels differing, milliseconds) — raises RuntimeError when the library reports a failure or the watchdog fires."""
-    import ctypes as C
-    if "RTR_MGPU_TIMEOUT_MS" not in os.environ:
-        A.mgpu_lib().rtr_mgpu_set_timeout_ms(mg.h, FIRST_EXCHANGE_TIMEOUT_MS)
-    t = time.perf_counter()
-    for j, p in enumerate(p_shards):
-        mg.render_async(0, camera, info(j), p, exchange=(j == len(p_shards) - 1))
-    mg.wait(0)
-    ms = (time.perf_counter() - t) * 1e3
-    if "RTR_MGPU_TIMEOUT_MS" not in os.environ:
-        A.mgpu_lib().rtr_mgpu_set_timeout_ms(mg.h, 120000)
-    want = render_whole()
-    got = mg.download(0) if want is not None else None
-    return (int((got != want).sum()) if want is not None else None), ms
+def verified_launches(mg, A, cams, p_run, K, B, unsharded):
+    """The FIRST launches of an N > 1 run are verified ones, joined under a watchdog: (1) one frame — every rank's render, the grouped
+    exchange, the de-interleave; (2) one launch of B frames in B slots, the shape the timed launches have (every slot's shards in the
+    launch's exchange) — each assembled frame compared with rank 0's unsharded render of the same camera.  unsharded(i) -> the
+    unsharded frame i as an array (rank 0) or None (the other ranks of a one-process-per-GPU job).
+    Returns {"pixels_differing": n or None, "ms": first exchange, "batch_frames": B, "batch_ms": ...}; RuntimeError when the library
+    reports a failure or the watchdog fires."""
+    lib = A.mgpu_lib()
+    own_watchdog = "RTR_MGPU_TIMEOUT_MS" not in os.environ
+    if own_watchdog:
+        lib.rtr_mgpu_set_timeout_ms(mg.h, FIRST_EXCHANGE_TIMEOUT_MS)
+    try:
+        t = time.perf_counter()
+        for j, p in enumerate(p_run):
+            mg.render_async(0, cams.camera(0), cams.info(0, j if K > 1 else None), p, exchange=(j == len(p_run) - 1))
+        mg.wait(0)
+        ms = (time.perf_counter() - t) * 1e3
+        want = unsharded(0)
+        bad = int((mg.download(0) != want).sum()) if want is not None else None
+        batch_ms = None
+        if B > 1 and K == 1:
+            t = time.perf_counter()
+            slots = list(range(B))
+            mg.render_batch_async(slots, [cams.camera(i) for i in slots], [cams.info(i) for i in slots], p_run[0])
+            for b in slots:
+                mg.wait(b)
+            batch_ms = (time.perf_counter() - t) * 1e3
+            for b in slots:
+                want = unsharded(b)
+                if want is not None:
+                    bad += int((mg.download(b) != want).sum())
+    finally:
+        if own_watchdog:
+            lib.rtr_mgpu_set_timeout_ms(mg.h, 120000)
+    return {"pixels_differing": bad, "ms": ms, "batch_frames": B if (B > 1 and K == 1) else 0, "batch_ms": batch_ms}
+
+
+def bring_up(args, create, verify, agree=lambda ok: ok, root=True, how=""):
+    """Makes the communicator and proves the exchange before anything is timed.  create() -> MultiGpu with its scene
+    (RuntimeError on failure); verify(mg) -> verified_launches(...); agree(ok) -> whether EVERY rank says ok (a collective in a
+    one-process-per-GPU job: a rank that failed must not leave the others inside one).
+    Two attempts: the plan's ONE RCCL group per launch; if its verified launches fail, time out or come out wrong, the communicator is
+    given up and everything is made again with one group PER SLOT (RTR_MGPU_GROUP_PER_SLOT=1, read at creation) — the fallback that
+    was only ever reachable by hand.  A run whose second attempt fails too ends here: the reason on stderr and in the JSON line, rc != 0."""
+    forced = os.environ.get("RTR_MGPU_GROUP_PER_SLOT") == "1"
+    for per_slot in ([True] if forced else [False, True]):
+        if per_slot:
+            os.environ["RTR_MGPU_GROUP_PER_SLOT"] = "1"
+        mg, rccl0, why, res = None, None, None, None
+        try:
+            mg = create()
+            rccl0 = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion), "group_per_slot": per_slot}
+        except RuntimeError as e:
+            why = e
+        if not agree(why is None):                  # no communicator, no scene: not a question of grouping — no second attempt
+            if root:
+                start_failure(args, how + " / rtr_mgpu_scene_create", why or "another rank failed (its stderr says why)", rccl0)
+            raise SystemExit(3)
+        if root:
+            start_line("communicator up", rccl_version=rccl0["version"], nranks=rccl0["nranks"], nlocal=rccl0["nlocal"], group_per_slot=int(per_slot))
+        try:
+            res = verify(mg)
+        except RuntimeError as e:
+            why = e
+        ran = agree(why is None)
+        good = ran and agree(not root or res["pixels_differing"] == 0)
+        if root and ran:
+            rccl0.update(first_exchange_verified=(res["pixels_differing"] == 0), first_exchange_pixels_differing=res["pixels_differing"], first_exchange_ms=round(res["ms"], 2),
+                         first_batch_frames=res["batch_frames"], first_batch_ms=round(res["batch_ms"], 2) if res["batch_ms"] else None)
+            start_line("first exchange " + ("verified" if good else "WRONG"), pixels_differing=res["pixels_differing"], ms=round(res["ms"], 1), batch_frames=res["batch_frames"],
+                       grouping="one group per slot" if per_slot else "one group per launch")
+        if good:
+            return mg, rccl0
+        if root and rccl0 is not None and not ran:
+            rccl0["first_exchange_verified"] = False
+        try:
+            mg.close()
+        except Exception:      # noqa: BLE001
+            pass
+        if per_slot:                                # nothing left to fall back to
+            if root:
+                if ran:
+                    start_failure(args, "first exchange verification", f"the assembled frames differ from rank 0's unsharded renders in {res['pixels_differing']} pixels", rccl0, code=4)
+                start_failure(args, "first grouped exchange (ncclGroupStart ... ncclGroupEnd, k_deinterleave)", why or "another rank failed (its stderr says why)", rccl0)
+            raise SystemExit(4 if ran else 3)
+        if root:
+            start_line("the verified launches " + ("came out WRONG" if ran else f"FAILED ({why})") + " with one RCCL group per launch: giving the communicator up, again with one group per slot")
 
 
 def run_inproc(args, K, plan):
@@ -261,18 +331,13 @@ def run_inproc(args, K, plan):
     # the library says what is wrong when the devices are not there ("8 devices requested, 1 present"): no check of our own before it
     start_line("one process drives the ranks (rtr_mgpu_create: ncclCommInitAll, a host thread per rank)", asked=N, devices_present=torch.cuda.device_count(),
                devices=plan["devices"], shared_device=bool(plan.get("shared_device")))
-    try:
-        mg = mgpu.MultiGpu(devices=plan["devices"], frames_in_flight=nbuf)
-    except RuntimeError as e:
-        start_failure(args, "rtr_mgpu_create (ncclCommInitAll)", e)
-    rccl0 = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion)}
-    start_line("communicator up", rccl_version=rccl0["version"], nranks=rccl0["nranks"], nlocal=rccl0["nlocal"], group_per_slot=os.environ.get("RTR_MGPU_GROUP_PER_SLOT", "0"))
+    if not plan.get("shared_device") and torch.cuda.device_count() < N:      # the library's own message, before a scene is built for nothing
+        try:
+            mgpu.MultiGpu(devices=plan["devices"], frames_in_flight=1).close()
+        except RuntimeError as e:
+            start_failure(args, "rtr_mgpu_create (ncclCommInitAll)", e)
     setup = build_setup(args, scenes, np)
     cams = CameraSource(setup, args.camera)
-    try:
-        mg.scene_create(setup.desc)
-    except RuntimeError as e:
-        start_failure(args, "rtr_mgpu_scene_create", e, rccl0)
     images = A.IMAGES_FRAMEBUFFER | (A.IMG_BIT(A.IMAGE_HDR) if K > 1 else 0)
 
     def params(collect=0, shard_index=0, shard_count=1, j=0):
@@ -298,19 +363,24 @@ def run_inproc(args, K, plan):
     kern = {"primary": 0.0, "shadow_gen": 0.0, "shadow_trace": 0.0, "shadow_tail": 0.0, "resolve": 0.0, "n": 0}
     inflight = [False] * nbuf
 
-    # the first launch: verified — before anything is timed, probed or warmed up
-    def whole_of_first():
+    # frames per launch: what was asked for, capped by what one launch of a rank's shard can address (rtr_render_batch_limit)
+    B = max(1, min(plan["frames_per_launch"], nbuf, api.render_batch_limit(scene, params(0, 0, N), setup.num_lights))) if K == 1 else 1
+
+    # the communicator, and the first launches: verified — before anything is timed, probed or warmed up (bring_up)
+    def create():
+        m = mgpu.MultiGpu(devices=plan["devices"], frames_in_flight=nbuf)
+        try:
+            m.scene_create(setup.desc)
+        except RuntimeError:
+            m.close()
+            raise
+        return m
+
+    def unsharded(i):
         for j in range(K):
-            api.render(scene, cams.camera(0), cams.info(0, j if K > 1 else None), params(0, j=j), whole)
+            api.render(scene, cams.camera(i), cams.info(i, j if K > 1 else None), params(0, j=j), whole)
         return whole.download()
-    try:
-        first_bad, first_ms = first_exchange(mg, A, whole_of_first, cams.camera(0), lambda j: cams.info(0, j if K > 1 else None), p_run)
-    except RuntimeError as e:
-        start_failure(args, "first grouped exchange (ncclGroupStart ... ncclGroupEnd, k_deinterleave)", e, rccl0)
-    rccl0.update(first_exchange_verified=(first_bad == 0), first_exchange_pixels_differing=first_bad, first_exchange_ms=round(first_ms, 2))
-    start_line("first exchange " + ("verified" if first_bad == 0 else "WRONG"), pixels_differing=first_bad, ms=round(first_ms, 1))
-    if first_bad != 0:
-        start_failure(args, "first exchange verification", f"the assembled frame differs from rank 0's unsharded render in {first_bad} pixels", rccl0, code=4)
+    mg, rccl0 = bring_up(args, create, lambda m: verified_launches(m, A, cams, p_run, K, B, unsharded), how="rtr_mgpu_create (ncclCommInitAll)")
 
     def collect(b):
         if not inflight[b]:
@@ -321,8 +391,6 @@ def run_inproc(args, K, plan):
         kern["primary"] += st.primaryMs; kern["shadow_gen"] += st.shadowGenMs
         kern["shadow_trace"] += st.shadowTraceMs; kern["shadow_tail"] += st.shadowTailMs; kern["resolve"] += st.resolveMs; kern["n"] += 1
 
-    # frames per launch: what was asked for, capped by what one launch of a rank's shard can address (rtr_render_batch_limit)
-    B = max(1, min(plan["frames_per_launch"], nbuf, api.render_batch_limit(scene, params(0, 0, N), setup.num_lights))) if K == 1 else 1
     groups, launch_no, last_slot = max(nbuf // B, 1), [0], [0]
 
     def step(i):
@@ -437,6 +505,7 @@ def run_inproc(args, K, plan):
         # what RCCL saw: the size of the communicator, how many of its ranks this process drives, the library that is loaded
         "rccl": {"nranks": int(info.nranks), "nlocal": int(info.nlocal), "version": int(info.rcclVersion), "launch": "one process, rtr_mgpu_create (ncclCommInitAll, a host thread per rank)",
                  "first_exchange_verified": rccl0["first_exchange_verified"], "first_exchange_ms": rccl0["first_exchange_ms"],
+                 "first_batch_frames": rccl0["first_batch_frames"], "first_batch_ms": rccl0["first_batch_ms"], "group_per_slot": rccl0["group_per_slot"],
                  "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
                  "env": plan["env_defaults"],
                  # host time of the slowest rank's thread per frame it enqueued (stream waits, the launch, RCCL calls, event records): the
@@ -685,11 +754,8 @@ def main():
     # frame slots with a render stream each, a communication stream with grouped ncclSend / ncclRecv to rank 0, k_deinterleave
     use_lib = dist_on and args.backend == "nccl"
     mg = None
+    rccl0 = None
     if use_lib:
-        uid = torch.zeros(A.MGPU_ID_BYTES, dtype=torch.uint8, device=device)
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(mgpu.MultiGpu.unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, src=0)
         if rank == 0:
             start_line("one process per GPU (torch.distributed.run; rtr_mgpu_create_rank: ncclCommInitRank, the id broadcast through torch.distributed)",
                        asked=world, devices_present=torch.cuda.device_count(), local_rank=local_rank)
@@ -699,46 +765,32 @@ def main():
             t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
             dist.all_reduce(t_, op=dist.ReduceOp.MIN)
             return bool(t_.item())
-        why, rccl0 = None, None
-        try:
-            mg = mgpu.MultiGpu.rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), frames_in_flight=nbuf)
-            rccl0 = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion)}
-            mg.scene_create(setup.desc)
-        except RuntimeError as e:
-            why = e
-        if not all_ranks_ok(why is None):
+
+        def create():
+            uid = torch.zeros(A.MGPU_ID_BYTES, dtype=torch.uint8, device=device)
             if rank == 0:
-                start_failure(args, "rtr_mgpu_create_rank (ncclCommInitRank) / rtr_mgpu_scene_create", why or "another rank failed (its stderr says why)", rccl0)
-            raise SystemExit(3)
-        if rank == 0:
-            start_line("communicator up", rccl_version=rccl0["version"], nranks=rccl0["nranks"], nlocal=rccl0["nlocal"], group_per_slot=os.environ.get("RTR_MGPU_GROUP_PER_SLOT", "0"))
-        # the first launch: verified — every rank renders its shard of frame 0 and takes part in the grouped exchange
-        # under the watchdog; rank 0 compares the assembled frame with its own unsharded render of the same camera
+                uid.copy_(torch.frombuffer(bytearray(mgpu.MultiGpu.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            m = mgpu.MultiGpu.rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), frames_in_flight=nbuf)
+            try:
+                m.scene_create(setup.desc)
+            except RuntimeError:
+                m.close()
+                raise
+            return m
         first_whole = api.Frame(ctx, W, H, images) if rank == 0 else None
 
-        def whole_of_first():
+        def unsharded(i):
             if rank != 0:
                 return None
-            render_step(first_whole, 0, [params(0, 0, 1, j=j) for j in range(K)], False)
+            render_step(first_whole, i, [params(0, 0, 1, j=j) for j in range(K)], False)
             return first_whole.download()
-        first_bad, first_ms = None, 0.0
-        try:
-            first_bad, first_ms = first_exchange(mg, A, whole_of_first, cams.camera(0), lambda j: cams.info(0, j if K > 1 else None), [params(0, j=j) for j in range(K)])
-        except RuntimeError as e:
-            why = e
-        if not all_ranks_ok(why is None):
-            if rank == 0:
-                start_failure(args, "first grouped exchange (ncclGroupStart ... ncclGroupEnd, k_deinterleave)", why or "another rank failed (its stderr says why)", rccl0)
-            raise SystemExit(3)
-        verified = all_ranks_ok(rank != 0 or first_bad == 0)
-        if rank == 0:
-            rccl0.update(first_exchange_verified=(first_bad == 0), first_exchange_pixels_differing=first_bad, first_exchange_ms=round(first_ms, 2))
-            start_line("first exchange " + ("verified" if first_bad == 0 else "WRONG"), pixels_differing=first_bad, ms=round(first_ms, 1))
+        p_first = [params(0, j=j) for j in range(K)]
+        B_first = max(1, min(plan["frames_per_launch"], nbuf, api.render_batch_limit(scene, p_first[0], setup.num_lights))) if K == 1 else 1
+        mg, rccl0 = bring_up(args, create, lambda m: verified_launches(m, A, cams, p_first, K, B_first, unsharded), agree=all_ranks_ok, root=(rank == 0),
+                             how="rtr_mgpu_create_rank (ncclCommInitRank)")
+        if first_whole is not None:
             first_whole.close()
-        if not verified:
-            if rank == 0:
-                start_failure(args, "first exchange verification", f"the assembled frame differs from rank 0's unsharded render in {first_bad} pixels", rccl0, code=4)
-            raise SystemExit(4)
 
     def collect(buf):
         """host-side join of the frame that used `buf` (the other frames stay in flight) + its per-launch HIP-event times"""
@@ -1204,6 +1256,7 @@ def main():
         if use_lib:
             out["rccl"] = {"nranks": int(mg.info.nranks), "nlocal": int(mg.info.nlocal), "version": int(mg.info.rcclVersion),
                            "first_exchange_verified": rccl0["first_exchange_verified"], "first_exchange_ms": rccl0["first_exchange_ms"],
+                           "first_batch_frames": rccl0["first_batch_frames"], "first_batch_ms": rccl0["first_batch_ms"], "group_per_slot": rccl0["group_per_slot"],
                            "launch": "one process per GPU under torch.distributed.run, rtr_mgpu_create_rank (ncclCommInitRank; the id travels through a broadcast)",
                            "exchange": "grouped ncclSend / ncclRecv to rank 0 on a communication stream + k_deinterleave (librtr_mgpu.so, plan = rtr_mgpu_plan)",
                            "env": plan["env_defaults"]}

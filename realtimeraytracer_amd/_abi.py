@@ -293,7 +293,7 @@ def test_hooks_requested():
     """This process wants the multi-GPU library's test build: RTR_TEST_HOOKS=1, or one of the two switches only that build has is set
     (child processes of the GPU tests, bench.py's one-GPU rehearsal of N ranks)"""
     e = os.environ
-    return e.get("RTR_TEST_HOOKS") == "1" or e.get("RTR_MGPU_SELF_EXCHANGE") == "1" or e.get("RTR_MGPU_TEST_SHARED_DEVICE") == "1" or e.get("RTR_MGPU_TEST_WRONG_PLACE") == "1"
+    return e.get("RTR_TEST_HOOKS") == "1" or e.get("RTR_MGPU_SELF_EXCHANGE") == "1" or e.get("RTR_MGPU_TEST_SHARED_DEVICE") == "1" or e.get("RTR_MGPU_TEST_WRONG_PLACE") in ("1", "2")
 
 
 def mgpu_lib():

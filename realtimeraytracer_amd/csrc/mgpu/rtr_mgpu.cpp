@@ -181,7 +181,8 @@ int prepare_slot(rtr_mgpu* m, Rank& r, Slot& s, const rtr_render_params& p, std:
  * launch: the shards of all its slots travel in one ncclGroupStart / ncclGroupEnd — on rank 0 the (N - 1) x nslots receives, on the
  * others nslots sends, slot by slot (RCCL matches the transfers between a pair of ranks in posting order) — not one group per slot:
  * a launch of sixteen shards at N = 8 is one RCCL launch on the rank that also renders and de-interleaves, not sixteen. */
-#define RTR_MGPU_TEST_WRONG_PLACE 0x40000000      /* internal, test build only (RTR_MGPU_TEST_WRONG_PLACE=1 at creation) */
+#define RTR_MGPU_TEST_WRONG_PLACE 0x40000000      /* internal, test build only (RTR_MGPU_TEST_WRONG_PLACE=1 / 2 at creation) */
+#define RTR_MGPU_TEST_WRONG_PLACE_ONE_GROUP 0x20000000
 int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t bandRows, int flags, int selfExchange, int nslots, std::vector<rtr_mgpu_op>& ops) {
     if (nranks < 1 || nranks > RTR_MGPU_MAX_RANKS || rank < 0 || rank >= nranks || width == 0 || height == 0 || nslots < 1 || nslots > RTR_MAX_BATCH) return RTR_ERR_INVALID_ARGUMENT;
     if (bandRows == 0) bandRows = 8;
@@ -218,7 +219,7 @@ int make_plan(int rank, int nranks, uint32_t width, uint32_t height, uint32_t ba
                 for (int src = 1; src < nranks; ++src) {
                     uint64_t at = shardBytes * (uint64_t)src;
 #ifdef RTR_TEST_HOOKS      /* librtr_mgpu_test.so only — the mutation bench.py's verified first exchange must catch: every shard lands in its neighbour's place */
-                    if (flags & RTR_MGPU_TEST_WRONG_PLACE) at = shardBytes * (uint64_t)((src + 1) % nranks);
+                    if ((flags & RTR_MGPU_TEST_WRONG_PLACE) || ((flags & RTR_MGPU_TEST_WRONG_PLACE_ONE_GROUP) && !(flags & RTR_MGPU_GROUP_PER_SLOT))) at = shardBytes * (uint64_t)((src + 1) % nranks);
 #endif
                     op(RTR_MGPU_OP_RECV, RTR_MGPU_STREAM_COMM, j, src, RTR_MGPU_BUF_GATHER, RTR_MGPU_EV_NONE, at, shardBytes);
                 }
@@ -393,7 +394,10 @@ void read_env(rtr_mgpu* m) {
     if (const char* t = getenv("RTR_MGPU_TIMEOUT_MS")) m->timeoutMs = (uint32_t)strtoul(t, nullptr, 10);
     if (const char* g = getenv("RTR_MGPU_GROUP_PER_SLOT")) if (g[0] == '1') m->planFlags |= RTR_MGPU_GROUP_PER_SLOT;
 #ifdef RTR_TEST_HOOKS
-    if (const char* g = getenv("RTR_MGPU_TEST_WRONG_PLACE")) if (g[0] == '1') m->planFlags |= RTR_MGPU_TEST_WRONG_PLACE;
+    if (const char* g = getenv("RTR_MGPU_TEST_WRONG_PLACE")) {      /* 1: always; 2: only while the launch's exchange is ONE group (what bench.py's fallback to a group per slot must get around) */
+        if (g[0] == '1') m->planFlags |= RTR_MGPU_TEST_WRONG_PLACE;
+        if (g[0] == '2') m->planFlags |= RTR_MGPU_TEST_WRONG_PLACE_ONE_GROUP;
+    }
 #endif
 }
 

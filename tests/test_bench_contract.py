@@ -72,6 +72,8 @@ def test_bench_multi_rank_path_with_one_rank_through_rccl(scene_cache):
     assert d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0 and "librtr_mgpu.so" in d["verify"]["gather"]
     assert d["cpu_baseline"] is None and d["presented_frame"] is None and d["value"] > 0
     assert d["rccl"]["nranks"] == 1 and d["rccl"]["nlocal"] == 1 and d["rccl"]["version"] > 20000 and "rtr_mgpu_create_rank" in d["rccl"]["launch"]
+    # the one-process-per-GPU start goes through the same bring-up: communicator, then verified first launches, before anything is timed
+    assert d["rccl"]["first_exchange_verified"] is True and d["rccl"]["group_per_slot"] is False and d["rccl"]["first_batch_frames"] > 1
 
 
 def test_bench_in_process_multi_gpu_path_with_one_rank(scene_cache):
@@ -123,25 +125,37 @@ def test_bench_gpus_4_started_plainly_with_the_ranks_sharing_one_gpu(scene_cache
 
 def test_bench_gpus_n_start_is_verified_and_a_wrong_exchange_stops_the_run(scene_cache):
     """first contact with RCCL at N > 1 must not be a silent failure.  Before any render bench.py --gpus N says
-    (stderr) how many devices there are, which RCCL answered and how large the communicator is; its first launch is a VERIFIED one.
-    The mutation: the test build's RTR_MGPU_TEST_WRONG_PLACE=1 makes rank 0 receive every shard into its neighbour's place — the
-    exchange completes, the frame is wrong — and the run must stop there: rc != 0, the reason on stderr and in the JSON line, no rate."""
+    (stderr) how many devices there are, which RCCL answered and how large the communicator is; its first launches — one frame, then one
+    launch of the timed launches' shape — are VERIFIED ones.  The mutations (test build only): RTR_MGPU_TEST_WRONG_PLACE=2 puts every
+    received shard in its neighbour's place while the launch's exchange is ONE group — the exchange completes, the frames are wrong — and
+    the run must give the communicator up, come back with one group per slot and finish with that; =1 does it in both forms, and the
+    run must stop: rc != 0, the reason on stderr and in the JSON line, no rate."""
     fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RTR_SCENE_CACHE=str(scene_cache), LD_PRELOAD=fake, RTR_MGPU_TEST_SHARED_DEVICE="1")
-    base.pop("WORLD_SIZE", None)
+    base.pop("WORLD_SIZE", None); base.pop("RTR_MGPU_GROUP_PER_SLOT", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2", "--width", "320", "--height", "200"]
+
+    def line(r):
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     good = subprocess.run(cmd, cwd=ROOT, env=base, capture_output=True, text=True, timeout=600)
     assert good.returncode == 0, good.stderr[-3000:]
     assert "N>1 start: one process drives the ranks" in good.stderr and "devices_present=" in good.stderr
-    assert "communicator up | rccl_version=99999 nranks=3" in good.stderr and "first exchange verified | pixels_differing=0" in good.stderr
-    d = json.loads([ln for ln in good.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["rccl"]["first_exchange_verified"] is True and d["value"] > 0
+    assert "communicator up | rccl_version=99999 nranks=3" in good.stderr and "first exchange verified | pixels_differing=0" in good.stderr and "grouping=one group per launch" in good.stderr
+    d = line(good)
+    assert d["rccl"]["first_exchange_verified"] is True and d["rccl"]["group_per_slot"] is False and d["rccl"]["first_batch_frames"] > 1 and d["value"] > 0
+    # one group per launch misbehaves: the fallback takes over and the run completes
+    fb = subprocess.run(cmd, cwd=ROOT, env=dict(base, RTR_MGPU_TEST_WRONG_PLACE="2"), capture_output=True, text=True, timeout=600)
+    assert fb.returncode == 0, fb.stderr[-3000:]
+    assert "first exchange WRONG" in fb.stderr and "again with one group per slot" in fb.stderr and "grouping=one group per slot" in fb.stderr
+    d = line(fb)
+    assert d["rccl"]["group_per_slot"] is True and d["rccl"]["first_exchange_verified"] is True and d["verify"]["assembled_vs_unsharded_pixels_differing"] == 0 and d["value"] > 0
+    # wrong in both forms: nothing left to fall back to
     bad = subprocess.run(cmd, cwd=ROOT, env=dict(base, RTR_MGPU_TEST_WRONG_PLACE="1"), capture_output=True, text=True, timeout=600)
     assert bad.returncode == 4, (bad.returncode, bad.stderr[-2000:])
-    assert "first exchange WRONG" in bad.stderr and "FAILED at first exchange verification" in bad.stderr
-    e = json.loads([ln for ln in bad.stdout.splitlines() if ln.startswith("{")][-1])
+    assert bad.stderr.count("first exchange WRONG") == 2 and "FAILED at first exchange verification" in bad.stderr
+    e = line(bad)
     assert e["value"] is None and e["error"]["stage"] == "first exchange verification" and e["rccl"]["first_exchange_verified"] is False and e["rccl"]["nranks"] == 3
-    # the per-slot grouping of the exchange stays reachable (the fallback should one group per launch ever misbehave on a node)
+    # the per-slot grouping asked for by hand: one attempt, with it
     per_slot = subprocess.run(cmd, cwd=ROOT, env=dict(base, RTR_MGPU_GROUP_PER_SLOT="1"), capture_output=True, text=True, timeout=600)
-    assert per_slot.returncode == 0 and "group_per_slot=1" in per_slot.stderr, per_slot.stderr[-2000:]
-    assert json.loads([ln for ln in per_slot.stdout.splitlines() if ln.startswith("{")][-1])["verify"]["assembled_vs_unsharded_pixels_differing"] == 0
+    assert per_slot.returncode == 0 and "group_per_slot=1" in per_slot.stderr and "grouping=one group per slot" in per_slot.stderr, per_slot.stderr[-2000:]
+    assert line(per_slot)["verify"]["assembled_vs_unsharded_pixels_differing"] == 0
