@@ -42,10 +42,13 @@ typedef struct oracle_scene {
      * 2 (tunable primary_wide = 1; needs `wide`): one ray per lane over the 4-wide view, closest hit, 16 stack entries + redo over the
      * BVH2 (k_primary4). */
     uint32_t primaryPackets;
-    /* The order a shadow ray tries the children of a wide record in — it decides the work counters, never the answer (any-hit is a
-     * pure function of ray and triangles): 0 = the nearest hit child first (strict <, ties to the lower slot), the others stacked in
-     * slot order; 1 = the any-hit order: the first hit slot in SLOT order, the others stacked so that they pop in slot order (the
-     * builder arranged the slots by where an occluder is expected soonest; no distance is compared). */
+    /* How a shadow ray is walked over the wide view — it decides the work counters, never the answer (any-hit is a pure function of ray
+     * and triangles).  The product's default (0): a ray that leaves its surface point INTO the surface — dot(hitNormal, direction) < 0,
+     * the area-light samples of raygen.rgen:206-241 only — first tests the triangles of the LEAF its own hit triangle sits in (it starts
+     * 0.01 above that triangle and nearly always re-enters it), then walks from the root; at a record the nearest hit child is entered
+     * first (strict <, ties to the lower slot), the others stacked in slot order.
+     * bit 0 (experiment, profiles/experiments/anyhit_order_lab.py): the any-hit slot order — the first hit slot in SLOT order, the
+     * others popping in slot order, no distance compared.  bit 1: no start at the own leaf (the product's tunable trace_own_leaf = 0). */
     uint32_t shadowWalk;
     /* Experiments only (profiles/experiments/anyhit_order_lab.py), normally NULL: numWide * 4 * 3 counters the shadow walk adds to —
      * per (record, slot) {times the walk went into the slot, record visits + triangle tests it then spent below it, occluders it found
@@ -57,6 +60,7 @@ typedef struct oracle_scene {
 typedef struct oracle_walk_stats {
     uint64_t occludedRays, occludedVisits, occludedTests;
     uint64_t visibleRays, visibleVisits, visibleTests;
+    uint64_t ownLeafRays;       /* rays that started at the leaf of their own triangle */
 } oracle_walk_stats;
 
 typedef struct oracle_out {

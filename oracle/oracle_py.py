@@ -20,7 +20,7 @@ class oracle_scene(C.Structure):
 
 
 class oracle_walk_stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("occludedRays", "occludedVisits", "occludedTests", "visibleRays", "visibleVisits", "visibleTests")]
+    _fields_ = [(n, C.c_uint64) for n in ("occludedRays", "occludedVisits", "occludedTests", "visibleRays", "visibleVisits", "visibleTests", "ownLeafRays")]
 
 
 class oracle_out(C.Structure):
@@ -101,12 +101,13 @@ class Result:
     pass
 
 
-def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None):
-    """Returns a Result with numpy uint32 images (rows x width) keyed like rtr_image, .hdr and .stats."""
+def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None, own_leaf=True):
+    """own_leaf=False: the product's tunable trace_own_leaf = 0 (shadow rays never start at their own triangle's leaf).
+    Returns a Result with numpy uint32 images (rows x width) keyed like rtr_image, .hdr and .stats."""
     L = lib()
     rows = _shard_rows(params.height, params.bandRows or 8, params.shardCount or 1)
     W = params.width
-    sc = make_scene(desc, bvh, primary_packets, primary_wide, shadow_walk, walk_profile)
+    sc = make_scene(desc, bvh, primary_packets, primary_wide, int(shadow_walk) | (0 if own_leaf else 2), walk_profile)
     out = oracle_out()
     r = Result()
     r.images = {}

@@ -28,9 +28,9 @@ namespace {
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
     uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0, primaryOverflow = 0;
-    uint64_t walk[6] = {0, 0, 0, 0, 0, 0};   /* oracle_walk_stats: shadow rays over the wide view, split by their answer */
+    uint64_t walk[7] = {0, 0, 0, 0, 0, 0, 0};   /* oracle_walk_stats: shadow rays over the wide view, split by their answer */
     void add(const Counters& o) {
-        for (int k = 0; k < 6; ++k) walk[k] += o.walk[k];
+        for (int k = 0; k < 7; ++k) walk[k] += o.walk[k];
         shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests; primaryOverflow += o.primaryOverflow;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
@@ -47,13 +47,14 @@ struct Scene {
     rtr_v3 skyLinear;
     bool useWide = false;                   /* shadow rays over the wide view (oracle_scene::wide) */
     uint32_t shadowWalk = 0;                /* oracle_scene::shadowWalk */
+    bool ownLeafFirst = false;              /* shadow rays that leave INTO their surface start at their own triangle's leaf (the staged pipeline's default; shadowWalk bit 1 turns it off) */
     std::vector<uint32_t> wideParent;       /* only with oracle_scene::walkProfile: record -> parent record * 4 + slot */
     int primaryStackLimit = 0;              /* 16 in the staged pipeline (k_primary_persist / k_primary + k_primary_tail), 0 = unbounded (megakernel) */
     bool primaryPackets = false;            /* camera rays walked tile by tile (trace_packet, k_primary_packet) */
     bool primaryWide = false;               /* camera rays one per lane over the 4-wide view (trace_wide_closest, k_primary4) */
 };
 
-struct Hit { bool hit; float t, u, v; uint32_t custom, prim; };
+struct Hit { bool hit; float t, u, v; uint32_t custom, prim; int32_t leaf; };      /* leaf: code of the leaf the hit triangle was found in (BVH walks; 0 otherwise) */
 
 /* ---- texture(): 8-bit texels, linear filter, repeat addressing, one mip (image_sampler.cppm:26-42) ------------- */
 inline void sample_tex(const rtr_texture& tx, float u, float v, float out[4], Counters& c) {
@@ -176,6 +177,7 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
                     if (!(t < tmax)) continue;
                     if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
                     consider(best, t, u, v, tr.customIndex, tr.primitiveId, tmax);
+                    if (best.hit && best.custom == tr.customIndex && best.prim == tr.primitiveId && best.t == t) best.leaf = cur;
                     if (anyHit && best.hit) return best;
                 }
             }
@@ -255,7 +257,7 @@ void trace_packet(const Scene& sc, rtr_v3 o, const rtr_v3* d, const bool* valid,
                     if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
                     Hit& b = out[l];
                     if (t < b.t || (t == b.t && id_less(tr.customIndex, tr.primitiveId, b.custom, b.prim))) {
-                        b.hit = true; b.t = t; b.u = u; b.v = v; b.custom = tr.customIndex; b.prim = tr.primitiveId;
+                        b.hit = true; b.t = t; b.u = u; b.v = v; b.custom = tr.customIndex; b.prim = tr.primitiveId; b.leaf = cur;
                     }
                 }
             }
@@ -285,7 +287,10 @@ inline float half_bits_to_float(uint32_t h) {
  * the nearest child that is hit (strict <, so ties go to the lower slot), push the other hit children in slot order (skipping a
  * code equal to the one entered, as the kernel's `c != next` does), test a leaf's triangles in storage order until one hits;
  * RTR_WIDE_STACK (16) stack entries, beyond which the ray is redone over the BVH2 as k_shadow_tail does. */
-Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Counters& c) {
+/* firstLeaf != 0 (the leaf code of the triangle the ray starts on, for a ray that leaves its surface point INTO the surface: dot(normal,
+ * direction) < 0): that leaf's triangles are tested first, the walk from the root follows if none of them stops the ray — the ray nearly
+ * always re-enters the triangle it starts 0.01 above, and an any-hit answer does not depend on the order triangles are met in. */
+Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Counters& c, int32_t firstLeaf = 0) {
     const RtrWideNode* nodes = sc.s->wide;
     const RtrBvhTri* tris = sc.s->tris;
     Hit best{}; best.hit = false; best.t = tmax;
@@ -294,7 +299,8 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
     rtr_ray_grid_centre(o, idir, sc.s->grid.origin, sc.s->grid.scale, sc.s->grid.wideCentreXY, sc.s->grid.wideCentreZ, &ga, &gb);
     std::vector<int32_t> stack;
     int32_t cur = 0;
-    const bool slotOrder = sc.shadowWalk == 1u;
+    if (firstLeaf < 0) { stack.push_back(0); cur = firstLeaf; }
+    const bool slotOrder = (sc.shadowWalk & 1u) != 0u;
     uint64_t visits = 0, tests = 0;            /* of this ray, for the split by its answer (oracle_walk_stats) */
     auto done = [&](bool occluded) { c.walk[occluded ? 0 : 3]++; c.walk[occluded ? 1 : 4] += visits; c.walk[occluded ? 2 : 5] += tests; };
     /* walk profile (experiments only, oracle.h): per (record, slot) {entries, work done below it, occluders found below it} */
@@ -308,6 +314,7 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
     };
     std::vector<uint32_t> from;                                                   /* parallel to `stack` */
     uint32_t curFrom = 0;
+    if (prof && firstLeaf < 0) from.push_back(0u);
     for (;;) {
         if (cur >= 0) {
             const RtrWideNode& n = nodes[cur];
@@ -429,7 +436,7 @@ Hit trace_wide_closest(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tm
                     if (!(t < tmax)) continue;
                     if ((tr.flags & 1u) && !alpha_pass(sc.s->desc, tr.customIndex, tr.primitiveId, u, v, c)) continue;
                     if (t < best.t || (t == best.t && id_less(tr.customIndex, tr.primitiveId, best.custom, best.prim))) {
-                        best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = tr.customIndex; best.prim = tr.primitiveId;
+                        best.hit = true; best.t = t; best.u = u; best.v = v; best.custom = tr.customIndex; best.prim = tr.primitiveId; best.leaf = cur;
                     }
                 }
             }
@@ -440,11 +447,11 @@ Hit trace_wide_closest(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tm
     return best;
 }
 
-inline Hit trace(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c) {
+inline Hit trace(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool anyHit, Counters& c, int32_t firstLeaf = 0) {
     c.rays++;
     if (anyHit) c.shadow++; else c.primary++;
     if (!(tmax > tmin)) { Hit h{}; h.hit = false; return h; }
-    if (anyHit && sc.useWide) return trace_wide(sc, o, d, tmin, tmax, c);
+    if (anyHit && sc.useWide) return trace_wide(sc, o, d, tmin, tmax, c, firstLeaf);
     if (!anyHit && sc.primaryWide) return trace_wide_closest(sc, o, d, tmin, tmax, c);
     return sc.s->nodes ? trace_bvh(sc, o, d, tmin, tmax, anyHit, c, anyHit ? 0 : sc.primaryStackLimit) : trace_brute(sc, o, d, tmin, tmax, anyHit, c);
 }
@@ -684,7 +691,9 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
                     rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
                     rtr_v3 sampledLightDir = rtr_normalize(lightVec);                     /* :221 */
                     float lightDistance = rtr_length(lightVec);                           /* :222 */
-                    Hit sh = trace(sc, shadowOrigin, sampledLightDir, 0.001f, lightDistance - 0.5f, true, c); /* :226-241 */
+                    const int32_t ownLeaf = (sc.ownLeafFirst && rtr_dot(hitNormal, sampledLightDir) < 0.0f) ? h.leaf : 0;
+                    if (ownLeaf) c.walk[6]++;
+                    Hit sh = trace(sc, shadowOrigin, sampledLightDir, 0.001f, lightDistance - 0.5f, true, c, ownLeaf); /* :226-241 */
                     float currShadow = sh.hit ? 0.0f : 1.0f;                              /* :244 */
                     /* every sample's BRDF is evaluated and multiplied by currShadow, as the shader does (the product skips the
                      * BRDF of an occluded sample when only the shadowed image is kept: same bits whenever contrib is finite,
@@ -849,6 +858,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     if (!prepare(s, sc)) return -1;
     sc.useWide = s->wide != nullptr && s->nodes != nullptr && s->numWide > 0 && prm.pipeline != 1;
     sc.shadowWalk = s->shadowWalk;
+    sc.ownLeafFirst = sc.useWide && (s->shadowWalk & 2u) == 0u;
     if (sc.useWide && s->walkProfile) {
         sc.wideParent.assign(s->numWide, 0u);
         for (uint32_t i = 0; i < s->numWide; ++i)
@@ -945,6 +955,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.primaryTailRays = tot.primaryOverflow;
     out->walk.occludedRays = tot.walk[0]; out->walk.occludedVisits = tot.walk[1]; out->walk.occludedTests = tot.walk[2];
     out->walk.visibleRays = tot.walk[3]; out->walk.visibleVisits = tot.walk[4]; out->walk.visibleTests = tot.walk[5];
+    out->walk.ownLeafRays = tot.walk[6];
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;

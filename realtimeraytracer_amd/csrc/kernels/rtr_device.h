@@ -74,7 +74,7 @@ struct LocalStats {
     }
 };
 
-struct HitRec { float t, u, v; uint32_t custom, prim; };   /* custom == 0xffffffff: miss */
+struct HitRec { float t, u, v; uint32_t custom, prim; int32_t leaf; };   /* custom == 0xffffffff: miss; leaf: code of the leaf the hit triangle sits in (the shadow rays that leave INTO the surface start their walk there) */
 #define RTR_MISS 0xffffffffu
 
 __device__ __forceinline__ rtr_v3 f4xyz(const float4& a) { return rtr_mk(a.x, a.y, a.z); }
@@ -241,7 +241,7 @@ template <bool ANY, bool STATS, int BLOCK, int LIMIT = 0, int OCT = 8>
 __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict__ stack,
                                       rtr_v3 o, rtr_v3 d, float tmin, float tmax, HitRec& best, LocalStats& st) {
     if (STATS) { st.rays++; if (ANY) st.shadow++; else st.primary++; }
-    best.custom = RTR_MISS; best.prim = RTR_MISS; best.t = tmax; best.u = 0.f; best.v = 0.f;
+    best.custom = RTR_MISS; best.prim = RTR_MISS; best.t = tmax; best.u = 0.f; best.v = 0.f; best.leaf = 0;
     if (!(tmax > tmin)) return false;
     const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
     rtr_v3 ga, gb;                                        /* t(q) = q * ga + gb (rtr_math.h) */
@@ -302,7 +302,7 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
                         if (!found) take = true;
                         else take = t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)));
                         if (take) {
-                            found = true; best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                            found = true; best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr; best.leaf = cur;
                             limit = t;
                             if (ANY) return true;
                         }
@@ -313,7 +313,7 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
         if (sp == 0) break;
         --sp; cur = stack[sp * BLOCK];
     }
-    if (LIMIT > 0 && over) { best.custom = RTR_STACK_OVERFLOW; best.prim = RTR_MISS; best.t = tmax; best.u = 0.f; best.v = 0.f; return false; }
+    if (LIMIT > 0 && over) { best.custom = RTR_STACK_OVERFLOW; best.prim = RTR_MISS; best.t = tmax; best.u = 0.f; best.v = 0.f; best.leaf = 0; return false; }
     return found;
 }
 
@@ -608,7 +608,7 @@ __device__ __forceinline__ rtr_v3 light_sample_pos(const rtr_v3* P, uint32_t s, 
     return rtr_madd(rtr_madd(P[0], rtr_sub(P[1], P[0]), r1), rtr_sub(P[2], P[0]), r2);
 }
 
-/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax, rawDir) (rawDir: dir before normalisation, only its signs are meaningful) answers the
+/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax, rawDir, intoSurface) (rawDir: dir before normalisation, only its signs are meaningful; intoSurface: dot(hitNormal, dir) < 0) answers the
  * shadow query; Policy::kShade == false (counting / emitting the queries) skips the BRDF arithmetic but keeps the exact
  * sequence of queries. */
 template <class Policy, bool STATS>
@@ -652,7 +652,9 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
                 const rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
                 const rtr_v3 sampledLightDir = rtr_normalize(lightVec);
                 const float lightDistance = rtr_length(lightVec);
-                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f, lightVec);
+                /* a ray that leaves its surface point INTO the surface nearly always re-enters the triangle it starts 0.01 above: the any-hit
+                 * kernel tests that triangle's leaf first (k_shadow_trace4's refill).  The directional ray below is only sent with the light in front. */
+                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f, lightVec, rtr_dot(hitNormal, sampledLightDir) < 0.0f);
                 if (Policy::kShade && (wantUnshadowed || !occ)) {
                     const float currShadow = occ ? 0.0f : 1.0f;
                     const rtr_v3 contrib = area_sample_contrib(hitNormal, viewDir, roughness, mSpecular, currDiffuse, lcol, lintensity, pdf, sampledLightDir, lightDistance);
@@ -683,7 +685,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
     /* directional light, raygen.rgen:289-338 */
     const rtr_v3 directLightDir = directional_light_dir();
     if (rtr_dot(hitNormal, directLightDir) <= 0.0f) return;
-    const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f, directLightDir);
+    const bool occ = pol.occluded(shadowOrigin, directLightDir, 10000.0f, directLightDir, false);
     if (Policy::kShade && (wantUnshadowed || wantAnalytic || !occ)) {
         const float currShadow = occ ? 0.0f : 1.0f;
         const rtr_v3 contrib = directional_contrib(hitNormal, viewDir, roughness, mSpecular, currDiffuse);

@@ -35,7 +35,7 @@ template <bool STATS, int STACK>
 struct InlinePolicy {
     static constexpr bool kShade = true;
     const DeviceScene& sc; int32_t* stack; LocalStats& st;
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
+    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3, bool) {
         HitRec h;
         return trace<true, STATS, kBlock>(sc, stack, o, d, 0.001f, tmax, h, st);
     }
@@ -51,7 +51,12 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return v;
 }
 typedef float rtr_f4 __attribute__((ext_vector_type(4)));
-/* one ray out of the queue: direction + far limit, visibility index, and the origin its pixel-sample's rays share */
+/* one ray out of the queue: direction + far limit, visibility index, and the origin its pixel-sample's rays share.
+ * Bit 31 of a ray's slot word (kRayIntoSurface; a visibility index stays below 2^31: rtr_render_batch_limit) says that the ray leaves
+ * its surface point INTO the surface — dot(hitNormal, direction) < 0 — and the w of the pixel-sample's origin record holds the code of the
+ * leaf its hit triangle sits in: k_shadow_trace4 starts such a ray's walk at that leaf (tunable trace_own_leaf).  Every other reader takes the
+ * bit off and walks from the root. */
+constexpr uint32_t kRayIntoSurface = 0x80000000u;
 __device__ __forceinline__ void queue_load(const RayQueue& q, uint32_t ray, rtr_v3& o, rtr_v3& d, float& tmax, uint32_t& slot, uint32_t nt) {
     float4 a;
     if (nt) {
@@ -59,15 +64,17 @@ __device__ __forceinline__ void queue_load(const RayQueue& q, uint32_t ray, rtr_
         a = make_float4(x.x, x.y, x.z, x.w);
         slot = __builtin_nontemporal_load(q.slot + ray);
     } else { a = q.dt[ray]; slot = q.slot[ray]; }
+    slot &= ~kRayIntoSurface;
     const float4 og = q.origin[slot & q.slotMask];
     o = rtr_mk(og.x, og.y, og.z); d = rtr_mk(a.x, a.y, a.z); tmax = a.w;
 }
-__device__ __forceinline__ void queue_store(const RayQueue& q, size_t idx, rtr_v3 o, rtr_v3 d, float tmax, uint32_t slot, uint32_t nt) {
-    if (slot < q.slotStride) q.origin[slot] = make_float4(o.x, o.y, o.z, 0.f);          /* the pixel-sample's first query (query 0: slot = pixel-sample) */
+__device__ __forceinline__ void queue_store(const RayQueue& q, size_t idx, rtr_v3 o, rtr_v3 d, float tmax, uint32_t slot, uint32_t nt, int32_t leaf, bool into) {
+    if (slot < q.slotStride) q.origin[slot] = make_float4(o.x, o.y, o.z, __int_as_float(leaf));          /* the pixel-sample's first query (query 0: slot = pixel-sample) */
+    const uint32_t word = slot | ((into && q.ownLeaf) ? kRayIntoSurface : 0u);
     if (nt) {
         __builtin_nontemporal_store(rtr_f4{d.x, d.y, d.z, tmax}, reinterpret_cast<rtr_f4*>(q.dt + idx));
-        __builtin_nontemporal_store(slot, q.slot + idx);
-    } else { q.dt[idx] = make_float4(d.x, d.y, d.z, tmax); q.slot[idx] = slot; }
+        __builtin_nontemporal_store(word, q.slot + idx);
+    } else { q.dt[idx] = make_float4(d.x, d.y, d.z, tmax); q.slot[idx] = word; }
 }
 
 /* Wave-level active-ray compaction, two phases so the global queue sees ONE atomic per wave
@@ -84,7 +91,7 @@ __device__ __forceinline__ void queue_store(const RayQueue& q, size_t idx, rtr_v
 struct CountPolicy {
     static constexpr bool kShade = false;
     uint32_t n;
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) { ++n; return false; }
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3, bool) { ++n; return false; }
 };
 
 struct EmitPolicy {
@@ -95,13 +102,13 @@ struct EmitPolicy {
      * query of 64 neighbouring pixels) are 64 consecutive bytes, whole 32-B sectors written by one wave from one XCD.  Pixel-major
      * (k * maxRays + j) had every byte of a sector written by another wave, mostly on another XCD, at another time: 522 MB of HBM
      * writes for 24.8 MB of payload (profiles/r02/pmc_roofline.json). */
-    RayQueue queue; lds_word waveOffset; uint32_t base; uint32_t slot;
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3) {
+    RayQueue queue; lds_word waveOffset; uint32_t base; uint32_t slot; int32_t leaf;
+    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3, bool into) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         const uint32_t off = *waveOffset;                      /* same LDS word for the whole wave: broadcast read */
         if (prefix == 0) *waveOffset = off + (uint32_t)__popcll(m);
-        queue_store(queue, (size_t)(base + off + prefix), o, d, tmax, slot, 0u);
+        queue_store(queue, (size_t)(base + off + prefix), o, d, tmax, slot, 0u, leaf, into);
         slot += queue.slotStride;
         return false;
     }
@@ -127,7 +134,7 @@ struct LookupPolicy {
     static constexpr bool kShade = true;
     const uint8_t* vis; uint32_t slot, slotStride;
     uint32_t mask, j;                        /* vis_mask32 of this pixel-sample; queries answered so far */
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3) {
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3, bool) {
         const bool occ = j < 32u ? ((mask >> j) & 1u) != 0u : vis[slot] != 0;
         slot += slotStride; ++j;
         return occ;
@@ -150,14 +157,14 @@ struct CountOctPolicy {
         const unsigned long long v = (unsigned long long)n << ((oct & 3u) * 16u);
         if (oct < 4u) lo += v; else hi += v;
     }
-    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3 raw) { add(raw_octant(raw), 1u); return false; }
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3, float, rtr_v3 raw, bool) { add(raw_octant(raw), 1u); return false; }
 };
 
 struct EmitOctPolicy {
     static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;
-    RayQueue queue; lds_word run; uint32_t slot, nt;         /* run[o]: next queue index of this wave's part of the octant-o run; slot as in EmitPolicy */
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw) {
+    RayQueue queue; lds_word run; uint32_t slot, nt; int32_t leaf;         /* run[o]: next queue index of this wave's part of the octant-o run; slot as in EmitPolicy; leaf: of the pixel-sample's hit triangle */
+    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw, bool into) {
         const uint32_t oct = raw_octant(raw);
         unsigned long long rem = __ballot(1);
         while (rem != 0ull) {                            /* one round per octant present among the lanes of this emission step */
@@ -167,7 +174,7 @@ struct EmitOctPolicy {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
                 const uint32_t pos = run[oo];
                 if (prefix == 0) run[oo] = pos + (uint32_t)__popcll(mo);
-                queue_store(queue, (size_t)(pos + prefix), o, d, tmax, slot, nt);
+                queue_store(queue, (size_t)(pos + prefix), o, d, tmax, slot, nt, leaf, into);
             }
             rem &= ~mo;
         }
@@ -219,7 +226,7 @@ constexpr int kPrimBlock = RTR_PRIMARY_BLOCK;
 static_assert(kPrimBlock % 64 == 0 && kPrimBlock >= 64 && kPrimBlock <= kBlock && kBlock % kPrimBlock == 0,
               "RTR_PRIMARY_BLOCK: a multiple of 64 that divides the 256-lane tile group (the launcher's grid is blocks * (kBlock / kPrimBlock))");
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
+__global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf,
                                                     Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
     __shared__ int32_t s_stack[16 * kPrimBlock];
     int32_t* stack = s_stack + threadIdx.x;
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBat
     else {
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
+        hitLeaf[k] = h.leaf;
     }
     if (STATS) st.flush(stats);
 }
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBat
  * form counts a node visit / triangle test for every lane of the visited mask, and the oracle restates this walk tile by tile
  * (oracle_render.cpp: trace_packet) for the counters to be held equal. */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, Counters* stats, uint32_t planeBlocks) {
+__global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf, Counters* stats, uint32_t planeBlocks) {
     __shared__ uint4 s_stack[kBlock / 64][64];           /* per wave: {child code, mask low, mask high, -} */
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t plane = blockIdx.x / planeBlocks;                 /* frame of the batch * spp + sample */
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, Frame
     const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
     rtr_v3 ga, gb;
     rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
-    HitRec best; best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+    HitRec best; best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS; best.leaf = 0;
     const uint4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
     uint32_t sp = 0;
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, Frame
                         const uint32_t cu = __float_as_uint(q0.w), pr = __float_as_uint(q1.w);
                         if (!(__float_as_uint(q2.w) & 1u) || alpha_pass<STATS>(sc, cu, pr, u, v, st)) {
                             if (t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)))) {
-                                best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                                best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr; best.leaf = cur;
                             }
                         }
                     }
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, Frame
         const size_t k = (size_t)plane * planeBlocks * kBlock + q;
         hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim));
         hitCustom[k] = best.custom;
+        hitLeaf[k] = best.leaf;
     }
     if (STATS) st.flush(stats);
 }
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, Frame
 /* Re-traces the pixel-samples the primary kernels abandoned: BVH2 walk with a full-depth stack in global memory (no LDS, so it
  * can always run).  STATS: the counting form (the ray itself was counted by the kernel that abandoned it). */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom,
+__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf,
                                                          const uint32_t* __restrict__ redoCount, const uint32_t* __restrict__ redoList,
                                                          int32_t* __restrict__ spill, uint32_t planeStride, Counters* stats) {
     const uint32_t n = *redoCount;
@@ -393,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBa
         if (STATS) { st.rays--; st.primary--; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
+        hitLeaf[k] = h.leaf;
     }
     if (STATS) st.flush(stats);
 }
@@ -420,7 +430,7 @@ __device__ __forceinline__ uint32_t wave_total(uint32_t v) {
  * of the hit records k_primary wrote (its grid x 256). */
 constexpr uint32_t kGenBlock = 1024;
 __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, FrameBatch fb, const float4* hitTuvp,
-                                                          const uint32_t* hitCustom, RayQueue queue, uint32_t* count, uint32_t planeStride) {
+                                                          const uint32_t* hitCustom, const int32_t* hitLeaf, RayQueue queue, uint32_t* count, uint32_t planeStride) {
     __shared__ uint32_t s_off[kGenBlock / 64], s_tot[kGenBlock / 64], s_base;
     uint32_t q;
     const uint32_t frame = batch_frame(blockIdx.x * kGenBlock + threadIdx.x, planeStride, q);
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, FrameB
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (plane0 + i) * planeStride + q;
-        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k};
+        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k, hitLeaf[k]};
         if (single) {
             if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
@@ -503,7 +513,7 @@ constexpr uint32_t kGenOctBlock = RTR_GEN_OCT_BLOCK;     /* two workgroups per C
 #else
 #define RTR_GEN_OCT_ATTR
 #endif
-__global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom,
+__global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom, const int32_t* hitLeaf,
                                                               RayQueue queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
                                                               uint32_t listStride, uint32_t kBatch, uint32_t nt) {
     constexpr uint32_t kWaves = kGenOctBlock / 64;
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
     if (!live || mine == 0) return;
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (plane0 + i) * planeStride + q;
-        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, nt};
+        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, nt, hitLeaf[k]};
         if (single) {
             if (surf0) light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
         } else {
@@ -1056,6 +1066,8 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (cur == kDone && prefix < avail) {
                         rayIndex = batchPos + prefix;
+                        bool into = false;                               /* the ray leaves its surface point into the surface: its own triangle's leaf first */
+                        int32_t ownLeaf = 0;
 #if RTR_REFILL_LDS
                         {   /* queue_load() through the addresses kept in LDS */
                             const global_f4 qdt = (global_f4)rc.dt, qorg = (global_f4)rc.origin;
@@ -1063,11 +1075,16 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                             rtr_f4 a;
                             if (octForms & 2u) { a = __builtin_nontemporal_load(qdt + rayIndex); slot = __builtin_nontemporal_load(qslot + rayIndex); }
                             else { a = qdt[rayIndex]; slot = qslot[rayIndex]; }
+                            into = (slot & kRayIntoSurface) != 0u;
+                            slot &= ~kRayIntoSurface;
                             const rtr_f4 og = qorg[slot & rc.slotMask];
                             o = rtr_mk(og.x, og.y, og.z); d = rtr_mk(a.x, a.y, a.z); tmax = a.w;
+                            ownLeaf = __float_as_int(og.w);
                         }
 #else
+                        into = (queue.slot[rayIndex] & kRayIntoSurface) != 0u;
                         queue_load(queue, rayIndex, o, d, tmax, slot, octForms & 2u);
+                        ownLeaf = __float_as_int(queue.origin[slot & queue.slotMask].w);
 #endif
                         if (STATS) { st.rays++; st.shadow++; }
                         if (!(tmax > tmin)) {
@@ -1081,6 +1098,12 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
                             rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);
 #endif
                             cur = 0; sp = lds; res = 0u;
+                            /* A ray that leaves its surface point INTO the surface (marked by the queue build: dot(hitNormal, direction) < 0) starts
+                             * 0.01 above the triangle it comes from and nearly always re-enters it a hair's breadth on: 44 % of the bench frame's
+                             * rays.  Its walk starts at that triangle's LEAF, the root waiting on the stack — an any-hit answer does not depend on
+                             * the order triangles are met in — so the leaf phase answers it without a single record visit (14.3 -> 10.6 visits
+                             * per ray over the frame; the oracle restates the rule: trace_wide's firstLeaf). */
+                            if (into) { sp = lds + kTraceBlock; *sp = 0; cur = ownLeaf; }
                         }
                     }
                     batchPos += (nIdle < avail) ? nIdle : avail;
@@ -1165,7 +1188,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
  * stacked in slot order, ALL triangles of a leaf tested (min over (t, customIndex, primitiveID), as trace()), RTR_WIDE_STACK = 16 LDS
  * entries, beyond which the ray goes to the redo list and k_primary_tail walks it over the BVH2 from scratch (both parts counted). */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, Counters* stats,
+__global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf, Counters* stats,
                                                      uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
     __shared__ int32_t s_stack[RTR_WIDE_STACK * kBlock];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1185,7 +1208,7 @@ __global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch 
     rtr_ray_grid_centre(o, idir, sc.grid->origin, sc.grid->scale, sc.grid->wideCentreXY, sc.grid->wideCentreZ, &ga, &gb);
     const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes4, 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t triBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, 0, 0xffffffff, 0x00020000);
-    HitRec best; best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+    HitRec best; best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS; best.leaf = 0;
     int32_t* const lds = s_stack + threadIdx.x;
     int sp = 0;                                          /* entries held: lds[0 .. sp-1] at stride kBlock */
     int32_t cur = 0;
@@ -1228,7 +1251,7 @@ __global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch 
                     const uint32_t cu = __float_as_uint(a0.w), pr = __float_as_uint(a1.w);
                     if ((__float_as_uint(a2.w) & 1u) && !alpha_pass<STATS>(sc, cu, pr, u, v, st)) continue;
                     if (t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)))) {
-                        best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                        best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr; best.leaf = cur;
                     }
                 }
             }
@@ -1238,7 +1261,7 @@ __global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch 
     }
     const size_t k = (size_t)plane * planeBlocks * kBlock + q;
     if (over) redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k;
-    else { hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[k] = best.custom; }
+    else { hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[k] = best.custom; hitLeaf[k] = best.leaf; }
     if (STATS) st.flush(stats);
 }
 
@@ -1285,7 +1308,7 @@ __device__ __forceinline__ void inner_nodes2(const __amdgpu_buffer_rsrc_t nodeBu
 }
 
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_primary_persist(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_primary_persist(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf,
                                                          Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t* cursors,
                                                          uint32_t planeStride, uint32_t kBatch, uint32_t kRefill, uint32_t kInnerMin) {
     __shared__ int32_t s_stack[(STACK + 1 + 1) * kBlock];    /* slot 0 holds kDone for good; one guard entry above the stack (inner_nodes2) */
@@ -1302,7 +1325,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     int32_t* sp = lds;
     const rtr_v3 o = rtr_ld3(ra.cam.position);
     rtr_v3 d = rtr_mk(0, 0, 0), ga = rtr_mk(0, 0, 0), gb = rtr_mk(0, 0, 0);
-    HitRec best; best.t = 0.f; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+    HitRec best; best.t = 0.f; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS; best.leaf = 0;
     uint32_t item = 0, res = kResNone;
     const float tmin = 0.001f, tmax = 10000.0f;
     const __amdgpu_buffer_rsrc_t nodeBuf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes, 0, 0xffffffff, 0x00020000);
@@ -1315,7 +1338,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         if (nIdle >= kRefill || nIdle == 64u) {
             if (cur == kDone && res != kResNone) {
                 if (res == 2u) redoList[atomicAdd(redoCount, 1u)] = item;              /* finished by k_primary_tail */
-                else { hitTuvp[item] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[item] = best.custom; }
+                else { hitTuvp[item] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[item] = best.custom; hitLeaf[item] = best.leaf; }
                 res = kResNone;
             }
             if (!exhausted) {
@@ -1348,7 +1371,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             if (STATS) { st.rays++; st.primary++; }
                             const rtr_v3 idir = rtr_mk(rtr_safe_rcp_dir(d.x), rtr_safe_rcp_dir(d.y), rtr_safe_rcp_dir(d.z));
                             rtr_ray_grid(o, idir, sc.grid->origin, sc.grid->scale, &ga, &gb);
-                            best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS;
+                            best.t = tmax; best.u = 0.f; best.v = 0.f; best.custom = RTR_MISS; best.prim = RTR_MISS; best.leaf = 0;
                             cur = 0; sp = lds; res = 0u;
                         }
                     }
@@ -1382,6 +1405,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         /* ---- leaves: every triangle, keep the closest (same acceptance and tie rule as trace()) ---- */
         if (cur < 0 && cur != kDone) {
+            const int32_t leafCode = cur;
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             for (uint32_t i = 0; i < cnt; ++i) {
@@ -1397,7 +1421,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     const uint32_t cu = r0.w, pr = r1.w;
                     if ((r2.w & 1u) && !alpha_pass<STATS>(sc, cu, pr, u, v, st)) continue;
                     if (t < best.t || (t == best.t && (cu < best.custom || (cu == best.custom && pr < best.prim)))) {
-                        best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr;
+                        best.t = t; best.u = u; best.v = v; best.custom = cu; best.prim = pr; best.leaf = leafCode;
                     }
                 }
             }
@@ -1717,7 +1741,7 @@ const TunableField kTunables[] = {
     {"primary_inner_min", &Tunables::primary_inner_min, 0u, 63u}, {"primary_wgs_per_cu", &Tunables::primary_wgs_per_cu, 1u, 8u},
     {"trace_bvh4", &Tunables::trace_bvh4, 0u, 1u}, {"trace_batch", &Tunables::trace_batch, 0u, 1u << 20}, {"trace_binned", &Tunables::trace_binned, 0u, 2u},
     {"queue_nt", &Tunables::queue_nt, 0u, 3u}, {"trace_wgs_per_cu", &Tunables::trace_wgs_per_cu, 0u, 8u}, {"trace_refill", &Tunables::trace_refill, 1u, 64u},
-    {"trace_inner_min", &Tunables::trace_inner_min, 0u, 63u}, {"trace_octant_forms", &Tunables::trace_octant_forms, 0u, 1u},
+    {"trace_inner_min", &Tunables::trace_inner_min, 0u, 63u}, {"trace_octant_forms", &Tunables::trace_octant_forms, 0u, 1u}, {"trace_own_leaf", &Tunables::trace_own_leaf, 0u, 1u},
     {"trace_top_nodes", &Tunables::trace_top_nodes, 0u, 0xffffffffu}, {"resolve_row_waves", &Tunables::resolve_row_waves, 0u, 1u}, {"resolve_compact", &Tunables::resolve_compact, 0u, 1u}, {"split_priorities", &Tunables::split_priorities, 0u, 1u},
 };
 }  // namespace
@@ -1809,22 +1833,22 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
         if (pblocks > pneeded) pblocks = pneeded;
         if (pblocks == 0) pblocks = 1;
-        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
-        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
     } else if (tun.primary_wide && sc.nodes4) {
         /* one camera ray per lane over the 4-wide view (not the default); rays that outgrow its 16 entries go to k_primary_tail like k_primary's */
-        if (stats) hipLaunchKernelGGL((k_primary4<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
-        else hipLaunchKernelGGL((k_primary4<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+        if (stats) hipLaunchKernelGGL((k_primary4<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+        else hipLaunchKernelGGL((k_primary4<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
     } else if (tun.primary_packet) {
         /* a tile's camera rays walk the tree as one packet (no ray is ever left to the tail kernel: it is not launched); not the default */
         packet = true;
-        if (stats) hipLaunchKernelGGL((k_primary_packet<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, blocks);
-        else hipLaunchKernelGGL((k_primary_packet<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, blocks);
-    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
+        if (stats) hipLaunchKernelGGL((k_primary_packet<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, blocks);
+        else hipLaunchKernelGGL((k_primary_packet<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, blocks);
+    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
     if (!packet) {
-        if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
-        else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+        if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+        else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
     }
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
@@ -1845,8 +1869,10 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
                         (size_t)ws.capRays / kBatch / kQueueRegions + genOctBlocks <= ws.listStride &&
                         (binMode == 1u || (binMode == 2u && maxRaysQ >= kBinnedMinRays && sc.numNodes4 >= kBinnedMinNodes));
     const uint32_t kNtQueue = tun.queue_nt;          /* bit 0: any-hit kernel reads the queue past the caches (default); bit 1: the queue-build kernel writes it so (slower, see queue_load) */
-    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
-    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue, ws.queueCount, blocks * kBlock);
+    RayQueue rq = ws.rayQueue;
+    rq.ownLeaf = (wide && tun.trace_own_leaf) ? 1u : 0u;          /* only the 4-wide any-hit kernel starts a walk at a leaf (the 2-wide comparison kernel takes the mark off) */
+    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, rq, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
+    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, rq, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
     /* persistent waves: as many workgroups as stay resident (17 KiB of LDS stack + 2.5 KiB of tree top per workgroup -> 8 per CU,
      * the 32-wave hardware maximum), each pulling batches until the queue is empty */

@@ -1041,6 +1041,36 @@ def test_split_render_1080p_against_the_unsplit_frame(gpu_ctx, scene_cache):
         o.close()
 
 
+@pytest.mark.parametrize("own_leaf", [1, 0])
+@pytest.mark.parametrize("name", ["sponza_class", "sponza_mixed", "textured_room", "cornell_box"])
+def test_own_leaf_start_of_the_shadow_walk_matches_the_oracle(gpu_ctx, oracle, scene_cache, name, own_leaf):
+    """A shadow ray that leaves its surface point INTO the surface starts its walk at the leaf of the triangle it comes from
+    (k_shadow_trace4's refill; tunable trace_own_leaf, default on): framebuffer bytes AND the any-hit work counters — record visits,
+    triangle tests, trips and lanes of both loops — equal the oracle's with the rule on and with it off, over two frames (other seeds)."""
+    W, H = 320, 184
+    s = getattr(scenes, name)(W, H)
+    scene = api.Scene(gpu_ctx, s.desc)
+    bvh = scene.export_bvh()
+    c = api.Context(0)
+    c.set_tunable("trace_own_leaf", own_leaf)
+    frame = api.Frame(c, W, H)
+    try:
+        for f in (0, 5):
+            p = api.make_params(W, H, spp=2, shadow_rays=3, collect_stats=1, pipeline=2)
+            api.render(scene, s.camera, s.scene_info(f), p, frame)
+            ref = oracle.render(s.desc, s.camera, s.scene_info(f), p, bvh=bvh, threads=8, own_leaf=bool(own_leaf))
+            _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"{name} own_leaf={own_leaf} frame {f}")
+            g, o = frame.stats(), ref.stats
+            for fld in ("numRays", "numShadowRays", "numShadowNodeVisits", "numShadowTriTests", "numNodeVisits", "numTriTests", "numAlphaTests", "numTexFetches", "shadowTailRays"):
+                assert getattr(g, fld) == getattr(o, fld), f"{name} own_leaf={own_leaf}: counter {fld}: gpu {getattr(g, fld)} != oracle {getattr(o, fld)}"
+            assert (ref.walk.ownLeafRays > 0) == bool(own_leaf)
+            # the timed form writes the same bytes
+            api.render(scene, s.camera, s.scene_info(f), api.make_params(W, H, spp=2, shadow_rays=3, pipeline=2), frame)
+            _assert_same(frame.download(), ref.images[A.IMAGE_SHADOWED], f"{name} own_leaf={own_leaf} frame {f}, timed form")
+    finally:
+        frame.close(); c.close(); scene.close()
+
+
 @pytest.mark.parametrize("case", ["cornell_s1", "cornell_s3_spp3", "cornell_s20", "cornell_s40", "sponza_class", "sponza_mixed", "textured_room"])
 def test_resolve_compact_and_per_pixel_forms_match_the_oracle(gpu_ctx, oracle, scene_cache, case):
     """k_resolve_compact (the framebuffer-only launch's default: the BRDF of a tile's VISIBLE samples dealt out densely over the wave's
@@ -1093,7 +1123,7 @@ def test_tunables_belong_to_the_context_and_change_no_pixel(gpu_ctx, scene_cache
     assert c.get_tunable("trace_refill") == 33 and gpu_ctx.get_tunable("trace_refill") == 20
     fr = api.Frame(c, W, H)
     for name, value in (("trace_binned", 1), ("trace_batch", 64), ("trace_wgs_per_cu", 3), ("trace_inner_min", 5), ("trace_octant_forms", 0),
-                        ("trace_top_nodes", 7), ("queue_nt", 3), ("resolve_row_waves", 1), ("resolve_compact", 0), ("primary_packet", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
+                        ("trace_top_nodes", 7), ("trace_own_leaf", 0), ("queue_nt", 3), ("resolve_row_waves", 1), ("resolve_compact", 0), ("primary_packet", 1), ("primary_persist", 1), ("trace_bvh4", 0)):
         c.set_tunable(name, value)
         assert c.get_tunable(name) == value
         api.render(scene, s.camera, s.scene_info(0), p, fr)

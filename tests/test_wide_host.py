@@ -130,3 +130,28 @@ def test_reinsertion_keeps_a_valid_tree(scene_cache, monkeypatch):
     assert st.numTriangles == st0.numTriangles and st.maxDepth <= 64
     assert st.sahCost <= st0.sahCost * 1.05                 # never much worse; on mixed-size assets better
     _check_wide(api.host_build_bvh_wide(s.desc))
+
+
+@pytest.mark.parametrize("name", ["sponza_class", "bunny_class", "cornell_box"])
+def test_shadow_rays_into_the_surface_start_at_their_own_leaf(name):
+    """Round 5: a shadow ray that leaves its surface point INTO the surface (dot(hitNormal, direction) < 0) tests the leaf of the triangle
+    it starts on first, then walks from the root (oracle trace_wide's firstLeaf = k_shadow_trace4's refill).  It cannot change a pixel —
+    an any-hit answer does not depend on the order triangles are met in — it only makes the walk shorter: on the Sponza-class frame four
+    rays in nine start that way and the record visits per ray fall by a quarter."""
+    from oracle import oracle_py as O
+    W, H = 160, 96
+    s = getattr(scenes, name)(W, H)
+    p = api.make_params(W, H, spp=1, shadow_rays=3, collect_stats=1)
+    bvh = api.host_build_bvh_wide(s.desc)
+    on = O.render(s.desc, s.camera, s.scene_info(0), p, bvh=bvh, threads=8)
+    off = O.render(s.desc, s.camera, s.scene_info(0), p, bvh=bvh, threads=8, own_leaf=False)
+    brute = O.render(s.desc, s.camera, s.scene_info(0), p, bvh=None, threads=8)
+    assert np.array_equal(on.images[A.IMAGE_SHADOWED], off.images[A.IMAGE_SHADOWED]) and np.array_equal(on.images[A.IMAGE_SHADOWED], brute.images[A.IMAGE_SHADOWED])
+    assert on.stats.numShadowRays == off.stats.numShadowRays == brute.stats.numShadowRays and on.stats.numRays == off.stats.numRays
+    assert off.walk.ownLeafRays == 0 and 0 < on.walk.ownLeafRays < on.stats.numShadowRays
+    assert on.walk.occludedRays == off.walk.occludedRays and on.walk.visibleRays == off.walk.visibleRays
+    assert on.stats.numShadowNodeVisits < off.stats.numShadowNodeVisits
+    if name == "sponza_class":
+        assert on.walk.ownLeafRays > 0.35 * on.stats.numShadowRays and on.stats.numShadowNodeVisits < 0.8 * off.stats.numShadowNodeVisits
+    # a visible ray is never made cheaper by it (every box it hits must still be opened), only dearer by its own leaf's triangles
+    assert on.walk.visibleVisits == off.walk.visibleVisits and on.walk.visibleTests >= off.walk.visibleTests
