@@ -43,7 +43,7 @@ typedef struct oracle_scene {
      * BVH2 (k_primary4). */
     uint32_t primaryPackets;
     /* How a shadow ray is walked over the wide view — it decides the work counters, never the answer (any-hit is a pure function of ray
-     * and triangles).  The product's default (0): a ray that leaves its surface point INTO the surface — dot(hitNormal, direction) < 0,
+     * and triangles).  The product's default (0): a ray that leaves its surface point INTO the surface — dot(hitNormal, light sample - hitPoint) < 0,
      * the area-light samples of raygen.rgen:206-241 only — first tests the triangles of the LEAF its own hit triangle sits in (it starts
      * 0.01 above that triangle and nearly always re-enters it), then walks from the root; at a record the nearest hit child is entered
      * first (strict <, ties to the lower slot), the others stacked in slot order.

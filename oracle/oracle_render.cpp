@@ -691,7 +691,7 @@ PixelOut shade_pixel(const Scene& sc, const RtrCameraData& cam, const RtrSceneIn
                     rtr_v3 lightVec = rtr_sub(lightSamplePos, hitPoint);
                     rtr_v3 sampledLightDir = rtr_normalize(lightVec);                     /* :221 */
                     float lightDistance = rtr_length(lightVec);                           /* :222 */
-                    const int32_t ownLeaf = (sc.ownLeafFirst && rtr_dot(hitNormal, sampledLightDir) < 0.0f) ? h.leaf : 0;
+                    const int32_t ownLeaf = (sc.ownLeafFirst && rtr_dot(hitNormal, lightVec) < 0.0f) ? h.leaf : 0;      /* the un-normalised direction: what the queue build's count pass has */
                     if (ownLeaf) c.walk[6]++;
                     Hit sh = trace(sc, shadowOrigin, sampledLightDir, 0.001f, lightDistance - 0.5f, true, c, ownLeaf); /* :226-241 */
                     float currShadow = sh.hit ? 0.0f : 1.0f;                              /* :244 */

@@ -608,9 +608,12 @@ __device__ __forceinline__ rtr_v3 light_sample_pos(const rtr_v3* P, uint32_t s, 
     return rtr_madd(rtr_madd(P[0], rtr_sub(P[1], P[0]), r1), rtr_sub(P[2], P[0]), r2);
 }
 
-/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax, rawDir, intoSurface) (rawDir: dir before normalisation, only its signs are meaningful; intoSurface: dot(hitNormal, dir) < 0) answers the
+/* The light loops of raygen.rgen:165-338 for one shaded surface point.  Policy::occluded(origin, dir, tmax, rawDir, intoSurface) (rawDir: dir before normalisation, only its signs are meaningful; intoSurface: dot(hitNormal, rawDir) < 0) answers the
  * shadow query; Policy::kShade == false (counting / emitting the queries) skips the BRDF arithmetic but keeps the exact
  * sequence of queries. */
+#ifndef RTR_INTO_EXPR
+#define RTR_INTO_EXPR (rtr_dot(hitNormal, lightVec) < 0.0f)
+#endif
 template <class Policy, bool STATS>
 __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderArgs& ra, uint32_t px, uint32_t py,
                                             const Surface& sf, uint32_t want, Accum& o, Policy& pol, LocalStats& st) {
@@ -654,7 +657,7 @@ __device__ __forceinline__ void light_loops(const DeviceScene& sc, const RenderA
                 const float lightDistance = rtr_length(lightVec);
                 /* a ray that leaves its surface point INTO the surface nearly always re-enters the triangle it starts 0.01 above: the any-hit
                  * kernel tests that triangle's leaf first (k_shadow_trace4's refill).  The directional ray below is only sent with the light in front. */
-                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f, lightVec, rtr_dot(hitNormal, sampledLightDir) < 0.0f);
+                const bool occ = pol.occluded(shadowOrigin, sampledLightDir, lightDistance - 0.5f, lightVec, RTR_INTO_EXPR);
                 if (Policy::kShade && (wantUnshadowed || !occ)) {
                     const float currShadow = occ ? 0.0f : 1.0f;
                     const rtr_v3 contrib = area_sample_contrib(hitNormal, viewDir, roughness, mSpecular, currDiffuse, lcol, lintensity, pdf, sampledLightDir, lightDistance);

@@ -39,7 +39,7 @@ constexpr size_t kSpillInts = (size_t)64 * 64 * 256;     /* full-depth stacks of
 struct RayQueue {
     float4*   dt = nullptr;          /* per ray: direction xyz, tmax */
     uint32_t* slot = nullptr;        /* per ray: visibility index = query * slotStride + pixel-sample */
-    float4*   origin = nullptr;      /* per pixel-sample: origin of its shadow rays (hit point + 0.01 normal) */
+    float4*   origin = nullptr;      /* per pixel-sample: origin of its shadow rays (hit point + 0.01 normal; the queue build), w = code of the leaf its hit triangle sits in (the camera-ray kernel) */
     uint32_t  slotStride = 0;        /* power of two >= pixel-sample slots of the frame */
     uint32_t  slotMask = 0;          /* slotStride - 1 */
     uint32_t  ownLeaf = 0;           /* 1: rays that leave INTO their surface are marked (bit 31 of the slot word) and start at their own triangle's leaf (tunable trace_own_leaf) */
@@ -50,7 +50,6 @@ struct RayQueue {
 struct Workspace {
     float4*   hitTuvp = nullptr;     /* per (pixel,sample): t,u,v,bits(primitiveID) */
     uint32_t* hitCustom = nullptr;   /* per (pixel,sample): customIndex or RTR_MISS */
-    int32_t*  hitLeaf = nullptr;     /* per (pixel,sample): code of the leaf the hit triangle sits in */
     RayQueue  rayQueue;              /* the queued shadow rays */
     uint8_t*  vis = nullptr;         /* per slot (query-major planes, rayQueue.slotStride apart): 1 = occluded */
     uint32_t  visFill = 1;           /* what the array is pre-filled with before every launch (the commoner outcome); the any-hit kernel stores the other */

@@ -68,8 +68,16 @@ __device__ __forceinline__ void queue_load(const RayQueue& q, uint32_t ray, rtr_
     const float4 og = q.origin[slot & q.slotMask];
     o = rtr_mk(og.x, og.y, og.z); d = rtr_mk(a.x, a.y, a.z); tmax = a.w;
 }
-__device__ __forceinline__ void queue_store(const RayQueue& q, size_t idx, rtr_v3 o, rtr_v3 d, float tmax, uint32_t slot, uint32_t nt, int32_t leaf, bool into) {
-    if (slot < q.slotStride) q.origin[slot] = make_float4(o.x, o.y, o.z, __int_as_float(leaf));          /* the pixel-sample's first query (query 0: slot = pixel-sample) */
+/* the record a pixel-sample's rays share: their origin (hit point + 0.01 normal: light_loops' shadowOrigin, the same expression), written
+ * by the queue build once per pixel-sample ahead of its emission loops, and in w the code of the leaf its hit triangle sits in, written by
+ * the camera-ray kernel that found the hit (the queue build never sees it: one value less to keep in a kernel capped at 64 registers) */
+__device__ __forceinline__ void queue_store_origin(const RayQueue& q, size_t k, rtr_v3 hitPoint, rtr_v3 hitNormal) {
+    const rtr_v3 o = rtr_madd(hitPoint, hitNormal, 0.01f);
+    float* p = reinterpret_cast<float*>(q.origin + k);
+    p[0] = o.x; p[1] = o.y; p[2] = o.z;
+}
+__device__ __forceinline__ void origin_leaf_store(float4* rayOrigin, size_t k, int32_t leaf) { reinterpret_cast<int32_t*>(rayOrigin + k)[3] = leaf; }
+__device__ __forceinline__ void queue_store(const RayQueue& q, size_t idx, rtr_v3 d, float tmax, uint32_t slot, uint32_t nt, bool into) {
     const uint32_t word = slot | ((into && q.ownLeaf) ? kRayIntoSurface : 0u);
     if (nt) {
         __builtin_nontemporal_store(rtr_f4{d.x, d.y, d.z, tmax}, reinterpret_cast<rtr_f4*>(q.dt + idx));
@@ -102,13 +110,13 @@ struct EmitPolicy {
      * query of 64 neighbouring pixels) are 64 consecutive bytes, whole 32-B sectors written by one wave from one XCD.  Pixel-major
      * (k * maxRays + j) had every byte of a sector written by another wave, mostly on another XCD, at another time: 522 MB of HBM
      * writes for 24.8 MB of payload (profiles/r02/pmc_roofline.json). */
-    RayQueue queue; lds_word waveOffset; uint32_t base; uint32_t slot; int32_t leaf;
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3, bool into) {
+    RayQueue queue; lds_word waveOffset; uint32_t base; uint32_t slot;
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3 d, float tmax, rtr_v3, bool into) {
         const unsigned long long m = __ballot(1);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         const uint32_t off = *waveOffset;                      /* same LDS word for the whole wave: broadcast read */
         if (prefix == 0) *waveOffset = off + (uint32_t)__popcll(m);
-        queue_store(queue, (size_t)(base + off + prefix), o, d, tmax, slot, 0u, leaf, into);
+        queue_store(queue, (size_t)(base + off + prefix), d, tmax, slot, 0u, into);
         slot += queue.slotStride;
         return false;
     }
@@ -163,8 +171,8 @@ struct CountOctPolicy {
 struct EmitOctPolicy {
     static constexpr bool kShade = false;
     typedef volatile __attribute__((address_space(3))) uint32_t* lds_word;
-    RayQueue queue; lds_word run; uint32_t slot, nt; int32_t leaf;         /* run[o]: next queue index of this wave's part of the octant-o run; slot as in EmitPolicy; leaf: of the pixel-sample's hit triangle */
-    __device__ __forceinline__ bool occluded(rtr_v3 o, rtr_v3 d, float tmax, rtr_v3 raw, bool into) {
+    RayQueue queue; lds_word run; uint32_t slot, nt;         /* run[o]: next queue index of this wave's part of the octant-o run; slot as in EmitPolicy */
+    __device__ __forceinline__ bool occluded(rtr_v3, rtr_v3 d, float tmax, rtr_v3 raw, bool into) {
         const uint32_t oct = raw_octant(raw);
         unsigned long long rem = __ballot(1);
         while (rem != 0ull) {                            /* one round per octant present among the lanes of this emission step */
@@ -174,7 +182,7 @@ struct EmitOctPolicy {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
                 const uint32_t pos = run[oo];
                 if (prefix == 0) run[oo] = pos + (uint32_t)__popcll(mo);
-                queue_store(queue, (size_t)(pos + prefix), o, d, tmax, slot, nt, leaf, into);
+                queue_store(queue, (size_t)(pos + prefix), d, tmax, slot, nt, into);
             }
             rem &= ~mo;
         }
@@ -226,7 +234,7 @@ constexpr int kPrimBlock = RTR_PRIMARY_BLOCK;
 static_assert(kPrimBlock % 64 == 0 && kPrimBlock >= 64 && kPrimBlock <= kBlock && kBlock % kPrimBlock == 0,
               "RTR_PRIMARY_BLOCK: a multiple of 64 that divides the 256-lane tile group (the launcher's grid is blocks * (kBlock / kPrimBlock))");
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf,
+__global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, float4* rayOrigin,
                                                     Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
     __shared__ int32_t s_stack[16 * kPrimBlock];
     int32_t* stack = s_stack + threadIdx.x;
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBat
     else {
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
-        hitLeaf[k] = h.leaf;
+        origin_leaf_store(rayOrigin, k, h.leaf);
     }
     if (STATS) st.flush(stats);
 }
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(kPrimBlock) void k_primary(DeviceScene sc, FrameBat
  * form counts a node visit / triangle test for every lane of the visited mask, and the oracle restates this walk tile by tile
  * (oracle_render.cpp: trace_packet) for the counters to be held equal. */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf, Counters* stats, uint32_t planeBlocks) {
+__global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, float4* rayOrigin, Counters* stats, uint32_t planeBlocks) {
     __shared__ uint4 s_stack[kBlock / 64][64];           /* per wave: {child code, mask low, mask high, -} */
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t plane = blockIdx.x / planeBlocks;                 /* frame of the batch * spp + sample */
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, Frame
         const size_t k = (size_t)plane * planeBlocks * kBlock + q;
         hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim));
         hitCustom[k] = best.custom;
-        hitLeaf[k] = best.leaf;
+        origin_leaf_store(rayOrigin, k, best.leaf);
     }
     if (STATS) st.flush(stats);
 }
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(DeviceScene sc, Frame
 /* Re-traces the pixel-samples the primary kernels abandoned: BVH2 walk with a full-depth stack in global memory (no LDS, so it
  * can always run).  STATS: the counting form (the ray itself was counted by the kernel that abandoned it). */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf,
+__global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, float4* rayOrigin,
                                                          const uint32_t* __restrict__ redoCount, const uint32_t* __restrict__ redoList,
                                                          int32_t* __restrict__ spill, uint32_t planeStride, Counters* stats) {
     const uint32_t n = *redoCount;
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_tail(DeviceScene sc, FrameBa
         if (STATS) { st.rays--; st.primary--; }
         hitTuvp[k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         hitCustom[k] = h.custom;
-        hitLeaf[k] = h.leaf;
+        origin_leaf_store(rayOrigin, k, h.leaf);
     }
     if (STATS) st.flush(stats);
 }
@@ -430,7 +438,7 @@ __device__ __forceinline__ uint32_t wave_total(uint32_t v) {
  * of the hit records k_primary wrote (its grid x 256). */
 constexpr uint32_t kGenBlock = 1024;
 __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, FrameBatch fb, const float4* hitTuvp,
-                                                          const uint32_t* hitCustom, const int32_t* hitLeaf, RayQueue queue, uint32_t* count, uint32_t planeStride) {
+                                                          const uint32_t* hitCustom, RayQueue queue, uint32_t* count, uint32_t planeStride) {
     __shared__ uint32_t s_off[kGenBlock / 64], s_tot[kGenBlock / 64], s_base;
     uint32_t q;
     const uint32_t frame = batch_frame(blockIdx.x * kGenBlock + threadIdx.x, planeStride, q);
@@ -479,15 +487,17 @@ __global__ __launch_bounds__(kGenBlock) void k_shadow_gen(DeviceScene sc, FrameB
     /* phase 2: emit */
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (plane0 + i) * planeStride + q;
-        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k, hitLeaf[k]};
+        EmitPolicy pol{queue, (EmitPolicy::lds_word)&s_off[wave], base, (uint32_t)k};
         if (single) {
-            if (surf0) light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
+            if (surf0) { queue_store_origin(queue, k, sf0.hitPoint, sf0.hitNormal); light_loops<EmitPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st); }
         } else {
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
-            if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st))
+            if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st)) {
+                queue_store_origin(queue, k, sf.hitPoint, sf.hitNormal);
                 light_loops<EmitPolicy, false>(sc, ra, px, py, sf, 0u, acc, pol, st);
+            }
         }
     }
 }
@@ -501,19 +511,20 @@ constexpr uint32_t kBinnedMinNodes = 1u << 16;       /* ... and this tree size: 
 constexpr uint32_t kGenOctBlock = RTR_GEN_OCT_BLOCK;     /* two workgroups per CU, so one's reservation round trips hide under the other's work */
 /* k_shadow_gen with the queue binned by direction octant (CountOctPolicy / EmitOctPolicy above).  ctrl = Workspace::queueCount:
  * [0] queued rays, [16 + 16 r] / [kQueueListLens + r] cursor / length of batch list r = octant * 8 + xcd; lists: listStride uint2 {first, count} per list. */
-/* Eight waves per SIMD: the kernel is neither issue- nor HBM-bound (its 527 MB of records per frame leave in whole lines: WRITE_SIZE =
- * 1.01 x the algorithmic bytes) but waits — on the hit -> object -> index -> vertex chain of its surface fetch, on its reservation
- * atomics and three barriers — so it wants waves more than registers: at the 88 VGPRs it would take by itself (5 waves per SIMD)
- * 0.171 ms per 1080p frame, capped at 64 (13 dwords spilled) 0.148 (profiles/r04/ab_tri2_gen_waves.log). */
+/* Seven waves per SIMD: the kernel is neither issue- nor HBM-bound (its records leave in whole lines: WRITE_SIZE = 1.01 x the algorithmic
+ * bytes) but waits — on the hit -> object -> index -> vertex chain of its surface fetch, on its reservation atomics and three barriers — so it
+ * wants waves more than registers: at the 88 VGPRs it would take by itself (5 waves per SIMD) 0.171 ms per 1080p frame, capped at 64 (8 waves,
+ * 13 dwords spilled) 0.148 (profiles/r04/ab_tri2_gen_waves.log).  Round 5: with the into-the-surface mark of every ray (a dot product and
+ * a bit per sample) the cap of 64 spilled 31 dwords and cost 0.010 ms; at 72 (7 waves) the kernel is back at 0.151 (profiles/r05/ab_gen_into.log). */
 #ifndef RTR_GEN_OCT_WAVES
-#define RTR_GEN_OCT_WAVES 8
+#define RTR_GEN_OCT_WAVES 7
 #endif
 #if RTR_GEN_OCT_WAVES > 0
 #define RTR_GEN_OCT_ATTR __attribute__((amdgpu_waves_per_eu(RTR_GEN_OCT_WAVES, 8)))
 #else
 #define RTR_GEN_OCT_ATTR
 #endif
-__global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom, const int32_t* hitLeaf,
+__global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oct(DeviceScene sc, FrameBatch fb, const float4* hitTuvp, const uint32_t* hitCustom,
                                                               RayQueue queue, uint32_t* ctrl, uint32_t planeStride, uint2* lists,
                                                               uint32_t listStride, uint32_t kBatch, uint32_t nt) {
     constexpr uint32_t kWaves = kGenOctBlock / 64;
@@ -595,15 +606,17 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
     if (!live || mine == 0) return;
     for (uint32_t i = 0; i < ra.spp; ++i) {
         const size_t k = (plane0 + i) * planeStride + q;
-        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, nt, hitLeaf[k]};
+        EmitOctPolicy pol{queue, (EmitOctPolicy::lds_word)&s_run[wave][0], (uint32_t)k, nt};
         if (single) {
-            if (surf0) light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st);
+            if (surf0) { queue_store_origin(queue, k, sf0.hitPoint, sf0.hitNormal); light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf0, 0u, acc, pol, st); }
         } else {
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
-            if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st))
+            if (fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st)) {
+                queue_store_origin(queue, k, sf.hitPoint, sf.hitNormal);
                 light_loops<EmitOctPolicy, false>(sc, ra, px, py, sf, 0u, acc, pol, st);
+            }
         }
     }
 }
@@ -1188,7 +1201,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
  * stacked in slot order, ALL triangles of a leaf tested (min over (t, customIndex, primitiveID), as trace()), RTR_WIDE_STACK = 16 LDS
  * entries, beyond which the ray goes to the redo list and k_primary_tail walks it over the BVH2 from scratch (both parts counted). */
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf, Counters* stats,
+__global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch fb, float4* hitTuvp, uint32_t* hitCustom, float4* rayOrigin, Counters* stats,
                                                      uint32_t* redoCount, uint32_t* redoList, uint32_t planeBlocks) {
     __shared__ int32_t s_stack[RTR_WIDE_STACK * kBlock];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1261,7 +1274,7 @@ __global__ __launch_bounds__(kBlock) void k_primary4(DeviceScene sc, FrameBatch 
     }
     const size_t k = (size_t)plane * planeBlocks * kBlock + q;
     if (over) redoList[atomicAdd(redoCount, 1u)] = (uint32_t)k;
-    else { hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[k] = best.custom; hitLeaf[k] = best.leaf; }
+    else { hitTuvp[k] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[k] = best.custom; origin_leaf_store(rayOrigin, k, best.leaf); }
     if (STATS) st.flush(stats);
 }
 
@@ -1308,7 +1321,7 @@ __device__ __forceinline__ void inner_nodes2(const __amdgpu_buffer_rsrc_t nodeBu
 }
 
 template <int STACK, bool STATS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_primary_persist(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom, int32_t* hitLeaf,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_primary_persist(DeviceScene sc, RenderArgs ra, float4* hitTuvp, uint32_t* hitCustom, float4* rayOrigin,
                                                          Counters* stats, uint32_t* redoCount, uint32_t* redoList, uint32_t* cursors,
                                                          uint32_t planeStride, uint32_t kBatch, uint32_t kRefill, uint32_t kInnerMin) {
     __shared__ int32_t s_stack[(STACK + 1 + 1) * kBlock];    /* slot 0 holds kDone for good; one guard entry above the stack (inner_nodes2) */
@@ -1338,7 +1351,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         if (nIdle >= kRefill || nIdle == 64u) {
             if (cur == kDone && res != kResNone) {
                 if (res == 2u) redoList[atomicAdd(redoCount, 1u)] = item;              /* finished by k_primary_tail */
-                else { hitTuvp[item] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[item] = best.custom; hitLeaf[item] = best.leaf; }
+                else { hitTuvp[item] = make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)); hitCustom[item] = best.custom; origin_leaf_store(rayOrigin, item, best.leaf); }
                 res = kResNone;
             }
             if (!exhausted) {
@@ -1833,22 +1846,22 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
         const uint32_t pneeded = (uint32_t)(((unsigned long long)planeStride * ra.spp + kBlock - 1) / kBlock);
         if (pblocks > pneeded) pblocks = pneeded;
         if (pblocks == 0) pblocks = 1;
-        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
-        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        if (stats) hipLaunchKernelGGL((k_primary_persist<16, true>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
+        else hipLaunchKernelGGL((k_primary_persist<16, false>), dim3(pblocks), dim3(kBlock), 0, s, sc, fb.ra[0], ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.queueCount + kPrimaryCursors, planeStride, kPBatch, kPRefill, kPInnerMin);
     } else if (tun.primary_wide && sc.nodes4) {
         /* one camera ray per lane over the 4-wide view (not the default); rays that outgrow its 16 entries go to k_primary_tail like k_primary's */
-        if (stats) hipLaunchKernelGGL((k_primary4<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
-        else hipLaunchKernelGGL((k_primary4<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+        if (stats) hipLaunchKernelGGL((k_primary4<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
+        else hipLaunchKernelGGL((k_primary4<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks);
     } else if (tun.primary_packet) {
         /* a tile's camera rays walk the tree as one packet (no ray is ever left to the tail kernel: it is not launched); not the default */
         packet = true;
-        if (stats) hipLaunchKernelGGL((k_primary_packet<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, blocks);
-        else hipLaunchKernelGGL((k_primary_packet<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, blocks);
-    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
+        if (stats) hipLaunchKernelGGL((k_primary_packet<true>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, blocks);
+        else hipLaunchKernelGGL((k_primary_packet<false>), dim3(blocks * ra.spp * nb), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, blocks);
+    } else if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(blocks * (kBlock / kPrimBlock) * ra.spp * nb), dim3(kPrimBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, stats, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, blocks * (kBlock / kPrimBlock));
     if (!packet) {
-        if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
-        else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+        if (stats) hipLaunchKernelGGL(k_primary_tail<true>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
+        else hipLaunchKernelGGL(k_primary_tail<false>, dim3(kTailBlocks), dim3(kBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.rayQueue.origin, ws.queueCount + kPrimaryRedoWord, ws.overflow + 1, ws.spill, planeStride, stats);
     }
     if (ev) hipEventRecord(ev[1], s);
     /* run-time tunables of the traversal kernels (profiles/sweep_*.sh); the defaults are the swept optima */
@@ -1871,8 +1884,8 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     const uint32_t kNtQueue = tun.queue_nt;          /* bit 0: any-hit kernel reads the queue past the caches (default); bit 1: the queue-build kernel writes it so (slower, see queue_load) */
     RayQueue rq = ws.rayQueue;
     rq.ownLeaf = (wide && tun.trace_own_leaf) ? 1u : 0u;          /* only the 4-wide any-hit kernel starts a walk at a leaf (the 2-wide comparison kernel takes the mark off) */
-    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, rq, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
-    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, ws.hitLeaf, rq, ws.queueCount, blocks * kBlock);
+    if (binned) hipLaunchKernelGGL(k_shadow_gen_oct, dim3(genOctBlocks), dim3(kGenOctBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, rq, ws.queueCount, blocks * kBlock, ws.batchLists, ws.listStride, kBatch, kNtQueue >> 1);
+    else hipLaunchKernelGGL(k_shadow_gen, dim3(genBlocks), dim3(kGenBlock), 0, s, sc, fb, ws.hitTuvp, ws.hitCustom, rq, ws.queueCount, blocks * kBlock);
     if (ev) hipEventRecord(ev[2], s);
     /* persistent waves: as many workgroups as stay resident (17 KiB of LDS stack + 2.5 KiB of tree top per workgroup -> 8 per CU,
      * the 32-wave hardware maximum), each pulling batches until the queue is empty */

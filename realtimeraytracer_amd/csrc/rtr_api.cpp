@@ -145,7 +145,6 @@ struct rtr_frame {
     uint32_t slotStride = 0;                       /* distance of the visibility planes: a power of two >= the pixel-sample slots */
     uint32_t visFill = 1;                          /* pre-fill of the visibility array for the next launch: the commoner outcome of the last one (1 = occluded) */
     DevBuf<uint32_t> hitCustom, queueCount;
-    DevBuf<int32_t> hitLeaf;
     DevBuf<uint8_t> vis;
     DevBuf<int32_t> spill;
     DevBuf<uint32_t> overflow;
@@ -1063,7 +1062,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
          * gets 1/16 of the queue (at least 2^20 entries) and k_shadow_tail redoes the whole queue should that ever overflow */
         uint64_t ovCap = std::max<uint64_t>(std::max<uint64_t>(nPS, nRays / 16), 1ull << 20);
         if (ovCap > nRays) ovCap = std::max<uint64_t>(nRays, nPS);
-        if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); HIP_TRY(f->hitLeaf.alloc(nPS)); HIP_TRY(f->rayOrigin.alloc(nPS)); }
+        if (f->hitTuvp.n < nPS) { HIP_TRY(f->hitTuvp.alloc(nPS)); HIP_TRY(f->hitCustom.alloc(nPS)); HIP_TRY(f->rayOrigin.alloc(nPS)); }
         if (f->vis.n < nSlots) HIP_TRY(f->vis.alloc(nSlots));
         if (f->rayDT.n < nRays) { HIP_TRY(f->rayDT.alloc(nRays)); HIP_TRY(f->raySlot.alloc(nRays)); }
         /* every array is (re)sized by its OWN need: the redo list is also k_primary's (one entry per pixel-sample at most), and a
@@ -1083,7 +1082,7 @@ static int enqueue_render(rtr_scene* s, const RtrCameraData* cams, const RtrScen
         if (!f->clk.p) { HIP_TRY(f->clk.alloc(2 * rtrdev::kQueueRegions)); HIP_TRY(hipMemsetAsync(f->clk.p, 0, 2 * rtrdev::kQueueRegions * sizeof(unsigned long long), st)); }
         if (!f->spill.p) HIP_TRY(f->spill.alloc(rtrdev::kSpillInts));      /* 64 entries x the redo kernels' grid */
         Workspace ws;
-        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.hitLeaf = f->hitLeaf.p; ws.vis = f->vis.p; ws.visFill = f->visFill;
+        ws.hitTuvp = f->hitTuvp.p; ws.hitCustom = f->hitCustom.p; ws.vis = f->vis.p; ws.visFill = f->visFill;
         ws.visPlaneBytes = (size_t)nPS; ws.visPlanes = (uint32_t)maxRays;      /* what a launch fills: the first nPS bytes of each of the maxRays planes, not the power-of-two pitch between them */
 #ifdef RTR_TEST_HOOKS
         if (const char* e = getenv("RTR_TRACE_VIS_FILL")) if ((e[0] == '0' || e[0] == '1') && !e[1]) ws.visFill = (uint32_t)(e[0] - '0');      /* force the pre-fill */
