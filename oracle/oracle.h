@@ -61,6 +61,7 @@ typedef struct oracle_walk_stats {
     uint64_t occludedRays, occludedVisits, occludedTests;
     uint64_t visibleRays, visibleVisits, visibleTests;
     uint64_t ownLeafRays;       /* rays that started at the leaf of their own triangle */
+    uint64_t ownLeafStopped;    /* ... and were stopped there, without a record visit */
 } oracle_walk_stats;
 
 typedef struct oracle_out {

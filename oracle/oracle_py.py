@@ -20,7 +20,7 @@ class oracle_scene(C.Structure):
 
 
 class oracle_walk_stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("occludedRays", "occludedVisits", "occludedTests", "visibleRays", "visibleVisits", "visibleTests", "ownLeafRays")]
+    _fields_ = [(n, C.c_uint64) for n in ("occludedRays", "occludedVisits", "occludedTests", "visibleRays", "visibleVisits", "visibleTests", "ownLeafRays", "ownLeafStopped")]
 
 
 class oracle_out(C.Structure):

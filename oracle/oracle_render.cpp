@@ -28,9 +28,9 @@ namespace {
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
     uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0, primaryOverflow = 0;
-    uint64_t walk[7] = {0, 0, 0, 0, 0, 0, 0};   /* oracle_walk_stats: shadow rays over the wide view, split by their answer */
+    uint64_t walk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* oracle_walk_stats: shadow rays over the wide view, split by their answer */
     void add(const Counters& o) {
-        for (int k = 0; k < 7; ++k) walk[k] += o.walk[k];
+        for (int k = 0; k < 8; ++k) walk[k] += o.walk[k];
         shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests; primaryOverflow += o.primaryOverflow;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
@@ -302,7 +302,7 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
     if (firstLeaf < 0) { stack.push_back(0); cur = firstLeaf; }
     const bool slotOrder = (sc.shadowWalk & 1u) != 0u;
     uint64_t visits = 0, tests = 0;            /* of this ray, for the split by its answer (oracle_walk_stats) */
-    auto done = [&](bool occluded) { c.walk[occluded ? 0 : 3]++; c.walk[occluded ? 1 : 4] += visits; c.walk[occluded ? 2 : 5] += tests; };
+    auto done = [&](bool occluded) { c.walk[occluded ? 0 : 3]++; c.walk[occluded ? 1 : 4] += visits; c.walk[occluded ? 2 : 5] += tests; if (occluded && firstLeaf < 0 && visits == 0) c.walk[7]++; };
     /* walk profile (experiments only, oracle.h): per (record, slot) {entries, work done below it, occluders found below it} */
     uint64_t* const prof = sc.s->walkProfile;
     auto credit = [&](uint32_t rec, uint32_t slot, int what, uint64_t n) {       /* (rec, slot) and every slot above it */
@@ -955,7 +955,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.primaryTailRays = tot.primaryOverflow;
     out->walk.occludedRays = tot.walk[0]; out->walk.occludedVisits = tot.walk[1]; out->walk.occludedTests = tot.walk[2];
     out->walk.visibleRays = tot.walk[3]; out->walk.visibleVisits = tot.walk[4]; out->walk.visibleTests = tot.walk[5];
-    out->walk.ownLeafRays = tot.walk[6];
+    out->walk.ownLeafRays = tot.walk[6]; out->walk.ownLeafStopped = tot.walk[7];
     st.localRows = rows; st.localPixels = rows * W;
     uint32_t k = 0;
     k += out->analytic ? 1u : 0u; k += out->shadowed ? 1u : 0u; k += out->unshadowed ? 1u : 0u;
