@@ -63,6 +63,7 @@ def _oracle_render(oracle, *a, **kw):
     """the oracle walks the camera rays the way the GPU is told to (in a soak — RTR_PRIMARY_PACKET=1: 8x8 packets; RTR_PRIMARY_WIDE=1: the 4-wide view) — work counters only"""
     kw.setdefault("primary_packets", os.environ.get("RTR_PRIMARY_PACKET") == "1")
     kw.setdefault("primary_wide", os.environ.get("RTR_PRIMARY_WIDE") == "1")
+    kw.setdefault("own_leaf", os.environ.get("RTR_TRACE_OWN_LEAF", "1") != "0")          # the tunable the GPU context read from the same environment
     return oracle.render(*a, **kw)
 
 
