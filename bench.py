@@ -1189,6 +1189,10 @@ def main():
                        "camera": ("a new view every frame: scripted walk (W / S held, cursor drifting; applyInput = Window::processInput), period %d frames" % PATH_PERIOD) if cams.mode == "path" else "static: every frame the same view",
                        "rays_per_frame": rays_per_frame, "primary_rays_per_frame": primary_per_frame, "rays_per_frame_is": "mean over the frames of the timed region (the counting form, one pass per view)",
                        "pipeline": "wavefront" if pipeline_used == 2 else "megakernel",
+                       # how the shadow rays are walked and the frame resolved (tunables of the context; every setting renders the same bytes): a ray
+                       # counts as a ray whether its walk starts at the root or at the leaf of the triangle it comes from
+                       "shadow_walk": {"own_leaf_start": bool(ctx.get_tunable("trace_own_leaf")), "queue_binned_by_octant": int(ctx.get_tunable("trace_binned")),
+                                       "resolve_compact": bool(ctx.get_tunable("resolve_compact"))},
                        "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries),
                                "build_ms": round(float(sstats.buildMs), 1)}},
             "primary_mrays_per_s": round(primary_total / elapsed / 1e6, 2),
