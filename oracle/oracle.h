@@ -45,15 +45,21 @@ typedef struct oracle_scene {
     /* How a shadow ray is walked over the wide view — it decides the work counters, never the answer (any-hit is a pure function of ray
      * and triangles).  The product's default (0): a ray that leaves its surface point INTO the surface — dot(hitNormal, light sample - hitPoint) < 0,
      * the area-light samples of raygen.rgen:206-241 only — first tests the triangles of the LEAF its own hit triangle sits in (it starts
-     * 0.01 above that triangle and nearly always re-enters it), then walks from the root; at a record the nearest hit child is entered
-     * first (strict <, ties to the lower slot), the others stacked in slot order.
-     * bit 0 (experiment, profiles/experiments/anyhit_order_lab.py): the any-hit slot order — the first hit slot in SLOT order, the
-     * others popping in slot order, no distance compared.  bit 1: no start at the own leaf (the product's tunable trace_own_leaf = 0). */
+     * 0.01 above that triangle and nearly always re-enters it), then walks from the root; at a record the hit child whose EXIT distance
+     * (clamped to the ray's far limit) is the greatest is entered first (strict >, ties to the lower slot) — a shadow ray's occluder
+     * sits, more often than not, towards the light — and the others are stacked in slot order.
+     * bit 0 (experiment, profiles/experiments/anyhit_order_lab.py): the static slot order — the first hit slot in SLOT order, the
+     * others popping in slot order, no distance compared.  bit 1: no start at the own leaf (the product's tunable trace_own_leaf = 0).
+     * bits 2-3: which child first — 0 farthest exit (the product), 1 nearest entry (rounds 1-4; a build with -DRTR_SHADOW_FAR_FIRST=0),
+     * 2 farthest entry, 3 nearest exit.  bit 4 (experiment): the stacked children sorted as well. */
     uint32_t shadowWalk;
     /* Experiments only (profiles/experiments/anyhit_order_lab.py), normally NULL: numWide * 4 * 3 counters the shadow walk adds to —
      * per (record, slot) {times the walk went into the slot, record visits + triangle tests it then spent below it, occluders it found
      * below it} — from which an order "by found occluders per unit of work" is made. */
     uint64_t* walkProfile;
+    /* Experiments only, normally NULL: one record of 8 floats per shadow ray walked over the wide view {visits, tests, occluded, started at its
+     * own leaf, t of the hit or -1, tmax, direction y, origin y}, the first walkRaysCap of them; *walkRaysCount counts all. */
+    float* walkRays; uint64_t walkRaysCap; uint64_t* walkRaysCount;
 } oracle_scene;
 
 /* shadow rays walked over the wide view, split by their answer (what an any-hit order is judged by) */

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 class oracle_scene(C.Structure):
     _fields_ = [("desc", A.rtr_scene_desc), ("nodes", C.POINTER(A.RtrBvhNode)), ("numNodes", A.u32),
                 ("tris", C.POINTER(A.RtrBvhTri)), ("numTris", A.u32), ("grid", A.RtrBvhGrid),
-                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("primaryPackets", A.u32), ("shadowWalk", A.u32), ("walkProfile", C.POINTER(C.c_uint64))]
+                ("wide", C.POINTER(A.RtrWideNode)), ("numWide", A.u32), ("primaryPackets", A.u32), ("shadowWalk", A.u32), ("walkProfile", C.POINTER(C.c_uint64)), ("walkRays", C.POINTER(C.c_float)), ("walkRaysCap", C.c_uint64), ("walkRaysCount", C.POINTER(C.c_uint64))]
 
 
 class oracle_walk_stats(C.Structure):
@@ -72,13 +72,15 @@ def lib():
     return _lib
 
 
-def make_scene(desc, bvh=None, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None):
+def make_scene(desc, bvh=None, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None, walk_rays=None):
     """bvh = (nodes, tris, grid) from api.Scene.export_bvh() (ctypes arrays + the RtrBvhGrid of rtr_scene_stats), or None
     for brute force.  primary_packets: the staged pipeline's camera rays are walked one ray per lane (the product's default, k_primary) or
     tile by tile (tunable primary_packet = 1, k_primary_packet) — it decides work counters only."""
     s = oracle_scene()
     s.desc = desc
     s.shadowWalk = int(shadow_walk)
+    if walk_rays is not None:         # (numpy float32 (cap, 8), numpy uint64 (1,)): experiments only
+        s.walkRays = walk_rays[0].ctypes.data_as(C.POINTER(C.c_float)); s.walkRaysCap = len(walk_rays[0]); s.walkRaysCount = walk_rays[1].ctypes.data_as(C.POINTER(C.c_uint64))
     if walk_profile is not None:      # numpy uint64 (numWide, 4, 3): experiments only
         s.walkProfile = walk_profile.ctypes.data_as(C.POINTER(C.c_uint64))
     s.primaryPackets = 2 if primary_wide else (1 if primary_packets else 0)      # how the staged pipeline walks its camera rays: 0 one ray per lane over the BVH2, 1 8x8 packets, 2 one ray per lane over the 4-wide view
@@ -101,13 +103,13 @@ class Result:
     pass
 
 
-def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None, own_leaf=True):
-    """own_leaf=False: the product's tunable trace_own_leaf = 0 (shadow rays never start at their own triangle's leaf).
+def render(desc, camera, scene_info, params, bvh=None, images=A.IMAGES_FRAMEBUFFER, hdr=None, threads=1, primary_packets=False, primary_wide=False, shadow_walk=0, walk_profile=None, own_leaf=True, walk_rays=None, nearest_first=False):
+    """nearest_first=True: the shadow walk of rounds 1-4 (a library built with -DRTR_SHADOW_FAR_FIRST=0).  own_leaf=False: the product's tunable trace_own_leaf = 0 (shadow rays never start at their own triangle's leaf).
     Returns a Result with numpy uint32 images (rows x width) keyed like rtr_image, .hdr and .stats."""
     L = lib()
     rows = _shard_rows(params.height, params.bandRows or 8, params.shardCount or 1)
     W = params.width
-    sc = make_scene(desc, bvh, primary_packets, primary_wide, int(shadow_walk) | (0 if own_leaf else 2), walk_profile)
+    sc = make_scene(desc, bvh, primary_packets, primary_wide, int(shadow_walk) | (0 if own_leaf else 2) | (4 if nearest_first else 0), walk_profile, walk_rays)
     out = oracle_out()
     r = Result()
     r.images = {}

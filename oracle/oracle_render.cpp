@@ -27,11 +27,11 @@ namespace {
 
 struct Counters {
     uint64_t rays = 0, primary = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, lightFetch = 0, lightTriFetch = 0;
-    uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0, primaryOverflow = 0;
+    uint64_t shadowNodes = 0, shadowTris = 0, texFetch = 0, alphaTests = 0, primaryOverflow = 0, shadowOverflow = 0;
     uint64_t walk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* oracle_walk_stats: shadow rays over the wide view, split by their answer */
     void add(const Counters& o) {
         for (int k = 0; k < 8; ++k) walk[k] += o.walk[k];
-        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests; primaryOverflow += o.primaryOverflow;
+        shadowNodes += o.shadowNodes; shadowTris += o.shadowTris; texFetch += o.texFetch; alphaTests += o.alphaTests; primaryOverflow += o.primaryOverflow; shadowOverflow += o.shadowOverflow;
         rays += o.rays; primary += o.primary; shadow += o.shadow; nodes += o.nodes; tris += o.tris;
         hits += o.hits; lightFetch += o.lightFetch; lightTriFetch += o.lightTriFetch;
     }
@@ -300,9 +300,21 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
     std::vector<int32_t> stack;
     int32_t cur = 0;
     if (firstLeaf < 0) { stack.push_back(0); cur = firstLeaf; }
-    const bool slotOrder = (sc.shadowWalk & 1u) != 0u;
+    /* which hit child is entered first: the product's rule (order 0) is the one whose EXIT distance (clamped to the ray's far limit) is the
+     * GREATEST — strict >, ties to the lower slot; the others are stacked in slot order.  A shadow ray's occluder sits, more often than not,
+     * towards the light's end of the ray (two thirds of the occluded area-light rays of the bench frame are stopped in the last 40 % of their
+     * length), and any-hit does not care which occluder is found.  Orders 1-3 (experiments; 1 = rounds 1-4): nearest entry, farthest entry,
+     * nearest exit. */
+    const uint32_t order = (sc.shadowWalk >> 2) & 3u;
+    const bool slotOrder = (sc.shadowWalk & 1u) != 0u, farFirst = order == 0u || order == 2u, byExit = order == 0u || order == 3u;
     uint64_t visits = 0, tests = 0;            /* of this ray, for the split by its answer (oracle_walk_stats) */
-    auto done = [&](bool occluded) { c.walk[occluded ? 0 : 3]++; c.walk[occluded ? 1 : 4] += visits; c.walk[occluded ? 2 : 5] += tests; if (occluded && firstLeaf < 0 && visits == 0) c.walk[7]++; };
+    auto done = [&](bool occluded) {
+        c.walk[occluded ? 0 : 3]++; c.walk[occluded ? 1 : 4] += visits; c.walk[occluded ? 2 : 5] += tests; if (occluded && firstLeaf < 0 && visits == 0) c.walk[7]++;
+        if (sc.s->walkRays && sc.s->walkRaysCap) {      /* experiments only: one record per shadow ray */
+            const uint64_t at = __atomic_fetch_add(sc.s->walkRaysCount, 1ull, __ATOMIC_RELAXED);
+            if (at < sc.s->walkRaysCap) { float* r = sc.s->walkRays + 8 * at; r[0] = (float)visits; r[1] = (float)tests; r[2] = occluded ? 1.f : 0.f; r[3] = firstLeaf < 0 ? 1.f : 0.f; r[4] = occluded ? best.t : -1.f; r[5] = tmax; r[6] = d.y; r[7] = o.y; }
+        }
+    };
     /* walk profile (experiments only, oracle.h): per (record, slot) {entries, work done below it, occluders found below it} */
     uint64_t* const prof = sc.s->walkProfile;
     auto credit = [&](uint32_t rec, uint32_t slot, int what, uint64_t n) {       /* (rec, slot) and every slot above it */
@@ -319,7 +331,7 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
         if (cur >= 0) {
             const RtrWideNode& n = nodes[cur];
             c.nodes++; c.shadowNodes++; visits++;
-            int hit[4]; float te[4];
+            int hit[4]; float te[4]; float tx[4];
             for (int k = 0; k < 4; ++k) {
                 const uint32_t wmin = n.plane[k][0], wmax = n.plane[k][1], wz = n.plane[k][2];
                 const float x0 = rtr_fma(half_bits_to_float(wmin & 0xffffu), ga.x, gb.x), x1 = rtr_fma(half_bits_to_float(wmax & 0xffffu), ga.x, gb.x);
@@ -327,10 +339,11 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
                 const float z0 = rtr_fma(half_bits_to_float(wz & 0xffffu), ga.z, gb.z), z1 = rtr_fma(half_bits_to_float(wz >> 16), ga.z, gb.z);
                 const float lo = rtr_hwmax(rtr_hwmax(rtr_hwmin(x0, x1), rtr_hwmin(y0, y1)), rtr_hwmax(rtr_hwmin(z0, z1), tmin));
                 const float hi = rtr_hwmin(rtr_hwmin(rtr_hwmax(x0, x1), rtr_hwmax(y0, y1)), rtr_hwmin(rtr_hwmax(z0, z1), tmax));
-                te[k] = lo;
+                te[k] = byExit ? hi : lo; tx[k] = hi;
                 hit[k] = lo <= hi * RTR_BOX_WIDEN;
                 if (k >= 2 && n.child[k] == RTR_WIDE_EMPTY) hit[k] = 0;
             }
+            (void)tx;
             int nextSlot = -1;
             if (slotOrder) {
                 /* the any-hit order: the record's slots were put in the order they should be tried when it was made (the builder's
@@ -338,6 +351,19 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
                  * pop in slot order — no distances are compared */
                 for (int k = 0; k < 4; ++k) if (hit[k]) { nextSlot = k; break; }
                 for (int k = 3; k >= 0; --k) if (hit[k] && k != nextSlot) { stack.push_back(n.child[k]); if (prof) from.push_back((uint32_t)cur * 4u + (uint32_t)k); }
+            } else if (farFirst) {
+                /* the farthest hit child first (strict >, ties to the lower slot): a shadow ray's occluder sits, more often than not, near the
+                 * light's end of the ray */
+                float tf = -3.0e38f;
+                if (hit[0]) { tf = te[0]; nextSlot = 0; }
+                for (int k = 1; k < 4; ++k) if (hit[k] && (nextSlot < 0 || te[k] > tf)) { tf = te[k]; nextSlot = k; }
+                if (sc.shadowWalk & 16u) {      /* experiment: the others sorted too, so that the farthest of them pops first */
+                    int idx[4], m = 0;
+                    for (int k = 0; k < 4; ++k) if (hit[k] && k != nextSlot) idx[m++] = k;
+                    for (int a = 0; a < m; ++a) for (int b = a + 1; b < m; ++b) if (te[idx[b]] < te[idx[a]]) { int t2 = idx[a]; idx[a] = idx[b]; idx[b] = t2; }      /* ascending: the last pushed = the farthest */
+                    for (int a = 0; a < m; ++a) { stack.push_back(n.child[idx[a]]); if (prof) from.push_back((uint32_t)cur * 4u + (uint32_t)idx[a]); }
+                } else
+                for (int k = 0; k < 4; ++k) if (hit[k] && k != nextSlot) { stack.push_back(n.child[k]); if (prof) from.push_back((uint32_t)cur * 4u + (uint32_t)k); }
             } else {
                 float tn = 3.0e38f;
                 if (hit[0]) { tn = te[0]; nextSlot = 0; }
@@ -349,6 +375,7 @@ Hit trace_wide(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, Coun
              * after a visit is abandoned there and re-traced from scratch over the BVH2 by k_shadow_tail (counting form: both parts
              * are counted) */
             if (stack.size() > RTR_WIDE_STACK) {
+                c.shadowOverflow++;
                 const uint64_t n0 = c.shadowNodes, t0 = c.shadowTris;
                 const Hit h = trace_bvh(sc, o, d, tmin, tmax, true, c);
                 visits += c.shadowNodes - n0; tests += c.shadowTris - t0;
@@ -952,7 +979,7 @@ int oracle_render(const oracle_scene* s, const RtrCameraData* cam, const RtrScen
     st.numTexFetches = tot.texFetch; st.numAlphaTests = tot.alphaTests;
     const uint64_t shadowNodeBytes = sc.useWide ? RTR_WIDE_NODE_BYTES : RTR_BVH_NODE_BYTES;
     st.shadowTraceBytes = shadowNodeBytes * tot.shadowNodes + 48 * tot.shadowTris + 37 * tot.shadow;   /* per ray: 20-B queue record + 16-B origin of its pixel-sample + visibility byte */
-    st.primaryTailRays = tot.primaryOverflow;
+    st.primaryTailRays = tot.primaryOverflow; st.shadowTailRays = tot.shadowOverflow;
     out->walk.occludedRays = tot.walk[0]; out->walk.occludedVisits = tot.walk[1]; out->walk.occludedTests = tot.walk[2];
     out->walk.visibleRays = tot.walk[3]; out->walk.visibleVisits = tot.walk[4]; out->walk.visibleTests = tot.walk[5];
     out->walk.ownLeafRays = tot.walk[6]; out->walk.ownLeafStopped = tot.walk[7];

@@ -195,7 +195,9 @@ __device__ __forceinline__ float vmin_raw(float a, float b) {
     asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-template <int OCT>
+/* EXIT: the distance handed back is the box's EXIT (clamped to tmax) instead of its entry: what the any-hit walk orders the children of a
+ * record by (farthest exit first, inner_nodes4) */
+template <int OCT, bool EXIT = false>
 __device__ __forceinline__ bool slab_wide(uint32_t wmin, uint32_t wmax, uint32_t wz, rtr_v3 ga, rtr_v3 gbc, float tmin, float tmax, float& t_entry) {
     typedef _Float16 rtr_h2 __attribute__((ext_vector_type(2)));
     const rtr_h2 pmin = __builtin_bit_cast(rtr_h2, wmin), pmax = __builtin_bit_cast(rtr_h2, wmax), pz = __builtin_bit_cast(rtr_h2, wz);
@@ -214,7 +216,7 @@ __device__ __forceinline__ bool slab_wide(uint32_t wmin, uint32_t wmax, uint32_t
     }
     const float lo = rtr_hwmax(rtr_hwmax(nx, ny), rtr_hwmax(nz, tmin));
     const float hi = rtr_hwmin(rtr_hwmin(fx, fy), vmin_raw(fz, tmax));
-    t_entry = lo;
+    t_entry = EXIT ? hi : lo;
     return lo <= hi * RTR_BOX_WIDEN;
 }
 

@@ -8,7 +8,7 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
-#define RTR_ANYHIT_KERNEL_REVISION "r05.2"
+#define RTR_ANYHIT_KERNEL_REVISION "r05.3"
 
 /* Batch cursors per queue (and batch lists per octant).  Workgroups are dealt round-robin to the XCDs, and a workgroup starts on
  * cursor blockIdx mod 8: with 8, 4, 2 or 1 XCDs visible (SPX, DPX, QPX, CPX partitions of an MI355X) a cursor is still used by the

@@ -841,6 +841,10 @@ __device__ __forceinline__ rtr_f4 load_f4(const __amdgpu_buffer_rsrc_t buf, int3
 }
 
 struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
+#ifndef RTR_SHADOW_FAR_FIRST
+#define RTR_SHADOW_FAR_FIRST 1
+#endif
+constexpr bool kFarFirst = RTR_SHADOW_FAR_FIRST != 0;       /* which child of a record the any-hit walk enters first (inner_nodes4); the oracle's trace_wide restates both */
 
 template <int STACK, int OCT, bool STATS>
 __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBuf, const uint4* ldsTop, const uint32_t topCount,
@@ -880,10 +884,10 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
             /* an empty slot (only slots 2, 3 can be) holds an inside-out box with infinite planes: in the octant forms its entry
              * is +inf and its exit -inf, so it is never hit and needs no test of its code; the mixed form's per-axis min / max would
              * turn it back into an all-enclosing box, so that form looks at the code */
-            const bool h0 = slab_wide<OCT>(q0.x, q0.y, q0.z, ga, gb, tmin, tmaxC, t0);
-            const bool h1 = slab_wide<OCT>(q0.w, q1.x, q1.y, ga, gb, tmin, tmaxC, t1);
-            const bool h2 = slab_wide<OCT>(q1.z, q1.w, q2.x, ga, gb, tmin, tmaxC, t2) & (OCT < 8 || c2 != kDone);
-            const bool h3 = slab_wide<OCT>(q2.y, q2.z, q2.w, ga, gb, tmin, tmaxC, t3) & (OCT < 8 || c3 != kDone);
+            const bool h0 = slab_wide<OCT, kFarFirst>(q0.x, q0.y, q0.z, ga, gb, tmin, tmaxC, t0);
+            const bool h1 = slab_wide<OCT, kFarFirst>(q0.w, q1.x, q1.y, ga, gb, tmin, tmaxC, t1);
+            const bool h2 = slab_wide<OCT, kFarFirst>(q1.z, q1.w, q2.x, ga, gb, tmin, tmaxC, t2) & (OCT < 8 || c2 != kDone);
+            const bool h3 = slab_wide<OCT, kFarFirst>(q2.y, q2.z, q2.w, ga, gb, tmin, tmaxC, t3) & (OCT < 8 || c3 != kDone);
             /* descend into the nearest child that is hit (strict <: ties go to the lower slot); the others go on the stack in slot
              * order.  e_k: slot k displaced the nearest so far; the slot entered is the last one that did (slot 0 if none did).
              * (Taking the first hit slot instead of the nearest saves instructions and costs 2 % more time; ordering the others too —
@@ -892,12 +896,16 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
              * comparison of codes — written on wave masks, so that every comparison is issued once and the rest is scalar (from bools
              * the compiler derived !(t2 < tn) with a second vector compare). */
             const unsigned long long H0 = __builtin_amdgcn_ballot_w64(h0), H1 = __builtin_amdgcn_ballot_w64(h1), H2 = __builtin_amdgcn_ballot_w64(h2), H3 = __builtin_amdgcn_ballot_w64(h3);
-            float tn = h0 ? t0 : 3.0e38f;
-            const unsigned long long E1 = H1 & __builtin_amdgcn_ballot_w64(t1 < tn);
+            /* kFarFirst (round 5; the default): t_k is child k's EXIT distance and the child entered is the one that exits LAST (strict >, ties
+             * to the lower slot) — a shadow ray's occluder sits, more often than not, towards the light's end of the ray, and any-hit does not
+             * care which occluder it finds: 10.6 -> 8.0 record visits and 3.40 -> 2.60 triangle tests per ray on the bench frame for the same
+             * instructions per visit (profiles/r05/far_first_lab.log).  Otherwise the nearest entry first, the closest-hit order of rounds 1-4. */
+            float tn = h0 ? t0 : (kFarFirst ? -3.0e38f : 3.0e38f);
+            const unsigned long long E1 = H1 & __builtin_amdgcn_ballot_w64(kFarFirst ? t1 > tn : t1 < tn);
             const bool e1 = __builtin_amdgcn_inverse_ballot_w64(E1); tn = e1 ? t1 : tn;
-            const unsigned long long E2 = H2 & __builtin_amdgcn_ballot_w64(t2 < tn);
+            const unsigned long long E2 = H2 & __builtin_amdgcn_ballot_w64(kFarFirst ? t2 > tn : t2 < tn);
             const bool e2 = __builtin_amdgcn_inverse_ballot_w64(E2); tn = e2 ? t2 : tn;
-            const unsigned long long E3 = H3 & __builtin_amdgcn_ballot_w64(t3 < tn);
+            const unsigned long long E3 = H3 & __builtin_amdgcn_ballot_w64(kFarFirst ? t3 > tn : t3 < tn);
             const bool e3 = __builtin_amdgcn_inverse_ballot_w64(E3);
             int32_t next = e3 ? c3 : (e2 ? c2 : (e1 ? c1 : c0));
             const bool any = __builtin_amdgcn_inverse_ballot_w64(H0 | H1 | H2 | H3);
