@@ -156,8 +156,8 @@ Hit trace_bvh(const Scene& sc, rtr_v3 o, rtr_v3 d, float tmin, float tmax, bool 
             int hr = rtr_slab_q(q[RTR_BVH_QSLOT(1, 0, 0)], q[RTR_BVH_QSLOT(1, 0, 1)], q[RTR_BVH_QSLOT(1, 0, 2)],
                                 q[RTR_BVH_QSLOT(1, 1, 0)], q[RTR_BVH_QSLOT(1, 1, 1)], q[RTR_BVH_QSLOT(1, 1, 2)], ga, gb, tmin, limit, &tr);
             if (hl && hr) {
-                int32_t nearC = n.child[0], farC = n.child[1];
-                if (tr < tl) { nearC = n.child[1]; farC = n.child[0]; }
+                int32_t nearC = n.child[0], farC = n.child[1];      /* the child entered first / stacked: closest hit the nearer first, any hit the FARTHER first (ties: child 0) */
+                if (anyHit ? tl < tr : tr < tl) { nearC = n.child[1]; farC = n.child[0]; }
                 /* the primary kernels of the staged pipeline keep 16 stack entries in LDS; a camera ray that needs a 17th is abandoned
                  * there and re-traced from scratch by k_primary_tail with a full-depth stack (both parts are counted) */
                 if (stackLimit > 0 && sp >= stackLimit) { c.primaryOverflow++; return trace_bvh(sc, o, d, tmin, tmax, anyHit, c, 0); }

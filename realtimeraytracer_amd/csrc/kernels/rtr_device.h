@@ -272,7 +272,9 @@ __device__ __forceinline__ bool trace(const DeviceScene& sc, int32_t* __restrict
             const bool hl = slab_oct<OCT>(a.x, a.y, b.x, ga, gb, tmin, limit, tl);
             const bool hr = slab_oct<OCT>(a.z, a.w, b.y, ga, gb, tmin, limit, tr);
             if (hl && hr) {
-                const bool swap = tr < tl;
+                /* closest hit: the nearer child first (ties: child 0).  Any hit: the FARTHER one first (ties: child 0) — a shadow ray's occluder
+                 * sits towards the light more often than not (k_shadow_trace4's rule, on entry distances here; the oracle's trace_bvh restates it) */
+                const bool swap = ANY ? tl < tr : tr < tl;
                 const int32_t nearC = swap ? ch.y : ch.x;
                 const int32_t farC = swap ? ch.x : ch.y;
                 if (LIMIT > 0 && sp >= LIMIT) { over = true; cur = kWalkEnd; }
