@@ -840,7 +840,10 @@ __device__ __forceinline__ rtr_f4 load_f4(const __amdgpu_buffer_rsrc_t buf, int3
     return rtr_f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
 }
 
-struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0; };     /* wave-uniform */
+struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLanes = 0, refills = 0, over64 = 0, leafLanes = 0; };     /* wave-uniform */
+#ifndef RTR_STATS_LEAF_PHASE
+#define RTR_STATS_LEAF_PHASE 0
+#endif
 #ifndef RTR_SHADOW_FAR_FIRST
 #define RTR_SHADOW_FAR_FIRST 1
 #endif
@@ -1164,11 +1167,16 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
             const uint32_t code = (uint32_t)~cur;
             const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             bool hit = false;
+#if RTR_STATS_LEAF_PHASE      /* experiment (profiles/experiments/leaf_phase_pairs.py): the counters re-used — trips := leaf phases, lanes := (ray, triangle) pairs waiting at their start, refills := phases with more than 64 pairs + (lanes at a leaf << 32) */
+            { const uint32_t pairs = wave_sum_u32(atLeaf ? cnt : 0u); ws.triIters++; ws.triLanes += pairs; if (pairs > 64u) ws.over64++; ws.leafLanes += (uint32_t)__popcll(__ballot(atLeaf)); }
+#endif
             for (uint32_t i = 0;; ++i) {
                 const bool go = atLeaf && i < cnt && !hit;
                 const unsigned long long m = __ballot(go);
                 if (m == 0ull) break;
+#if !RTR_STATS_LEAF_PHASE
                 ws.triIters++; ws.triLanes += (uint32_t)__popcll(m);
+#endif
                 if (go) { st.tris++; st.shadowTris++; hit = tri_any<true>(sc, triBuf, first + i, o, d, tmin, tmax, st); }
             }
             if (atLeaf) {
@@ -1194,7 +1202,11 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 
         if (STATS && (threadIdx.x & 63u) == 0) {
             atomicAdd(&stats->innerIters, (unsigned long long)ws.innerIters); atomicAdd(&stats->innerLanes, (unsigned long long)ws.innerLanes);
             atomicAdd(&stats->triIters, (unsigned long long)ws.triIters); atomicAdd(&stats->triLanes, (unsigned long long)ws.triLanes);
+#if RTR_STATS_LEAF_PHASE
+            atomicAdd(&stats->refills, (unsigned long long)ws.over64 | ((unsigned long long)ws.leafLanes << 32));
+#else
             atomicAdd(&stats->refills, (unsigned long long)ws.refills);
+#endif
             atomicAdd(&stats->clockCycles, c1 - c0); atomicAdd(&stats->clockRef, r1 - r0);
         }
     }
