@@ -1,5 +1,14 @@
+#!/usr/bin/env python3
+"""CPU-only: the shadow rays of the reduced bench frame by class — started at their own leaf and stopped there / walked on, from the root
+and occluded / visible, directional — with each class's share of the record visits and triangle tests, and for the occluded area-light
+rays where along the ray the occluder was found (what the farthest-exit-first order was read off: profiles/r05/far_first_lab.log).
+Uses the oracle's per-ray walk records (oracle_scene::walkRays).
+
+    python profiles/experiments/ray_classes.py [sponza_class | sponza_mixed | bunny_class]
+"""
+import os
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from realtimeraytracer_amd import _abi as A, api, scenes
 from oracle import oracle_py as O

@@ -670,6 +670,9 @@ constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
  * (1.86 -> 1.80 ms), but a big workgroup frees its LDS only when its last wave retires, which is when the other frames' kernels
  * can start: with four frames in flight 11.57 G rays/s became 11.1 (512 lanes) and 10.3 (1024) — profiles/r02/trace_block_size.log. */
 constexpr int kTraceBlock = RTR_TRACE_BLOCK;
+#ifndef RTR_SHADOW_STACK
+#define RTR_SHADOW_STACK RTR_WIDE_STACK      /* experiments only (profiles/r05/ab_stack_top.log): the oracle restates RTR_WIDE_STACK entries */
+#endif
 #ifndef RTR_TRACE_TOP
 #define RTR_TRACE_TOP 40
 #endif
@@ -1930,11 +1933,11 @@ static hipError_t wave_t(const DeviceScene& sc, const FrameBatch& fb, const Work
     if (tblocks4 == 0) tblocks4 = 1;
     if (wide) {
         if (stats) {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_SHADOW_STACK, true, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_SHADOW_STACK, false, true>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         } else {
-            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
-            else hipLaunchKernelGGL((k_shadow_trace4<RTR_WIDE_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            if (binned) hipLaunchKernelGGL((k_shadow_trace4<RTR_SHADOW_STACK, true, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
+            else hipLaunchKernelGGL((k_shadow_trace4<RTR_SHADOW_STACK, false, false>), dim3(tblocks4), dim3(kTraceBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap, kOct, top, ws.batchLists, ws.listStride, stats, ws.clk);
         }
     } else hipLaunchKernelGGL((k_shadow_trace<16>), dim3(tblocks), dim3(kBlock), 0, s, sc, ws.rayQueue, ws.queueCount, ws.queueCount + kBatchCursorWord, ws.vis, ws.visFill, kBatch, kRefill, kInnerMin, ws.overflow, ws.overflowCap);
     if (ev) hipEventRecord(ev[5], s);
