@@ -1192,6 +1192,7 @@ def main():
                        # how the shadow rays are walked and the frame resolved (tunables of the context; every setting renders the same bytes): a ray
                        # counts as a ray whether its walk starts at the root or at the leaf of the triangle it comes from
                        "shadow_walk": {"own_leaf_start": bool(ctx.get_tunable("trace_own_leaf")), "queue_binned_by_octant": int(ctx.get_tunable("trace_binned")),
+                                       "child_entered_first": "nearest entry" if A.hip_lib().rtr_kernel_revision().decode().endswith("nearest-first") else "farthest exit",
                                        "resolve_compact": bool(ctx.get_tunable("resolve_compact"))},
                        "bvh": {"nodes": int(sstats.numNodes), "max_depth": int(sstats.maxDepth), "lds_stack_entries": int(sstats.stackEntries),
                                "build_ms": round(float(sstats.buildMs), 1)}},

@@ -8,7 +8,16 @@ namespace rtrdev {
 /* Bumped whenever the any-hit kernel (k_shadow_trace4) or the tree it walks changes what it executes: the counter files under
  * profiles/ carry the revision they were collected with, and bench.py refuses to mix revisions ("record the layout
  * version next to every number"). */
+/* Which hit child of a 4-wide record a shadow ray enters first: 1 (default) the one that EXITS last, 0 the nearest entry (rounds 1-4) — a
+ * compile-time choice (inner_nodes4); a build with 0 says so in its revision, and the oracle walks either way (shadowWalk bits 2-3). */
+#ifndef RTR_SHADOW_FAR_FIRST
+#define RTR_SHADOW_FAR_FIRST 1
+#endif
+#if RTR_SHADOW_FAR_FIRST
 #define RTR_ANYHIT_KERNEL_REVISION "r05.3"
+#else
+#define RTR_ANYHIT_KERNEL_REVISION "r05.3-nearest-first"
+#endif
 
 /* Batch cursors per queue (and batch lists per octant).  Workgroups are dealt round-robin to the XCDs, and a workgroup starts on
  * cursor blockIdx mod 8: with 8, 4, 2 or 1 XCDs visible (SPX, DPX, QPX, CPX partitions of an MI355X) a cursor is still used by the

@@ -847,9 +847,6 @@ struct WaveStats { uint32_t innerIters = 0, innerLanes = 0, triIters = 0, triLan
 #ifndef RTR_STATS_LEAF_PHASE
 #define RTR_STATS_LEAF_PHASE 0
 #endif
-#ifndef RTR_SHADOW_FAR_FIRST
-#define RTR_SHADOW_FAR_FIRST 1
-#endif
 constexpr bool kFarFirst = RTR_SHADOW_FAR_FIRST != 0;       /* which child of a record the any-hit walk enters first (inner_nodes4); the oracle's trace_wide restates both */
 
 template <int STACK, int OCT, bool STATS>

@@ -48,7 +48,7 @@ def test_bench_line_keeps_the_contract(scene_cache):
     assert d["latency"]["limit_ms"] == 16.7 and d["latency"]["chosen_by"] == "probe"
     assert all(p_["launch_ms"] > 0 for p_ in d["latency"]["probes"]) and d["latency"]["probes"][-1]["frames"] == d["latency"]["frames_per_launch_limit"]
     assert d["latency"]["probes"][-1]["launch_ms"] <= 16.7 and "scripted walk" in d["config"]["camera"]
-    assert d["config"]["shadow_walk"] == {"own_leaf_start": True, "queue_binned_by_octant": 2, "resolve_compact": True}
+    assert d["config"]["shadow_walk"] == {"own_leaf_start": True, "queue_binned_by_octant": 2, "child_entered_first": "farthest exit", "resolve_compact": True}
     assert d["one_frame_at_a_time"]["frame_latency_ms"] == d["one_frame_at_a_time"]["ms_per_step"] > 0
     assert "frac_useful" in r and "issue_cycles_per_inst_measured" in r
     assert r["frac"] is None or 0 < r["frac"] <= 1.05          # counters are committed for the default workload only (pmc_note says so otherwise)
