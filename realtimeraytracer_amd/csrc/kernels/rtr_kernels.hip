@@ -1560,6 +1560,9 @@ __global__ __launch_bounds__(kBlock) RTR_RESOLVE_ATTR void k_resolve(DeviceScene
  * light_sample_pos) and the sums are formed in the same order, so the image is the one k_resolve writes, bit for bit (tests: both
  * forms against the oracle).  A round holds at most CAP items and 32 steps; longer light lists take more rounds.  Only the
  * framebuffer-only launch has this form: with the unshadowed image asked for every sample's BRDF is an output and nothing is sparse. */
+#ifndef RTR_EXP_DOUBLE_FETCH
+#define RTR_EXP_DOUBLE_FETCH 0
+#endif
 #ifndef RTR_RESOLVE_CAP
 #define RTR_RESOLVE_CAP 192
 #endif
@@ -1611,6 +1614,14 @@ void k_resolve_compact(DeviceScene sc, FrameBatch fb, uint32_t planeStride, cons
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             has = fetch_surface<true, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);      /* a miss / a light adds its colour to acc.shadowed, as in k_resolve */
+#if RTR_EXP_DOUBLE_FETCH      /* experiment (profiles/r05/ab_resolve_fetch_share.log): the surface fetched a second time — what one fetch costs this kernel is the upper bound of what a surface record written by the queue build could save it */
+            if (has) {
+                HitRec h2 = h; h2.u = h.u + (float)(ra.spp - 1u) * 1.0e-30f; h2.v = h.v + (float)(ra.spp - 1u) * 1.0e-30f;
+                Surface sf2; Accum acc2 = zero_accum();
+                const bool has2 = fetch_surface<true, false>(sc, ra, h2, primary_dir(ra, px, py, i), false, acc2, sf2, st);
+                if (has2 && sf2.roughness == 12345.0f && sf2.hitPoint.x == 4321.0f && sf2.color.y == 777.0f && sf2.viewDir.z == 55.0f && sf2.hitNormal.y == 99.0f) sf = sf2;
+            }
+#endif
         }
         wave_lds_sync();                                 /* the last sample's evaluation has read the surfaces */
         if (has) {
