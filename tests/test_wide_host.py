@@ -155,3 +155,32 @@ def test_shadow_rays_into_the_surface_start_at_their_own_leaf(name):
         assert on.walk.ownLeafRays > 0.35 * on.stats.numShadowRays and on.stats.numShadowNodeVisits < 0.8 * off.stats.numShadowNodeVisits
     # a visible ray is never made cheaper by it (every box it hits must still be opened), only dearer by its own leaf's triangles
     assert on.walk.visibleVisits == off.walk.visibleVisits and on.walk.visibleTests >= off.walk.visibleTests
+
+
+@pytest.mark.parametrize("name", ["sponza_class", "bunny_class", "cornell_box"])
+def test_the_child_a_shadow_ray_enters_first_changes_the_work_never_the_answer(name):
+    """Round 5: at a 4-wide record a shadow ray enters the hit child whose EXIT distance is the greatest (k_shadow_trace4's inner_nodes4 =
+    oracle trace_wide, shadowWalk order 0); rounds 1-4 entered the nearest ENTRY (a library built with -DRTR_SHADOW_FAR_FIRST=0 = the oracle's
+    nearest_first).  Any-hit is a pure function of ray and triangles: every order gives the brute-force image, a VISIBLE ray opens the
+    same boxes under every order, and on the atrium — occluders towards the lights — the occluded rays' walks are a third shorter."""
+    from oracle import oracle_py as O
+    W, H = 160, 96
+    s = getattr(scenes, name)(W, H)
+    p = api.make_params(W, H, spp=1, shadow_rays=3, collect_stats=1)
+    bvh = api.host_build_bvh_wide(s.desc)
+    brute = O.render(s.desc, s.camera, s.scene_info(0), p, bvh=None, threads=8)
+    runs = {}
+    for label, kw in (("far_exit", {}), ("near_entry", {"nearest_first": True}), ("far_entry", {"shadow_walk": 8}), ("near_exit", {"shadow_walk": 12})):
+        r = O.render(s.desc, s.camera, s.scene_info(0), p, bvh=bvh, threads=8, **kw)
+        assert np.array_equal(r.images[A.IMAGE_SHADOWED], brute.images[A.IMAGE_SHADOWED]), label
+        assert r.stats.numShadowRays == brute.stats.numShadowRays and r.walk.occludedRays + r.walk.visibleRays == r.stats.numShadowRays, label
+        runs[label] = r
+    ref = runs["far_exit"]
+    for label, r in runs.items():
+        assert r.walk.occludedRays == ref.walk.occludedRays and r.walk.visibleRays == ref.walk.visibleRays, label
+        assert r.walk.visibleVisits == ref.walk.visibleVisits, label          # nothing in the way: every box the ray meets is opened, in whatever order
+        assert r.walk.ownLeafRays == ref.walk.ownLeafRays and r.walk.ownLeafStopped == ref.walk.ownLeafStopped, label
+    if name == "sponza_class":
+        assert ref.walk.occludedVisits < 0.75 * runs["near_entry"].walk.occludedVisits
+        assert ref.stats.numShadowTriTests < 0.9 * runs["near_entry"].stats.numShadowTriTests
+        assert ref.stats.numShadowNodeVisits <= min(r.stats.numShadowNodeVisits for r in runs.values())
