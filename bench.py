@@ -1135,6 +1135,10 @@ def main():
                 "l2_frac": round(per_launch("TCP_TCC_READ_REQ") * 64 / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if pmc else None,
                 # the second unit that is nearly full: one L1 (TCP) per CU, one tag look-up per clock
                 "l1_tag_lookups_per_l1_clock": round(per_launch("TCP_TOTAL_CACHE_ACCESSES") / (num_simds / 4 * launch_cycles), 4) if (pmc and launch_cycles) else None,
+                # `frac` says how busy the vector pipes are, not what the next instruction costs (measured, round 5)
+                "margin_note": "7.8 % fewer vector instructions (the IEEE reciprocal sequences as v_rcp_f32 + one Newton step) leave this kernel's duration unchanged "
+                               "(profiles/r05/pmc_rcp_instr.log); its time follows the record VISITS - dependent fetches through L1s at l1_tag_lookups_per_l1_clock - "
+                               "with the vector pipes `frac` busy beside them (DESIGN.md 5)",
                 # algorithmic bytes of the same kernel (its counting form): 64 B per 4-wide record visited + 48 B per triangle test + 37 B per
                 # ray.  Served by LDS / L1 / L2 / Infinity Cache: this rate is NOT a fraction of any ceiling and is not the roofline
                 "algorithmic_bytes_per_launch": int(trace_bytes / n_launches),
