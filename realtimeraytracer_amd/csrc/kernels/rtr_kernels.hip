@@ -670,6 +670,13 @@ constexpr uint32_t kResNone = 3u;          /* lane holds no unwritten result */
  * (1.86 -> 1.80 ms), but a big workgroup frees its LDS only when its last wave retires, which is when the other frames' kernels
  * can start: with four frames in flight 11.57 G rays/s became 11.1 (512 lanes) and 10.3 (1024) — profiles/r02/trace_block_size.log. */
 constexpr int kTraceBlock = RTR_TRACE_BLOCK;
+/* cache policy of the any-hit kernel's triangle / record loads (raw_buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1): the default policy is the fastest (profiles/r05/ab_cache_policy.log) */
+#ifndef RTR_TRI_AUX
+#define RTR_TRI_AUX 0
+#endif
+#ifndef RTR_NODE_AUX
+#define RTR_NODE_AUX 0
+#endif
 #ifndef RTR_SHADOW_STACK
 #define RTR_SHADOW_STACK RTR_WIDE_STACK      /* experiments only (profiles/r05/ab_stack_top.log): the oracle restates RTR_WIDE_STACK entries */
 #endif
@@ -825,9 +832,9 @@ __device__ __forceinline__ bool tri_any(const DeviceScene& sc, const __amdgpu_bu
                                         const float tmin, const float tmax, LocalStats& st) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int32_t triOff = (int32_t)(tri * 48u);
-    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff, 0, 0);
-    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 16, 0, 0);
-    const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 32, 0, 0);
+    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff, 0, RTR_TRI_AUX);
+    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 16, 0, RTR_TRI_AUX);
+    const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(triBuf, triOff + 32, 0, RTR_TRI_AUX);
     const float4 q0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
     const float4 q1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
     const float4 q2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
@@ -876,10 +883,10 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
                 q2 = u32x4{a2.x, a2.y, a2.z, a2.w}; q3 = u32x4{a3.x, a3.y, a3.z, a3.w};
             } else {
                 const int32_t nodeOff = cur << 6;
-                q0 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, 0);
-                q1 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, 0);
-                q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, 0);
-                q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, 0);
+                q0 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff, 0, RTR_NODE_AUX);
+                q1 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 16, 0, RTR_NODE_AUX);
+                q2 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 32, 0, RTR_NODE_AUX);
+                q3 = __builtin_amdgcn_raw_buffer_load_b128(nodeBuf, nodeOff + 48, 0, RTR_NODE_AUX);
             }
             const int32_t top = *sp;                           /* speculative: hides the pop's LDS latency under the node loads */
             const int32_t c0 = (int32_t)q3.x, c1 = (int32_t)q3.y, c2 = (int32_t)q3.z, c3 = (int32_t)q3.w;
