@@ -284,7 +284,8 @@ inline float half_bits_to_float(uint32_t h) {
 /* Any-hit walk over the 4-wide view, restating k_shadow_trace4 / inner_nodes4 (realtimeraytracer_amd/csrc/kernels/rtr_kernels.hip):
  * per visit the four slab tests on half-float planes about the scene's wide centre (fma(plane, ga, gbc) per plane; the kernel's
  * per-octant forms give the same bits as the min / max form here because the fma is monotone in the plane), descend into
- * the nearest child that is hit (strict <, so ties go to the lower slot), push the other hit children in slot order (skipping a
+ * the BEST child that is hit (the farthest exit by default, the nearest entry in rounds 1-4: `order` below; strict comparison, so ties go to
+ * the lower slot), push the other hit children in slot order (skipping a
  * code equal to the one entered, as the kernel's `c != next` does), test a leaf's triangles in storage order until one hits;
  * RTR_WIDE_STACK (16) stack entries, beyond which the ray is redone over the BVH2 as k_shadow_tail does. */
 /* firstLeaf != 0 (the leaf code of the triangle the ray starts on, for a ray that leaves its surface point INTO the surface: dot(normal,

@@ -898,10 +898,11 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
             const bool h1 = slab_wide<OCT, kFarFirst>(q0.w, q1.x, q1.y, ga, gb, tmin, tmaxC, t1);
             const bool h2 = slab_wide<OCT, kFarFirst>(q1.z, q1.w, q2.x, ga, gb, tmin, tmaxC, t2) & (OCT < 8 || c2 != kDone);
             const bool h3 = slab_wide<OCT, kFarFirst>(q2.y, q2.z, q2.w, ga, gb, tmin, tmaxC, t3) & (OCT < 8 || c3 != kDone);
-            /* descend into the nearest child that is hit (strict <: ties go to the lower slot); the others go on the stack in slot
-             * order.  e_k: slot k displaced the nearest so far; the slot entered is the last one that did (slot 0 if none did).
-             * (Taking the first hit slot instead of the nearest saves instructions and costs 2 % more time; ordering the others too —
-             * a 5-exchange sort, or just the second nearest on top — costs more instructions than the better order saves:
+            /* descend into the BEST hit child — by default the one that exits last (kFarFirst, below), in rounds 1-4 the nearest —
+             * strict comparison: ties go to the lower slot; the others go on the stack in slot order.  e_k: slot k displaced the best
+             * so far; the slot entered is the last one that did (slot 0 if none did).
+             * (Taking the first hit slot instead of the best saves instructions and costs 2 % more time; ordering the others too —
+             * a 5-exchange sort, or just the second best on top — costs more instructions than the better order saves:
              * 2.15 / 2.22 ms against 2.05.)  Which slots are stacked is mask arithmetic on the comparison results, not a
              * comparison of codes — written on wave masks, so that every comparison is issued once and the rest is scalar (from bools
              * the compiler derived !(t2 < tn) with a second vector compare). */
@@ -951,7 +952,7 @@ __device__ __forceinline__ void inner_nodes4(const __amdgpu_buffer_rsrc_t nodeBu
  * (four loads issued together) holding up to four child boxes, so a ray makes about half as many DEPENDENT visits; the
  * instruction and look-up totals stay about the same.  2.17 -> 2.05 ms on the bench frame; identical visibility bits. */
 /* STATS: the same kernel with per-ray work counters (a ray's sequence of visits and triangle tests depends only on the ray and the
- * tree: nearest hit child first, ties to the lower slot, the others stacked in slot order — whatever the scheduling, the octant
+ * tree: the hit child that exits last first (kFarFirst), ties to the lower slot, the others stacked in slot order — whatever the scheduling, the octant
  * form or the queue mode, so the counting form's numbers are the timed form's, and the oracle restates them), per-trip lane counts
  * of the two phases, and a shader-clock stamp pair per wave. */
 template <int STACK, bool LISTS, bool STATS>
