@@ -548,7 +548,15 @@ __global__ __launch_bounds__(kGenOctBlock) RTR_GEN_OCT_ATTR void k_shadow_gen_oc
             const float4 r = hitTuvp[k];
             HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = __float_as_uint(r.w); h.custom = hitCustom[k];
             Surface sf;
-            const bool surf = fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);
+            bool surf = fetch_surface<false, false>(sc, ra, h, primary_dir(ra, px, py, i), false, acc, sf, st);
+#if RTR_EXP_DOUBLE_FETCH_GEN      /* experiment (profiles/r05/ab_gen_fetch_share.log): what one surface fetch costs the queue build — a DEPENDENT second fetch, so that its chain of gathers is waited for again */
+            if (surf) {
+                HitRec h2 = h; h2.u = h.u + sf.hitPoint.x * (float)(ra.spp - 1u) * 1.0e-30f; h2.v = h.v + sf.hitNormal.y * (float)(ra.spp - 1u) * 1.0e-30f;
+                h2.prim = h.prim + (__float_as_uint(sf.hitPoint.z) == 0x7fc12345u ? 1u : 0u);
+                Surface sf2;
+                if (fetch_surface<false, false>(sc, ra, h2, primary_dir(ra, px, py, i), false, acc, sf2, st)) sf = sf2;
+            }
+#endif
             if (surf) light_loops<CountOctPolicy, false>(sc, ra, px, py, sf, 0u, acc, cp, st);
             if (i == 0) { sf0 = sf; surf0 = surf; }
         }
@@ -1568,6 +1576,9 @@ __global__ __launch_bounds__(kBlock) RTR_RESOLVE_ATTR void k_resolve(DeviceScene
  * light_sample_pos) and the sums are formed in the same order, so the image is the one k_resolve writes, bit for bit (tests: both
  * forms against the oracle).  A round holds at most CAP items and 32 steps; longer light lists take more rounds.  Only the
  * framebuffer-only launch has this form: with the unshadowed image asked for every sample's BRDF is an output and nothing is sparse. */
+#ifndef RTR_EXP_DOUBLE_FETCH_GEN
+#define RTR_EXP_DOUBLE_FETCH_GEN 0
+#endif
 #ifndef RTR_EXP_DOUBLE_FETCH
 #define RTR_EXP_DOUBLE_FETCH 0
 #endif
